@@ -1,0 +1,172 @@
+"""ctypes binding of libboxdreamer_hip.so (the C ABI in include/boxdreamer_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, this raises.  PyTorch is used
+only for device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libboxdreamer_hip.so")
+
+DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
+PREC_BF16, PREC_F16, PREC_BF16X3 = 0, 1, 2
+PREC_NAMES = {"bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16x3": PREC_BF16X3}
+ACT_NONE, ACT_GELU = 0, 1
+
+_ERR = {-1: "BD_ERR_SHAPE", -2: "BD_ERR_DTYPE", -3: "BD_ERR_ALIGN", -4: "BD_ERR_WORKSPACE", -5: "BD_ERR_NULL"}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("a_plane", C.c_int64),
+                ("W", C.c_void_p), ("ldw", C.c_int64), ("w_plane", C.c_int64),
+                ("bias", C.c_void_p),
+                ("resid", C.c_void_p), ("ldr", C.c_int64),
+                ("addtab", C.c_void_p), ("tab_rows", C.c_int),
+                ("out", C.c_void_p), ("ldo", C.c_int64), ("out_plane", C.c_int64),
+                ("out_f32", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("act", C.c_int),
+                ("rpg_in", C.c_int), ("rpg_out", C.c_int), ("row_off", C.c_int)]
+
+
+class Linear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p)]
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [("ln1_w", C.c_void_p), ("ln1_b", C.c_void_p), ("ln2_w", C.c_void_p), ("ln2_b", C.c_void_p),
+                ("qkv", Linear), ("proj", Linear), ("fc1", Linear), ("fc2", Linear),
+                ("q_norm_w", C.c_void_p), ("k_norm_w", C.c_void_p)]
+
+
+class DinoWeights(C.Structure):
+    _fields_ = [("depth", C.c_int), ("dim", C.c_int), ("heads", C.c_int), ("n_prefix", C.c_int),
+                ("grid", C.c_int), ("patch", C.c_int), ("kpad", C.c_int),
+                ("ln_eps", C.c_float),
+                ("patch_embed", Linear),
+                ("pos_patch", C.c_void_p), ("prefix_tokens", C.c_void_p),
+                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
+                ("blocks", C.POINTER(BlockWeights))]
+
+
+class BetrWeights(C.Structure):
+    _fields_ = [("depth", C.c_int), ("dim", C.c_int), ("heads", C.c_int), ("grid", C.c_int),
+                ("patch", C.c_int), ("box_dim", C.c_int), ("kpad", C.c_int),
+                ("ln_eps", C.c_float), ("adapter_ln_eps", C.c_float), ("rms_eps", C.c_float),
+                ("adapter_fc1", Linear), ("adapter_fc2", Linear), ("bbox_emb", Linear), ("bbox_proj", Linear),
+                ("pos_table", C.c_void_p), ("query_token", C.c_void_p),
+                ("blocks", C.POINTER(BlockWeights))]
+
+
+class TraceRecord(C.Structure):
+    _fields_ = [("kind", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ms", C.c_float)]
+
+
+EXPORTS = [
+    "bd_abi_version", "bd_target_arch", "bd_gemm", "bd_layernorm", "bd_qk_rmsnorm", "bd_attention",
+    "bd_im2col_images", "bd_patchify_heatmaps", "bd_write_prefix_tokens", "bd_query_substitute",
+    "bd_gather_query_tokens", "bd_unpatchify_sigmoid", "bd_decode_topk",
+    "bd_encoder_workspace_bytes", "bd_encoder_forward", "bd_decoder_workspace_bytes", "bd_decoder_forward",
+    "bd_trace_begin", "bd_trace_end",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: the gfx950 HIP kernels are not built. Run "
+            "`python -m boxdreamer_amd.build` (or __graft_entry__.build()). There is no CPU/PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}")
+    i, i64, vp, f, sz = C.c_int, C.c_int64, C.c_void_p, C.c_float, C.c_size_t
+    lib.bd_abi_version.restype = i
+    lib.bd_target_arch.restype = C.c_char_p
+    lib.bd_gemm.argtypes = [C.POINTER(GemmArgs), i, vp]
+    lib.bd_layernorm.argtypes = [vp, i64, vp, vp, f, vp, i64, vp, i64, i, i, i, i, i, i, vp]
+    lib.bd_qk_rmsnorm.argtypes = [vp, i64, vp, vp, f, i, i, i, i, vp]
+    lib.bd_attention.argtypes = [vp, i64, vp, i64, i, i, i, i, f, i, vp]
+    lib.bd_im2col_images.argtypes = [vp, i, vp, i64, i, i, i, i, i, vp]
+    lib.bd_patchify_heatmaps.argtypes = [vp, i, vp, i64, i, i, i, i, i, i, vp]
+    lib.bd_write_prefix_tokens.argtypes = [vp, vp, i, i, i, i, vp]
+    lib.bd_query_substitute.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
+    lib.bd_gather_query_tokens.argtypes = [vp, vp, vp, i64, i, i, i, i, i, vp]
+    lib.bd_unpatchify_sigmoid.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    lib.bd_decode_topk.argtypes = [vp, i, i, i, i, vp, vp, vp, vp]
+    lib.bd_encoder_workspace_bytes.argtypes = [C.POINTER(DinoWeights), i, i]
+    lib.bd_encoder_workspace_bytes.restype = sz
+    lib.bd_encoder_forward.argtypes = [C.POINTER(DinoWeights), vp, i, i, i, vp, vp, i64, vp, sz, i, vp]
+    lib.bd_decoder_workspace_bytes.argtypes = [C.POINTER(BetrWeights), i, i, i]
+    lib.bd_decoder_workspace_bytes.restype = sz
+    lib.bd_decoder_forward.argtypes = [C.POINTER(BetrWeights), vp, i, vp, i64, vp, i, i, i, vp, vp, vp, sz, i, vp]
+    lib.bd_trace_begin.argtypes = [i]
+    lib.bd_trace_end.argtypes = [C.POINTER(TraceRecord), i]
+    if lib.bd_abi_version() != 1:
+        raise HipLibraryError("libboxdreamer_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        raise HipLibraryError(f"{what} rejected its arguments: {_ERR.get(rc, rc)}")
+    raise HipLibraryError(f"{what} failed with hipError_t {rc}")
+
+
+def prec_id(prec) -> int:
+    if isinstance(prec, int):
+        return prec
+    try:
+        return PREC_NAMES[prec]
+    except KeyError:
+        raise ValueError(f"unknown precision {prec!r}; choose from {sorted(PREC_NAMES)}") from None
+
+
+def op_dtype(prec) -> torch.dtype:
+    return torch.float16 if prec_id(prec) == PREC_F16 else torch.bfloat16
+
+
+def planes(prec) -> int:
+    return 2 if prec_id(prec) == PREC_BF16X3 else 1
+
+
+def dtype_id(t: torch.Tensor) -> int:
+    try:
+        return {torch.bfloat16: DTYPE_BF16, torch.float16: DTYPE_F16, torch.float32: DTYPE_F32}[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported input dtype {t.dtype} (bf16 / fp16 / fp32)") from None
+
+
+def ptr(t) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise HipLibraryError("the HIP path needs device tensors (got a CPU tensor); there is no CPU fallback")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise HipLibraryError("no HIP device visible: BoxDreamer's MI355X path cannot run (no CPU fallback)")

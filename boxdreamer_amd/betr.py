@@ -1,0 +1,159 @@
+"""Decoder plugin: `BETR` with the reference's constructor, parameter names (so reference
+checkpoints load with strict=True) and forward signature
+(/root/reference/src/models/modules/backbone/betr.py:11-437), backed by `bd_decoder_forward`.
+
+Only the released configuration is on the MI355X hot path: pose_representation='bb8',
+bbox_representation='heatmap', use_pretrained=True.  Inference only.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+from torch import nn
+
+from . import _lib, hip_ops, pack
+
+
+class _Norm(nn.Module):
+    """Parameter container named like nn.LayerNorm / LlamaRMSNorm (blocks.py:35-56)."""
+
+    def __init__(self, n, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(n))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, d_in, d_hidden, d_out):
+        super().__init__()
+        self.fc1 = nn.Linear(d_in, d_hidden)
+        self.fc2 = nn.Linear(d_hidden, d_out)
+
+
+class _Attention(nn.Module):
+    """Parameters of blocks.py:208-241 (qkv, q_norm, k_norm, proj)."""
+
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.q_norm = _Norm(dim // heads, bias=False)
+        self.k_norm = _Norm(dim // heads, bias=False)
+        self.proj = nn.Linear(dim, dim)
+
+
+class SelfAttentionBlock(nn.Module):
+    """Parameters of blocks.py:808-874 (norm1, attn, norm2, mlp)."""
+
+    def __init__(self, hidden_size, num_heads, mlp_ratio=4.0):
+        super().__init__()
+        self.norm1 = _Norm(hidden_size)
+        self.attn = _Attention(hidden_size, num_heads)
+        self.norm2 = _Norm(hidden_size)
+        self.mlp = _Mlp(hidden_size, int(hidden_size * mlp_ratio), hidden_size)
+
+
+class BETR(nn.Module):
+    """Box Estimation TRansformer on MI355X (HIP kernels behind the reference interface)."""
+
+    def __init__(self, d_model=512, nhead=8, num_decoder_layers=6, **kwargs):
+        super().__init__()
+        self.d_model, self.nhead, self.att_depth = d_model, nhead, num_decoder_layers
+        self.decoder_only = kwargs["decoder_only"]
+        self.patch_size = kwargs["patch_size"]
+        self.img_size = kwargs["img_size"]
+        self.nvs_supervision = kwargs.get("nvs_supervision", False)
+        self.ray_supervision = kwargs.get("ray_supervision", False)
+        self.use_mask = kwargs.get("use_mask", False)
+        self.patchify_rays = kwargs.get("patchify_rays", False)
+        self.pose_representation = kwargs.get("pose_representation", "bb8")
+        self.bbox_representation = kwargs.get("bbox_representation", "voting")
+        self.diff_emb = kwargs["diff_emb"]
+        self.use_pretrained = kwargs["use_pretrained"]
+        assert self.nvs_supervision or self.ray_supervision, "At least one supervision should be True"
+        if (self.pose_representation != "bb8" or self.bbox_representation != "heatmap"
+                or not self.use_pretrained or self.nvs_supervision):
+            raise NotImplementedError(
+                "the MI355X path implements the released configuration only: pose_representation='bb8', "
+                "bbox_representation='heatmap', use_pretrained=True, nvs_supervision=False")
+        self.box_dim = 8
+        self.cat_dim = 3 + 8
+        self.hip_precision = kwargs.get("hip_precision", os.environ.get("BOXDREAMER_HIP_PREC", "bf16"))
+
+        self.attn = nn.Sequential(*[SelfAttentionBlock(d_model, nhead) for _ in range(num_decoder_layers)])
+        self.bbox_proj = nn.Linear(d_model, self.patch_size ** 2 * 8)
+        self.input_transform = _Mlp(d_model, d_model, d_model)
+        self.norm = nn.Module()          # LayerNorm(elementwise_affine=False): no parameters (betr.py:161)
+        self.bbox_learnable_query = nn.Parameter(torch.zeros(1, d_model))
+        self.bbox_emb = nn.Linear(self.patch_size ** 2 * 8, d_model)
+
+        self._packed = {}
+        self._ws = None
+        self.last_logits = None
+
+    # -- packed-weight cache invalidation
+    def _apply(self, fn, *a, **k):
+        self._packed = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = {}
+        return super().load_state_dict(*a, **k)
+
+    def _weights(self, device, prec) -> pack.Packed:
+        key = (str(device), _lib.prec_id(prec))
+        if key not in self._packed:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            self._packed[key] = pack.pack_betr(sd, prec, device, self.nhead, self.patch_size, self.img_size)
+        return self._packed[key]
+
+    # -- reference helpers kept for API compatibility (host-side, tiny)
+    def patchify(self, imgs, c):
+        p = self.patch_size
+        h = w = imgs.shape[2] // p
+        x = imgs.reshape(imgs.shape[0], c, h, p, w, p)
+        return torch.einsum("nchpwq->nhwpqc", x).reshape(imgs.shape[0], h * w, p ** 2 * c)
+
+    def unpatchify(self, x, c):
+        p = self.patch_size
+        h = w = int(x.shape[1] ** 0.5)
+        x = x.reshape(x.shape[0], h, w, p, p, c)
+        return torch.einsum("nhwpqc->nchpwq", x).reshape(x.shape[0], c, h * p, h * p)
+
+    @torch.no_grad()
+    def forward(self, pose_feat, rgbs=None, masks=None, pretrain_rgb_feat=None, image_masks=None):
+        """pose_feat (B,T,8,H,W) in [-1,1]; rgbs (B,T,3,H,W) (shape check only); masks (B,T) bool, one query
+        view per sample; pretrain_rgb_feat (B,T,P,C) from the encoder.  Returns (B,8,H,W) fp32 in [-1,1]."""
+        assert rgbs is not None, "rgbs input should not be None"
+        B, T, _, H, W = rgbs.shape
+        assert H == W == self.img_size, f"H and W should be equal to img_size {self.img_size}, got {H}x{W}"
+        if pretrain_rgb_feat is None:
+            raise NotImplementedError("the MI355X path requires pretrained RGB features (use_pretrained=True)")
+        _lib.require_gpu()
+        lib = _lib.load()
+        dev = pose_feat.device
+        prec = self.hip_precision
+        pid = _lib.prec_id(prec)
+        w = self._weights(dev, prec).struct
+        P, D = w.grid * w.grid, w.dim
+        if masks.dtype != torch.bool or masks.shape != (B, T):
+            raise ValueError("masks must be a (B, T) bool tensor")
+        query_idx = masks.to(torch.int32).argmax(dim=1).to(torch.int32).contiguous()
+        tagged = getattr(pretrain_rgb_feat, "_bd_feats16", None)
+        if tagged is not None and tagged[1] == pid:
+            feats16 = tagged[0]
+        else:   # features from somewhere else: cast/split here (glue, off the default path)
+            feats16 = hip_ops.to_operand(pretrain_rgb_feat.reshape(B * T * P, D).float(), prec)
+        pose_feat = pose_feat.contiguous()
+        need = lib.bd_decoder_workspace_bytes(w, B, T, pid)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        logits = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)
+        heat = torch.empty_like(logits)
+        _lib.check(lib.bd_decoder_forward(w, _lib.ptr(pose_feat), _lib.dtype_id(pose_feat), _lib.ptr(feats16),
+                                          B * T * P * D if _lib.planes(prec) == 2 else 0, _lib.ptr(query_idx), B, T, H,
+                                          _lib.ptr(logits), _lib.ptr(heat), _lib.ptr(self._ws), self._ws.numel(), pid,
+                                          _lib.stream()), "bd_decoder_forward")
+        self.last_logits = logits
+        return heat

@@ -1,0 +1,58 @@
+// Shared device-side definitions for the BoxDreamer gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/boxdreamer_hip.h"
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 f16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+// 16-byte register quantum for global/LDS moves (a native vector: HIP's struct uint4 defeats SROA
+// and lands staging registers in scratch)
+typedef __attribute__((__vector_size__(16))) unsigned int u128;
+
+// 16-bit MFMA operand types.  Both run v_mfma_f32_32x32x16_* at the same rate; the C/D
+// fragment layout is dtype-independent (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+template <class T> struct Op16;
+template <> struct Op16<__bf16> {
+    typedef bf16x8 vec8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Op16<_Float16> {
+    typedef f16x8 vec8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <class T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+template <class T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+
+template <class T> __device__ __forceinline__ typename Op16<T>::vec8 as_vec8(u128 u);
+template <> __device__ __forceinline__ bf16x8 as_vec8<__bf16>(u128 u) { return __builtin_bit_cast(bf16x8, u); }
+template <> __device__ __forceinline__ f16x8 as_vec8<_Float16>(u128 u) { return __builtin_bit_cast(f16x8, u); }
+
+// load one element of a runtime-typed input tensor (bf16 / f16 / f32) as fp32
+__device__ __forceinline__ float load_any(const void* p, size_t i, int dtype) {
+    if (dtype == BD_DTYPE_F32) return ((const float*)p)[i];
+    if (dtype == BD_DTYPE_BF16) return (float)((const __bf16*)p)[i];
+    return (float)((const _Float16*)p)[i];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// trace.hip
+int bd_trace_open(hipStream_t s, int kind, int M, int N, int K);
+void bd_trace_close(hipStream_t s, int slot);
+
+#define BD_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

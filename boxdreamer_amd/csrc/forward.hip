@@ -1,0 +1,212 @@
+// Whole-path entry points: the DINOv2 encoder (DinoV2Wrapper.predict) and the BETR decoder
+// (BETR.forward) as straight-line sequences of kernel launches on the caller's stream.
+// No allocation, no synchronisation, no state: the caller provides one workspace blob that is
+// carved here (256-byte aligned slices).
+#include "bd_common.h"
+
+namespace {
+
+struct Carver {
+    unsigned char* base;
+    size_t off;
+    void* take(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+inline int planes_of(int prec) { return prec == BD_PREC_BF16X3 ? 2 : 1; }
+
+struct BlockBufs {
+    float* x;        // fp32 residual stream [M, D]
+    void* xn;        // 16-bit LN output     [M, D]
+    void* qkv;       // 16-bit               [M, 3D]
+    void* ao;        // 16-bit attention out [M, D]
+    void* h;         // 16-bit MLP hidden    [M, 4D]
+};
+
+inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const bd_linear& lin, int64_t ldw, int N,
+                              void* out, int64_t ldo, int64_t out_plane, int out_f32, int M, int K, int act) {
+    bd_gemm_args g{};
+    g.A = A; g.lda = lda; g.a_plane = a_plane;
+    g.W = lin.w; g.ldw = ldw; g.w_plane = (int64_t)N * ldw;
+    g.bias = lin.b;
+    g.out = out; g.ldo = ldo; g.out_plane = out_plane; g.out_f32 = out_f32;
+    g.M = M; g.N = N; g.K = K; g.act = act;
+    return g;
+}
+
+#define BD_TRY(expr) do { int rc__ = (expr); if (rc__ != BD_OK) return rc__; } while (0)
+
+// One pre-LN transformer block: x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x))).
+// BETR: blocks.py:876-886 (+ q/k RMSNorm :257); DINOv2: layers/block.py:89-114 (LayerScale folded).
+int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, int seq, int D, int heads,
+              float ln_eps, float rms_eps, int prec, void* stream) {
+    const int hd = D / heads;
+    const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D, p4D = (int64_t)M * 4 * D;
+    BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
+    {
+        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, 0, M, D, BD_ACT_NONE);
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    if (w.q_norm_w) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, prec, stream));
+    BD_TRY(bd_attention(b.qkv, p3D, b.ao, pD, batch, seq, heads, hd, 1.0f / sqrtf((float)hd), prec, stream));
+    {
+        bd_gemm_args g = gemm_args(b.ao, D, pD, w.proj, D, D, b.x, D, 0, 1, M, D, BD_ACT_NONE);
+        g.resid = b.x; g.ldr = D;
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    BD_TRY(bd_layernorm(b.x, D, w.ln2_w, w.ln2_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
+    {
+        bd_gemm_args g = gemm_args(b.xn, D, pD, w.fc1, D, 4 * D, b.h, 4 * D, p4D, 0, M, D, BD_ACT_GELU);
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    {
+        bd_gemm_args g = gemm_args(b.h, 4 * D, p4D, w.fc2, 4 * D, D, b.x, D, 0, 1, M, 4 * D, BD_ACT_NONE);
+        g.resid = b.x; g.ldr = D;
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    return BD_OK;
+}
+
+BlockBufs carve_block(Carver& c, int64_t M, int D, int np) {
+    BlockBufs b;
+    b.x = (float*)c.take((size_t)M * D * 4);
+    b.xn = c.take((size_t)M * D * 2 * np);
+    b.qkv = c.take((size_t)M * 3 * D * 2 * np);
+    b.ao = c.take((size_t)M * D * 2 * np);
+    b.h = c.take((size_t)M * 4 * D * 2 * np);
+    return b;
+}
+
+struct EncBufs { void* a_patch; BlockBufs blk; size_t bytes; };
+EncBufs carve_encoder(const bd_dino_weights* w, int n, int prec, void* ws) {
+    Carver c{(unsigned char*)ws, 0};
+    const int np = planes_of(prec), P = w->grid * w->grid;
+    EncBufs e;
+    e.a_patch = c.take((size_t)n * P * w->kpad * 2 * np);
+    e.blk = carve_block(c, (int64_t)n * (P + w->n_prefix), w->dim, np);
+    e.bytes = c.off + 256;
+    return e;
+}
+
+struct DecBufs { void *a_heat, *t1, *qtok; float *t2, *rgb, *proj; BlockBufs blk; size_t bytes; };
+DecBufs carve_decoder(const bd_betr_weights* w, int B, int T, int prec, void* ws) {
+    Carver c{(unsigned char*)ws, 0};
+    const int np = planes_of(prec), P = w->grid * w->grid, D = w->dim;
+    const int64_t Mb = (int64_t)B * T * P, Mq = (int64_t)B * P;
+    const int F = w->patch * w->patch * w->box_dim;
+    DecBufs d;
+    d.a_heat = c.take((size_t)Mb * w->kpad * 2 * np);
+    d.t1 = c.take((size_t)Mb * D * 2 * np);
+    d.t2 = (float*)c.take((size_t)Mb * D * 4);
+    d.rgb = (float*)c.take((size_t)Mb * D * 4);
+    d.qtok = c.take((size_t)Mq * D * 2 * np);
+    d.proj = (float*)c.take((size_t)Mq * F * 4);
+    d.blk = carve_block(c, Mb, D, np);
+    d.bytes = c.off + 256;
+    return d;
+}
+
+inline bool bad_prec(int prec) { return prec != BD_PREC_BF16 && prec != BD_PREC_F16 && prec != BD_PREC_BF16X3; }
+
+}  // namespace
+
+extern "C" int bd_abi_version(void) { return BD_ABI_VERSION; }
+extern "C" const char* bd_target_arch(void) { return "gfx950"; }
+
+extern "C" size_t bd_encoder_workspace_bytes(const bd_dino_weights* w, int n_images, int prec) {
+    if (!w || n_images <= 0 || bad_prec(prec)) return 0;
+    return carve_encoder(w, n_images, prec, nullptr).bytes;
+}
+
+extern "C" int bd_encoder_forward(const bd_dino_weights* w, const void* images, int img_dtype, int n_images,
+                                  int size, float* feats32, void* feats16, int64_t feats16_plane, void* workspace,
+                                  size_t workspace_bytes, int prec, void* stream) {
+    if (!w || !images || !workspace || !w->blocks || (!feats32 && !feats16)) return BD_ERR_NULL;
+    if (bad_prec(prec)) return BD_ERR_DTYPE;
+    if (n_images <= 0 || size != w->grid * w->patch || w->dim % w->heads || w->kpad % 64 ||
+        w->kpad < 3 * w->patch * w->patch)
+        return BD_ERR_SHAPE;
+    if ((uintptr_t)workspace & 255) return BD_ERR_ALIGN;
+    const EncBufs e = carve_encoder(w, n_images, prec, workspace);
+    if (workspace_bytes < e.bytes) return BD_ERR_WORKSPACE;
+    const int P = w->grid * w->grid, D = w->dim, tpi = P + w->n_prefix;
+    const int Mp = n_images * P, Md = n_images * tpi;
+
+    // K1+K2: normalise + im2col, then the patch-embed GEMM scattering rows b*P+p -> b*tpi+n_prefix+p and
+    // adding the (pre-resampled) positional table  (vision_transformer.py:213-232, patch_embed.py:65-75)
+    BD_TRY(bd_im2col_images(images, img_dtype, e.a_patch, (int64_t)Mp * w->kpad, n_images, size, w->patch, w->kpad,
+                            prec, stream));
+    {
+        bd_gemm_args g = gemm_args(e.a_patch, w->kpad, (int64_t)Mp * w->kpad, w->patch_embed, w->kpad, D, e.blk.x, D, 0,
+                                   1, Mp, w->kpad, BD_ACT_NONE);
+        g.addtab = w->pos_patch; g.tab_rows = P;
+        g.rpg_in = P; g.rpg_out = tpi; g.row_off = w->n_prefix;
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    BD_TRY(bd_write_prefix_tokens(e.blk.x, w->prefix_tokens, n_images, tpi, w->n_prefix, D, stream));
+    for (int i = 0; i < w->depth; ++i)
+        BD_TRY(run_block(w->blocks[i], e.blk, Md, n_images, tpi, D, w->heads, w->ln_eps, 0.f, prec, stream));
+    // final LayerNorm on the patch tokens only (vision_transformer.py:263-267)
+    BD_TRY(bd_layernorm(e.blk.x, D, w->norm_w, w->norm_b, w->ln_eps, feats16, feats16_plane, feats32, D, Mp, D, P, tpi,
+                        w->n_prefix, prec, stream));
+    return BD_OK;
+}
+
+extern "C" size_t bd_decoder_workspace_bytes(const bd_betr_weights* w, int B, int T, int prec) {
+    if (!w || B <= 0 || T <= 0 || bad_prec(prec)) return 0;
+    return carve_decoder(w, B, T, prec, nullptr).bytes;
+}
+
+extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_feat, int in_dtype, const void* feats16,
+                                  int64_t feats16_plane, const int32_t* query_idx, int B, int T, int size,
+                                  float* logits, float* heat, void* workspace, size_t workspace_bytes, int prec,
+                                  void* stream) {
+    if (!w || !bbox_feat || !feats16 || !query_idx || !workspace || !w->blocks || (!logits && !heat)) return BD_ERR_NULL;
+    if (bad_prec(prec)) return BD_ERR_DTYPE;
+    if (B <= 0 || T <= 0 || size != w->grid * w->patch || w->dim % w->heads || w->kpad % 64 || w->box_dim != 8 ||
+        w->kpad < w->patch * w->patch * w->box_dim)
+        return BD_ERR_SHAPE;
+    if ((uintptr_t)workspace & 255) return BD_ERR_ALIGN;
+    const DecBufs d = carve_decoder(w, B, T, prec, workspace);
+    if (workspace_bytes < d.bytes) return BD_ERR_WORKSPACE;
+    const int P = w->grid * w->grid, D = w->dim, F = w->patch * w->patch * w->box_dim;
+    const int Mb = B * T * P, Mq = B * P;
+    const int64_t pD = (int64_t)Mb * D;
+
+    // K6 adapter: LN_noaffine(fc2(gelu(fc1(feat))))  (betr.py:313-317)
+    {
+        bd_gemm_args g = gemm_args(feats16, D, feats16_plane, w->adapter_fc1, D, D, d.t1, D, pD, 0, Mb, D, BD_ACT_GELU);
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    {
+        bd_gemm_args g = gemm_args(d.t1, D, pD, w->adapter_fc2, D, D, d.t2, D, 0, 1, Mb, D, BD_ACT_NONE);
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    BD_TRY(bd_layernorm(d.t2, D, nullptr, nullptr, w->adapter_ln_eps, nullptr, 0, d.rgb, D, Mb, D, 0, 0, 0, prec, stream));
+    // K7+K8: heatmap patch embedding fused with  + rgb + pos  (betr.py:324-329, 367-399)
+    BD_TRY(bd_patchify_heatmaps(bbox_feat, in_dtype, d.a_heat, (int64_t)Mb * w->kpad, B * T, w->box_dim, size, w->patch,
+                                w->kpad, prec, stream));
+    {
+        bd_gemm_args g = gemm_args(d.a_heat, w->kpad, (int64_t)Mb * w->kpad, w->bbox_emb, w->kpad, D, d.blk.x, D, 0, 1,
+                                   Mb, w->kpad, BD_ACT_NONE);
+        g.addtab = w->pos_table; g.tab_rows = P;
+        g.resid = d.rgb; g.ldr = D;
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    BD_TRY(bd_query_substitute(d.blk.x, d.rgb, w->pos_table, w->query_token, query_idx, B, T, P, D, stream));
+    // K9: joint self-attention over all T*P tokens of a sample
+    for (int i = 0; i < w->depth; ++i)
+        BD_TRY(run_block(w->blocks[i], d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, prec, stream));
+    // K10: head on the query view's tokens (no final norm, betr.py:298-306)
+    BD_TRY(bd_gather_query_tokens(d.blk.x, query_idx, d.qtok, (int64_t)Mq * D, B, T, P, D, prec, stream));
+    {
+        bd_gemm_args g = gemm_args(d.qtok, D, (int64_t)Mq * D, w->bbox_proj, D, F, d.proj, F, 0, 1, Mq, D, BD_ACT_NONE);
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    BD_TRY(bd_unpatchify_sigmoid(d.proj, logits, heat, B, w->box_dim, size, w->patch, stream));
+    return BD_OK;
+}

@@ -1,0 +1,218 @@
+// Data-movement kernels either side of the GEMMs (HBM-bound): image normalise + im2col,
+// heatmap patchify, token-row bookkeeping, unpatchify + sigmoid.
+#include "bd_common.h"
+
+namespace {
+
+template <class T, int NS>
+__device__ __forceinline__ void store8(T* dst, int64_t plane, const float (&v)[8]) {
+    typedef typename Op16<T>::vec8 vec8;
+    vec8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hi[j] = from_f32<T>(v[j]);
+        if (NS == 2) lo[j] = from_f32<T>(v[j] - to_f32<T>(hi[j]));
+    }
+    *(vec8*)dst = hi;
+    if (NS == 2) *(vec8*)(dst + plane) = lo;
+}
+
+// one thread per 8-wide chunk of an output row [n*grid*grid, kpad]; k = c*p*p + py*p + px
+template <class T, int NS>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ img, int dtype, void* __restrict__ out_,
+                                                     int64_t plane, int n_images, int size, int patch, int kpad) {
+    T* out = (T*)out_;
+    const int grid = size / patch, pp = patch * patch, kreal = 3 * pp, cpr = kpad / 8;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n_images * grid * grid * cpr;
+    if (t >= total) return;
+    const int kc = (int)(t % cpr);
+    const int64_t row = t / cpr;
+    const int gx = (int)(row % grid), gy = (int)((row / grid) % grid);
+    const int64_t n = row / (grid * grid);
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = kc * 8 + j;
+        float y = 0.f;
+        if (k < kreal) {
+            const int c = k / pp, rem = k % pp, py = rem / patch, px = rem % patch;
+            const int64_t src = ((n * 3 + c) * size + gy * patch + py) * size + gx * patch + px;
+            y = (load_any(img, src, dtype) - mean[c]) / stdv[c];   // encoder/dinov2.py:45-46
+        }
+        v[j] = y;
+    }
+    store8<T, NS>(out + row * kpad + kc * 8, plane, v);
+}
+
+// BETR.patchify: chunk j of a row holds the `channels` (= 8) values of pixel (py, px), j = py*p + px
+template <class T, int NS>
+__global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ heat, int dtype, void* __restrict__ out_,
+                                                       int64_t plane, int n_images, int size, int patch, int kpad) {
+    T* out = (T*)out_;
+    const int grid = size / patch, pp = patch * patch, cpr = kpad / 8;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n_images * grid * grid * cpr;
+    if (t >= total) return;
+    const int j = (int)(t % cpr);
+    const int64_t row = t / cpr;
+    const int gx = (int)(row % grid), gy = (int)((row / grid) % grid);
+    const int64_t n = row / (grid * grid);
+    float v[8];
+    if (j < pp) {
+        const int py = j / patch, px = j % patch;
+        const int64_t pix = (int64_t)(gy * patch + py) * size + gx * patch + px;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = load_any(heat, (n * 8 + c) * (int64_t)size * size + pix, dtype);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = 0.f;
+    }
+    store8<T, NS>(out + row * kpad + j * 8, plane, v);
+}
+
+__global__ __launch_bounds__(256) void prefix_kernel(float* __restrict__ x, const float* __restrict__ prefix,
+                                                     int n_images, int tpi, int n_prefix, int dim) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n_images * n_prefix * dim;
+    if (t >= total) return;
+    const int d = (int)(t % dim), pfx = (int)((t / dim) % n_prefix);
+    const int64_t n = t / ((int64_t)dim * n_prefix);
+    x[(n * tpi + pfx) * dim + d] = prefix[pfx * dim + d];
+}
+
+__global__ __launch_bounds__(256) void query_sub_kernel(float* __restrict__ x, const float* __restrict__ rgb,
+                                                        const float* __restrict__ pos, const float* __restrict__ qtok,
+                                                        const int32_t* __restrict__ qidx, int B, int T, int P, int dim) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)B * P * dim;
+    if (t >= total) return;
+    const int d = (int)(t % dim), tok = (int)((t / dim) % P);
+    const int b = (int)(t / ((int64_t)dim * P));
+    const int64_t row = ((int64_t)b * T + qidx[b]) * P + tok;
+    // betr.py:288-290 + :367,399:  (query + rgb) + pos  -- same association order as the reference
+    x[row * dim + d] = (qtok[d] + rgb[row * dim + d]) + pos[tok * dim + d];
+}
+
+template <class T, int NS>
+__global__ __launch_bounds__(256) void gather_query_kernel(const float* __restrict__ x, const int32_t* __restrict__ qidx,
+                                                           void* __restrict__ out_, int64_t plane, int B, int T_, int P, int dim) {
+    T* out = (T*)out_;
+    const int cpr = dim / 8;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)B * P * cpr;
+    if (t >= total) return;
+    const int c = (int)(t % cpr), tok = (int)((t / cpr) % P);
+    const int b = (int)(t / ((int64_t)cpr * P));
+    const float* src = x + (((int64_t)b * T_ + qidx[b]) * P + tok) * dim + c * 8;
+    const float4 a = *(const float4*)src, bb = *(const float4*)(src + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, bb.x, bb.y, bb.z, bb.w};
+    store8<T, NS>(out + ((int64_t)b * P + tok) * dim + c * 8, plane, v);
+}
+
+// one thread per output pixel (b, y, x): reads the pixel's 8 consecutive channel features, writes 8 planes
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ proj, float* __restrict__ logits,
+                                                         float* __restrict__ heat, int B, int size, int patch) {
+    const int grid = size / patch, F = patch * patch * 8;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)B * size * size;
+    if (t >= total) return;
+    const int x = (int)(t % size), y = (int)((t / size) % size);
+    const int64_t b = t / ((int64_t)size * size);
+    const int gx = x / patch, px = x % patch, gy = y / patch, py = y % patch;
+    const float* src = proj + (b * grid * grid + gy * grid + gx) * F + (py * patch + px) * 8;
+    const float4 a = *(const float4*)src, c = *(const float4*)(src + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        const int64_t o = ((b * 8 + ch) * size + y) * size + x;
+        if (logits) logits[o] = v[ch];
+        if (heat) heat[o] = 2.0f * (1.0f / (1.0f + expf(-v[ch]))) - 1.0f;   // betr.py:432-435
+    }
+}
+
+inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace
+
+#define BD_PREC_SWITCH(FN, ...)                                                        \
+    switch (prec) {                                                                    \
+        case BD_PREC_BF16: hipLaunchKernelGGL((FN<__bf16, 1>), __VA_ARGS__); break;    \
+        case BD_PREC_F16: hipLaunchKernelGGL((FN<_Float16, 1>), __VA_ARGS__); break;   \
+        case BD_PREC_BF16X3: hipLaunchKernelGGL((FN<__bf16, 2>), __VA_ARGS__); break;  \
+        default: return BD_ERR_DTYPE;                                                  \
+    }
+
+extern "C" int bd_im2col_images(const void* images, int img_dtype, void* out16, int64_t out_plane, int n_images,
+                                int size, int patch, int kpad, int prec, void* stream) {
+    if (!images || !out16) return BD_ERR_NULL;
+    if (n_images <= 0 || size % patch || kpad % 8 || kpad < 3 * patch * patch) return BD_ERR_SHAPE;
+    if (img_dtype < 0 || img_dtype > 2) return BD_ERR_DTYPE;
+    const int grid = size / patch;
+    const int64_t total = (int64_t)n_images * grid * grid * (kpad / 8);
+    hipStream_t s = (hipStream_t)stream;
+    BD_PREC_SWITCH(im2col_kernel, dim3(nblk(total)), dim3(256), 0, s, images, img_dtype, out16, out_plane,
+                   n_images, size, patch, kpad)
+    BD_CHECK_LAUNCH();
+    return BD_OK;
+}
+
+extern "C" int bd_patchify_heatmaps(const void* heat, int in_dtype, void* out16, int64_t out_plane, int n_images,
+                                    int channels, int size, int patch, int kpad, int prec, void* stream) {
+    if (!heat || !out16) return BD_ERR_NULL;
+    if (channels != 8 || n_images <= 0 || size % patch || kpad % 8 || kpad < patch * patch * 8) return BD_ERR_SHAPE;
+    if (in_dtype < 0 || in_dtype > 2) return BD_ERR_DTYPE;
+    const int grid = size / patch;
+    const int64_t total = (int64_t)n_images * grid * grid * (kpad / 8);
+    hipStream_t s = (hipStream_t)stream;
+    BD_PREC_SWITCH(patchify_kernel, dim3(nblk(total)), dim3(256), 0, s, heat, in_dtype, out16, out_plane,
+                   n_images, size, patch, kpad)
+    BD_CHECK_LAUNCH();
+    return BD_OK;
+}
+
+extern "C" int bd_write_prefix_tokens(float* x, const float* prefix, int n_images, int tokens_per_image,
+                                      int n_prefix, int dim, void* stream) {
+    if (!x || !prefix) return BD_ERR_NULL;
+    if (n_images <= 0 || n_prefix <= 0 || n_prefix > tokens_per_image || dim <= 0) return BD_ERR_SHAPE;
+    const int64_t total = (int64_t)n_images * n_prefix * dim;
+    hipLaunchKernelGGL(prefix_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, prefix, n_images,
+                       tokens_per_image, n_prefix, dim);
+    BD_CHECK_LAUNCH();
+    return BD_OK;
+}
+
+extern "C" int bd_query_substitute(float* x, const float* rgb, const float* pos, const float* query_token,
+                                   const int32_t* query_idx, int B, int T, int P, int dim, void* stream) {
+    if (!x || !rgb || !pos || !query_token || !query_idx) return BD_ERR_NULL;
+    if (B <= 0 || T <= 0 || P <= 0 || dim <= 0) return BD_ERR_SHAPE;
+    const int64_t total = (int64_t)B * P * dim;
+    hipLaunchKernelGGL(query_sub_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, rgb, pos,
+                       query_token, query_idx, B, T, P, dim);
+    BD_CHECK_LAUNCH();
+    return BD_OK;
+}
+
+extern "C" int bd_gather_query_tokens(const float* x, const int32_t* query_idx, void* out16, int64_t out_plane,
+                                      int B, int T, int P, int dim, int prec, void* stream) {
+    if (!x || !query_idx || !out16) return BD_ERR_NULL;
+    if (B <= 0 || T <= 0 || P <= 0 || dim % 8) return BD_ERR_SHAPE;
+    const int64_t total = (int64_t)B * P * (dim / 8);
+    hipStream_t s = (hipStream_t)stream;
+    BD_PREC_SWITCH(gather_query_kernel, dim3(nblk(total)), dim3(256), 0, s, x, query_idx, out16, out_plane, B, T, P, dim)
+    BD_CHECK_LAUNCH();
+    return BD_OK;
+}
+
+extern "C" int bd_unpatchify_sigmoid(const float* proj, float* logits, float* heat, int B, int channels, int size,
+                                     int patch, void* stream) {
+    if (!proj || (!logits && !heat)) return BD_ERR_NULL;
+    if (channels != 8 || B <= 0 || size % patch) return BD_ERR_SHAPE;
+    const int64_t total = (int64_t)B * size * size;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, proj, logits, heat,
+                       B, size, patch);
+    BD_CHECK_LAUNCH();
+    return BD_OK;
+}

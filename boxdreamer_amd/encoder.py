@@ -1,0 +1,162 @@
+"""Encoder plugin: the reference's `PretrainedModelWrapper` / `DinoV2Wrapper` surface
+(/root/reference/src/models/modules/encoder/base.py:3-13, encoder/dinov2.py:6-60) backed by the
+HIP DINOv2 forward (`bd_encoder_forward`).
+
+Differences that are deliberate:
+  * weights are never fetched with `torch.hub` (no network; and the hub model's xformers path is the
+    CUDA dependency being replaced).  `ckpt_path` is a local state_dict file (.pth/.pt/.safetensors)
+    with the hub key names, or cfg['state_dict'] / cfg['synthetic_seed'] supply tensors directly;
+  * `predict` returns fp32 features and tags the tensor with the operand-dtype copy the decoder consumes.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import _lib, pack, synth
+
+_ARCH = {  # model_type -> (dim, depth, heads)
+    "dinov2_vits14_reg": (384, 12, 6),
+    "dinov2_vitb14_reg": (768, 12, 12),
+    "dinov2_vitl14_reg": (1024, 24, 16),
+}
+
+
+class PretrainedModelWrapper:
+    """Mirror of encoder/base.py:3-13 (a plain object, not an nn.Module: encoder weights are
+    outside the checkpoint)."""
+
+    def __init__(self, model_name_or_path):
+        self.model_name_or_path = model_name_or_path
+        self.model = None
+
+    def load_model(self, device="cuda"):
+        raise NotImplementedError("Subclasses should implement this method")
+
+    def predict(self, input_tensor):
+        raise NotImplementedError
+
+
+class DinoV2Encoder:
+    """DINOv2 ViT-*/14 + 4 registers, inference only, on the HIP library."""
+
+    def __init__(self, state_dict: dict, heads: int, patch: int = 14, prec="bf16"):
+        self.sd = {k: v.detach().float() for k, v in state_dict.items()}
+        self.heads, self.patch, self.prec = heads, patch, prec
+        self.device = torch.device("cpu")
+        self._packed = {}       # (device, prec, img_size) -> pack.Packed
+        self._ws = None
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self._packed.clear()
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        return iter(())          # frozen: nothing to hand to an optimiser
+
+    def _weights(self, size: int, prec) -> pack.Packed:
+        key = (str(self.device), _lib.prec_id(prec), size)
+        if key not in self._packed:
+            self._packed[key] = pack.pack_dino(self.sd, prec, self.device, self.heads, self.patch, size)
+        return self._packed[key]
+
+    @torch.no_grad()
+    def patch_tokens(self, images: torch.Tensor, prec=None):
+        """images (N, 3, S, S) in [0, 1] (bf16/fp16/fp32, NCHW) -> (feats32 (N, P, C), feats16)."""
+        _lib.require_gpu()
+        lib = _lib.load()
+        prec = self.prec if prec is None else prec
+        if images.device != self.device:
+            self.to(images.device)
+        images = images.contiguous()
+        n, c, size, size2 = images.shape
+        if c != 3 or size != size2 or size % self.patch:
+            raise ValueError(f"expected (N,3,S,S) with S % {self.patch} == 0, got {tuple(images.shape)}")
+        pk = self._weights(size, prec)
+        w = pk.struct
+        P, D = w.grid * w.grid, w.dim
+        need = lib.bd_encoder_workspace_bytes(w, n, _lib.prec_id(prec))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != images.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=images.device)
+        feats32 = torch.empty((n, P, D), dtype=torch.float32, device=images.device)
+        np_ = _lib.planes(prec)
+        feats16 = torch.empty((np_, n * P, D) if np_ == 2 else (n * P, D), dtype=_lib.op_dtype(prec),
+                              device=images.device)
+        _lib.check(lib.bd_encoder_forward(w, _lib.ptr(images), _lib.dtype_id(images), n, size, _lib.ptr(feats32),
+                                          _lib.ptr(feats16), n * P * D if np_ == 2 else 0, _lib.ptr(self._ws),
+                                          self._ws.numel(), _lib.prec_id(prec), _lib.stream()), "bd_encoder_forward")
+        return feats32, feats16
+
+
+def _load_state_dict_file(path: str) -> dict:
+    if path.endswith((".safetensors", ".safetensor")):
+        from safetensors.torch import load_file
+        return load_file(path)
+    sd = torch.load(path, map_location="cpu")
+    return sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+
+
+class DinoV2Wrapper(PretrainedModelWrapper):
+    """Same constructor / API as encoder/dinov2.py:6-60."""
+
+    def __init__(self, ckpt_path=None, cfg=None):
+        super().__init__(model_name_or_path="dinov2")
+        cfg = cfg or {}
+        self.ckpt_path = ckpt_path
+        self.model_type = cfg.get("model_type", "dinov2_vits14_reg")
+        assert self.model_type in ["dinov2_vits14_reg", "dinov2_vitb14_reg", "dinov2_vitl14_reg",
+                                   "dinov2_vitg14_reg"]
+        if self.model_type not in _ARCH:
+            raise NotImplementedError("dinov2_vitg14_reg (SwiGLU FFN) is outside the MI355X hot path")
+        self.freeze = cfg.get("freeze", True)
+        self.cfg = cfg
+        self.device = None
+        self.prec = cfg.get("hip_precision", os.environ.get("BOXDREAMER_HIP_PREC", "bf16"))
+        self.load_model()
+
+    def get_device(self):
+        return self.device
+
+    def to_device(self, device):
+        self.model = self.model.to(device)
+        self.device = device
+
+    def load_model(self, device="cuda"):
+        dim, depth, heads = _ARCH[self.model_type]
+        path = self.ckpt_path or os.environ.get("BOXDREAMER_DINO_WEIGHTS")
+        if "state_dict" in self.cfg:
+            sd = self.cfg["state_dict"]
+        elif path is not None and os.path.isfile(path):
+            print(f"Loading model from {path}")
+            sd = _load_state_dict_file(path)
+        elif "synthetic_seed" in self.cfg:
+            sd = synth.dino_state_dict(seed=int(self.cfg["synthetic_seed"]), depth=self.cfg.get("depth", depth),
+                                       dim=dim, nheads=heads)
+        else:
+            raise FileNotFoundError(
+                "DINOv2 weights: give encoder.dino.ckpt_path (or $BOXDREAMER_DINO_WEIGHTS) pointing at a local "
+                f"{self.model_type} state_dict file; torch.hub download is not available on this path")
+        self.model = DinoV2Encoder(sd, heads=heads, prec=self.prec)
+        if torch.cuda.is_available():
+            self.model.to(device)
+            self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        else:
+            self.device = torch.device("cpu")
+
+    def predict(self, input_tensor):
+        """(B,T,3,H,W) or (N,3,H,W) in [0,1] -> x_norm_patchtokens (B,T,P,C) / (N,P,C), fp32."""
+        flag = False
+        if input_tensor.dim() == 5:
+            B, T = input_tensor.shape[:2]
+            input_tensor = input_tensor.flatten(0, 1)
+            flag = True
+        with torch.no_grad():
+            feats32, feats16 = self.model.patch_tokens(input_tensor, self.prec)
+            ret = feats32.view(B, T, *feats32.shape[1:]) if flag else feats32
+            ret._bd_feats16 = (feats16, _lib.prec_id(self.prec))     # hand-off to BETR without a re-cast
+            return ret

@@ -1,0 +1,140 @@
+"""Thin tensor-level wrappers over the C ABI (one function per exported operator).
+
+Used by the GPU parity tests and by the module mirrors.  All tensors must live on the HIP device;
+every call is enqueued on torch's current stream.  In the "bf16x3" mode a 16-bit activation is a
+stacked pair [2, rows, cols] (hi plane, lo plane).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, planes, prec_id, ptr, stream
+
+
+def _alloc16(rows: int, cols: int, prec, device) -> torch.Tensor:
+    shape = (2, rows, cols) if planes(prec) == 2 else (rows, cols)
+    return torch.empty(shape, dtype=_lib.op_dtype(prec), device=device)
+
+
+def _plane(t: torch.Tensor, prec) -> int:
+    return t[0].numel() if planes(prec) == 2 else 0
+
+
+def to_operand(x: torch.Tensor, prec) -> torch.Tensor:
+    """fp32 [rows, cols] -> operand tensor (test helper; torch ops, not on the product path)."""
+    dt = _lib.op_dtype(prec)
+    hi = x.to(dt)
+    if planes(prec) == 1:
+        return hi.contiguous()
+    return torch.stack([hi, (x.float() - hi.float()).to(dt)]).contiguous()
+
+
+def from_operand(t: torch.Tensor, prec) -> torch.Tensor:
+    return t.float() if planes(prec) == 1 else t[0].float() + t[1].float()
+
+
+def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, addtab=None, out=None,
+         out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0)):
+    """out[map(r)] = act(A W^T + bias) + addtab[r % rows(addtab)] + resid[map(r)]."""
+    lib = _lib.load()
+    np_ = planes(prec)
+    A2 = a16[0] if np_ == 2 else a16
+    W2 = w16[0] if np_ == 2 else w16
+    M, K = A2.shape
+    N = n if n is not None else W2.shape[0]
+    rows_out = out_rows if out_rows is not None else M
+    if out is None:
+        out = (torch.empty((rows_out, N), dtype=torch.float32, device=A2.device) if out_f32
+               else _alloc16(rows_out, N, prec, A2.device))
+    g = _lib.GemmArgs()
+    g.A, g.lda, g.a_plane = ptr(a16), A2.stride(0), _plane(a16, prec)
+    g.W, g.ldw, g.w_plane = ptr(w16), W2.stride(0), _plane(w16, prec)
+    g.bias = ptr(bias)
+    g.resid, g.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
+    g.addtab, g.tab_rows = ptr(addtab), (addtab.shape[0] if addtab is not None else 0)
+    o2 = out if (out_f32 or np_ == 1) else out[0]
+    g.out, g.ldo, g.out_plane, g.out_f32 = ptr(out), o2.stride(0), (0 if out_f32 else _plane(out, prec)), int(out_f32)
+    g.M, g.N, g.K, g.act = M, N, K, act
+    g.rpg_in, g.rpg_out, g.row_off = rpg
+    check(lib.bd_gemm(C.byref(g), prec_id(prec), stream()), "bd_gemm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, *, prec="bf16", want16=True, want32=False, rows=None, rpg=(0, 0, 0)):
+    lib = _lib.load()
+    M = rows if rows is not None else x.shape[0]
+    cols = x.shape[1]
+    o16 = _alloc16(M, cols, prec, x.device) if want16 else None
+    o32 = torch.empty((M, cols), dtype=torch.float32, device=x.device) if want32 else None
+    check(lib.bd_layernorm(ptr(x), x.stride(0), ptr(gamma), ptr(beta), eps, ptr(o16),
+                           _plane(o16, prec) if o16 is not None else 0, ptr(o32), cols, M, cols, *rpg,
+                           prec_id(prec), stream()), "bd_layernorm")
+    return o16, o32
+
+
+def qk_rmsnorm_(qkv16, wq, wk, eps, heads, head_dim, *, prec="bf16"):
+    lib = _lib.load()
+    q2 = qkv16[0] if planes(prec) == 2 else qkv16
+    rows = q2.numel() // (3 * heads * head_dim)
+    check(lib.bd_qk_rmsnorm(ptr(qkv16), _plane(qkv16, prec), ptr(wq), ptr(wk), eps, rows, heads, head_dim,
+                            prec_id(prec), stream()), "bd_qk_rmsnorm")
+    return qkv16
+
+
+def attention(qkv16, batch, seq, heads, head_dim, scale, *, prec="bf16"):
+    lib = _lib.load()
+    dev = qkv16.device
+    out = _alloc16(batch * seq, heads * head_dim, prec, dev)
+    check(lib.bd_attention(ptr(qkv16), _plane(qkv16, prec), ptr(out), _plane(out, prec), batch, seq, heads,
+                           head_dim, scale, prec_id(prec), stream()), "bd_attention")
+    return out
+
+
+def im2col_images(images, patch=14, kpad=640, *, prec="bf16"):
+    lib = _lib.load()
+    images = images.contiguous()
+    n, size = images.shape[0], images.shape[-1]
+    grid = size // patch
+    out = _alloc16(n * grid * grid, kpad, prec, images.device)
+    check(lib.bd_im2col_images(ptr(images), _lib.dtype_id(images), ptr(out), _plane(out, prec), n, size, patch,
+                               kpad, prec_id(prec), stream()), "bd_im2col_images")
+    return out
+
+
+def patchify_heatmaps(heat, patch=14, kpad=1600, *, prec="bf16"):
+    lib = _lib.load()
+    heat = heat.contiguous()
+    n, c, size = heat.shape[0], heat.shape[1], heat.shape[-1]
+    grid = size // patch
+    out = _alloc16(n * grid * grid, kpad, prec, heat.device)
+    check(lib.bd_patchify_heatmaps(ptr(heat), _lib.dtype_id(heat), ptr(out), _plane(out, prec), n, c, size, patch,
+                                   kpad, prec_id(prec), stream()), "bd_patchify_heatmaps")
+    return out
+
+
+def unpatchify_sigmoid(proj, B, size=224, patch=14):
+    lib = _lib.load()
+    logits = torch.empty((B, 8, size, size), dtype=torch.float32, device=proj.device)
+    heat = torch.empty_like(logits)
+    check(lib.bd_unpatchify_sigmoid(ptr(proj), ptr(logits), ptr(heat), B, 8, size, patch, stream()),
+          "bd_unpatchify_sigmoid")
+    return logits, heat
+
+
+def decode_topk(heat, k=20, want_idx=True):
+    """heat: fp32 [..., H, W] in [-1, 1] -> (kp_px [..., 2], kp_norm [..., 2], idx [..., k] int32)."""
+    lib = _lib.load()
+    heat = heat.contiguous()
+    if heat.dtype != torch.float32:
+        heat = heat.float()
+    H, W = heat.shape[-2:]
+    lead = heat.shape[:-2]
+    n = heat.numel() // (H * W)
+    kp = torch.empty((n, 2), dtype=torch.float32, device=heat.device)
+    kn = torch.empty_like(kp)
+    idx = torch.empty((n, k), dtype=torch.int32, device=heat.device) if want_idx else None
+    check(lib.bd_decode_topk(ptr(heat), n, H, W, k, ptr(kp), ptr(kn), ptr(idx), stream()), "bd_decode_topk")
+    return kp.reshape(*lead, 2), kn.reshape(*lead, 2), (idx.reshape(*lead, k) if want_idx else None)

@@ -1,0 +1,187 @@
+"""Weight re-packing at load time (pure host logic; unit-tested on CPU).
+
+fp32 checkpoint tensors (reference key names) -> device arrays the HIP kernels consume:
+  * nn.Linear weights stay [N, K] (both GEMM operands are K-contiguous), K zero-padded to a
+    multiple of 64, cast to the operand dtype; BF16X3 stores two planes (hi, lo = bf16(w - hi));
+  * DINOv2 LayerScale gamma is folded into proj / fc2 (weight rows and bias) in fp32 before the cast
+    (src/models/sources/DINOv2/layers/block.py:89-114, layer_scale.py:26-27);
+  * input-independent tables are precomputed once: the DINOv2 positional embedding resampled
+    37x37 -> grid x grid (vision_transformer.py:179-211) and BETR's 2-D sincos table
+    (pos_encodiong.py:125-213, consumed at betr.py:357-364).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def split_planes(w: torch.Tensor, prec) -> torch.Tensor:
+    """fp32 -> operand dtype; BF16X3 -> stacked (hi, lo) planes, shape [2, ...]."""
+    dt = _lib.op_dtype(prec)
+    hi = w.to(dt)
+    if _lib.planes(prec) == 1:
+        return hi.contiguous()
+    lo = (w - hi.float()).to(dt)
+    return torch.stack([hi, lo]).contiguous()
+
+
+def pack_linear_weight(weight: torch.Tensor, prec, kpad: int | None = None,
+                       row_scale: torch.Tensor | None = None) -> torch.Tensor:
+    """[N, K] fp32 -> [planes?, N, Kpad] operand dtype (row_scale folds LayerScale)."""
+    w = weight.detach().float().reshape(weight.shape[0], -1)
+    if row_scale is not None:
+        w = w * row_scale.detach().float().reshape(-1, 1)
+    k = w.shape[1]
+    kp = kpad if kpad is not None else round_up(k, 64)
+    if kp % 64 or kp < k:
+        raise ValueError(f"bad kpad {kp} for K={k}")
+    if kp != k:
+        w = F.pad(w, (0, kp - k))
+    return split_planes(w, prec)
+
+
+def pack_bias(bias: torch.Tensor, row_scale: torch.Tensor | None = None) -> torch.Tensor:
+    b = bias.detach().float()
+    if row_scale is not None:
+        b = b * row_scale.detach().float()
+    return b.contiguous()
+
+
+def sincos_table(dim: int, grid: int) -> torch.Tensor:
+    """BETR positional table (grid*grid, dim): token i*grid+j -> [sin(j w)|cos(j w)|sin(i w)|cos(i w)],
+    w_d = 10000^(-d/(dim/4)), float64 math then fp32 (pos_encodiong.py:139-150, 200-213)."""
+    q = dim // 4
+    omega = 1.0 / 10000 ** (torch.arange(q, dtype=torch.float64) / q)
+    idx = torch.arange(grid, dtype=torch.float64)
+    ii = idx.repeat_interleave(grid).reshape(-1, 1)
+    jj = idx.repeat(grid).reshape(-1, 1)
+    ow, oh = jj * omega, ii * omega
+    return torch.cat([ow.sin(), ow.cos(), oh.sin(), oh.cos()], dim=1).float().contiguous()
+
+
+def dino_pos_tables(pos_embed: torch.Tensor, cls_token: torch.Tensor, register_tokens: torch.Tensor | None,
+                    grid: int):
+    """(prefix_tokens [1+nreg, C], pos_patch [grid*grid, C]) in fp32.
+
+    prepare_tokens_with_masks (vision_transformer.py:213-232): cls gets pos[0] added, patch tokens get
+    the bicubic+antialias resample of pos[1:]; registers are inserted afterwards without pos."""
+    pe = pos_embed.detach().float()
+    n = pe.shape[1] - 1
+    dim = pe.shape[-1]
+    if n == grid * grid:
+        patch_pe = pe[0, 1:]
+    else:
+        m = int(math.sqrt(n))
+        if m * m != n:
+            raise ValueError("pos_embed is not square")
+        patch_pe = F.interpolate(pe[:, 1:].reshape(1, m, m, dim).permute(0, 3, 1, 2), mode="bicubic",
+                                 antialias=True, size=(grid, grid))
+        patch_pe = patch_pe.permute(0, 2, 3, 1).reshape(-1, dim)
+    rows = [cls_token.detach().float().reshape(1, dim) + pe[0, :1]]
+    if register_tokens is not None:
+        rows.append(register_tokens.detach().float().reshape(-1, dim))
+    return torch.cat(rows, 0).contiguous(), patch_pe.contiguous()
+
+
+class Packed:
+    """Owns the device tensors behind a ctypes weight struct (keeps them alive)."""
+
+    def __init__(self):
+        self.tensors = []
+        self.struct = None
+        self.blocks = None
+
+    def keep(self, t: torch.Tensor, device) -> C.c_void_p:
+        t = t.to(device).contiguous()
+        self.tensors.append(t)
+        return C.c_void_p(t.data_ptr())
+
+    def linear(self, w: torch.Tensor, b: torch.Tensor, device) -> _lib.Linear:
+        return _lib.Linear(self.keep(w, device), self.keep(b, device))
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.tensors)
+
+
+def _pack_block(pk: Packed, sd: dict, p: str, prec, device, ls: bool, qk_norm: bool) -> _lib.BlockWeights:
+    g1 = sd[p + "ls1.gamma"] if ls else None
+    g2 = sd[p + "ls2.gamma"] if ls else None
+    bw = _lib.BlockWeights()
+    bw.ln1_w = pk.keep(sd[p + "norm1.weight"].float(), device)
+    bw.ln1_b = pk.keep(sd[p + "norm1.bias"].float(), device)
+    bw.ln2_w = pk.keep(sd[p + "norm2.weight"].float(), device)
+    bw.ln2_b = pk.keep(sd[p + "norm2.bias"].float(), device)
+    bw.qkv = pk.linear(pack_linear_weight(sd[p + "attn.qkv.weight"], prec), pack_bias(sd[p + "attn.qkv.bias"]), device)
+    bw.proj = pk.linear(pack_linear_weight(sd[p + "attn.proj.weight"], prec, row_scale=g1),
+                        pack_bias(sd[p + "attn.proj.bias"], g1), device)
+    bw.fc1 = pk.linear(pack_linear_weight(sd[p + "mlp.fc1.weight"], prec), pack_bias(sd[p + "mlp.fc1.bias"]), device)
+    bw.fc2 = pk.linear(pack_linear_weight(sd[p + "mlp.fc2.weight"], prec, row_scale=g2),
+                       pack_bias(sd[p + "mlp.fc2.bias"], g2), device)
+    if qk_norm:
+        bw.q_norm_w = pk.keep(sd[p + "attn.q_norm.weight"].float(), device)
+        bw.k_norm_w = pk.keep(sd[p + "attn.k_norm.weight"].float(), device)
+    return bw
+
+
+def pack_dino(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int = 224) -> Packed:
+    """DINOv2 ViT state_dict (hub key names) -> bd_dino_weights."""
+    pk = Packed()
+    dim = sd["cls_token"].shape[-1]
+    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    grid = img_size // patch
+    reg = sd.get("register_tokens")
+    prefix, pos_patch = dino_pos_tables(sd["pos_embed"], sd["cls_token"], reg, grid)
+    kpad = round_up(3 * patch * patch, 64)
+    blocks = (_lib.BlockWeights * depth)()
+    for i in range(depth):
+        blocks[i] = _pack_block(pk, sd, f"blocks.{i}.", prec, device, ls=f"blocks.{i}.ls1.gamma" in sd, qk_norm=False)
+    w = _lib.DinoWeights()
+    w.depth, w.dim, w.heads, w.n_prefix = depth, dim, heads, prefix.shape[0]
+    w.grid, w.patch, w.kpad = grid, patch, kpad
+    w.ln_eps = 1e-6                                              # vision_transformer.py:95
+    w.patch_embed = pk.linear(pack_linear_weight(sd["patch_embed.proj.weight"], prec, kpad=kpad),
+                              pack_bias(sd["patch_embed.proj.bias"]), device)
+    w.pos_patch = pk.keep(pos_patch, device)
+    w.prefix_tokens = pk.keep(prefix, device)
+    w.norm_w = pk.keep(sd["norm.weight"].float(), device)
+    w.norm_b = pk.keep(sd["norm.bias"].float(), device)
+    w.blocks = C.cast(blocks, C.POINTER(_lib.BlockWeights))
+    pk.struct, pk.blocks = w, blocks
+    return pk
+
+
+def pack_betr(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int = 224, box_dim: int = 8) -> Packed:
+    """BETR state_dict (reference key names, no 'decoder.' prefix) -> bd_betr_weights."""
+    pk = Packed()
+    dim = sd["bbox_learnable_query"].shape[-1]
+    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("attn."))
+    grid = img_size // patch
+    kpad = round_up(patch * patch * box_dim, 64)
+    blocks = (_lib.BlockWeights * depth)()
+    for i in range(depth):
+        blocks[i] = _pack_block(pk, sd, f"attn.{i}.", prec, device, ls=False, qk_norm=True)
+    w = _lib.BetrWeights()
+    w.depth, w.dim, w.heads, w.grid, w.patch, w.box_dim, w.kpad = depth, dim, heads, grid, patch, box_dim, kpad
+    w.ln_eps = 1e-5              # get_layernorm ignores its eps argument: blocks.py:805
+    w.adapter_ln_eps = 1e-6      # betr.py:161
+    w.rms_eps = 1e-6             # blocks.py:45
+    w.adapter_fc1 = pk.linear(pack_linear_weight(sd["input_transform.fc1.weight"], prec),
+                              pack_bias(sd["input_transform.fc1.bias"]), device)
+    w.adapter_fc2 = pk.linear(pack_linear_weight(sd["input_transform.fc2.weight"], prec),
+                              pack_bias(sd["input_transform.fc2.bias"]), device)
+    w.bbox_emb = pk.linear(pack_linear_weight(sd["bbox_emb.weight"], prec, kpad=kpad), pack_bias(sd["bbox_emb.bias"]), device)
+    w.bbox_proj = pk.linear(pack_linear_weight(sd["bbox_proj.weight"], prec), pack_bias(sd["bbox_proj.bias"]), device)
+    w.pos_table = pk.keep(sincos_table(dim, grid), device)
+    w.query_token = pk.keep(sd["bbox_learnable_query"].float().reshape(-1), device)
+    w.blocks = C.cast(blocks, C.POINTER(_lib.BlockWeights))
+    pk.struct, pk.blocks = w, blocks
+    return pk

@@ -1,0 +1,204 @@
+/*
+ * boxdreamer_hip.h -- C ABI of libboxdreamer_hip.so (gfx950 / MI355X only).
+ *
+ * The drop-in boundary for BoxDreamer's corner-heatmap inference path.  The reference is pure
+ * Python: its "native" boundary is the set of library calls it makes into CUDA-only packages
+ * and ATen.  Each entry point below cites the reference call it replaces
+ * (paths relative to the reference repo root).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host];
+ *   - the caller (PyTorch) owns every input / output / workspace buffer; the library never
+ *     allocates, frees, synchronises or keeps state between calls;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return 0 on success, a negative BD_ERR_* for bad arguments, a positive hipError_t if a
+ *     launch failed; no exceptions, no exit();
+ *   - re-entrant; one device per process in the multi-GPU sweep.
+ *
+ * Precision modes (`prec`): MFMA operands are 16-bit, accumulation / residual stream / norms /
+ * softmax are fp32.
+ *   BD_PREC_BF16    one v_mfma_f32_32x32x16_bf16 pass             (headline mode)
+ *   BD_PREC_F16     one v_mfma_f32_32x32x16_f16 pass              (4x finer operand rounding)
+ *   BD_PREC_BF16X3  split-bf16 (hi*hi + hi*lo + lo*hi), 3 passes  (strict parity mode)
+ * In BF16X3 every 16-bit activation / weight tensor is stored as two planes (hi, then lo at
+ * +plane elements); see DESIGN.md "data layout".
+ */
+#ifndef BOXDREAMER_HIP_H
+#define BOXDREAMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BD_ABI_VERSION 1
+
+#define BD_DTYPE_BF16 0
+#define BD_DTYPE_F16 1
+#define BD_DTYPE_F32 2
+
+#define BD_PREC_BF16 0
+#define BD_PREC_F16 1
+#define BD_PREC_BF16X3 2
+
+#define BD_OK 0
+#define BD_ERR_SHAPE (-1)
+#define BD_ERR_DTYPE (-2)
+#define BD_ERR_ALIGN (-3)
+#define BD_ERR_WORKSPACE (-4)
+#define BD_ERR_NULL (-5)
+
+#define BD_ACT_NONE 0
+#define BD_ACT_GELU 1 /* exact erf GELU (timm Mlp / vggsfm Mlp / DINOv2 Mlp all use nn.GELU()) */
+
+int bd_abi_version(void);
+const char* bd_target_arch(void); /* "gfx950" */
+
+/* ------------------------------------------------------------------------------------------
+ * Unit operators (used directly by the parity tests and composed by the forward entry points)
+ * ---------------------------------------------------------------------------------------- */
+
+/* out[map(r), :] = act(A[r,:] . W^T + bias) + addtab[r % tab_rows, :] + resid[map(r), :]
+ * Replaces every nn.Linear on the path (cuBLAS via ATen):
+ *   src/models/modules/backbone/utils/blocks.py:229,233 (qkv, proj), timm Mlp fc1/fc2 (blocks.py:859-867),
+ *   src/models/modules/backbone/betr.py:131-176 (bbox_emb, bbox_proj, input_transform),
+ *   src/models/sources/DINOv2/layers/attention.py:51-53, layers/mlp.py:29-31,
+ *   and the 14x14/s14 patch-embed conv as an im2col GEMM (layers/patch_embed.py:65,75).
+ * A: [M, K] 16-bit row-major (lda elements); W: [N, K] 16-bit row-major (nn.Linear layout).
+ * K must be a multiple of 64 (callers zero-pad); M, N arbitrary.
+ * map(r) = r if rpg_in == 0 else (r / rpg_in) * rpg_out + r % rpg_in + row_off. */
+typedef struct bd_gemm_args {
+    const void* A; int64_t lda; int64_t a_plane;   /* a_plane: elements between hi/lo planes (BF16X3) */
+    const void* W; int64_t ldw; int64_t w_plane;
+    const float* bias;                             /* [N] or NULL */
+    const float* resid; int64_t ldr;               /* fp32 [*, N] indexed by the OUTPUT row, or NULL */
+    const float* addtab; int tab_rows;             /* fp32 [tab_rows, N] or NULL */
+    void* out; int64_t ldo; int64_t out_plane;     /* 16-bit (operand dtype of `prec`) or fp32 */
+    int out_f32;                                   /* 1: fp32 output, 0: operand-dtype output */
+    int M, N, K;
+    int act;
+    int rpg_in, rpg_out, row_off;
+} bd_gemm_args;
+int bd_gemm(const bd_gemm_args* args /*[host]*/, int prec, void* stream);
+
+/* LayerNorm over the last dim (fp32 statistics), optional affine, fp32 input rows gathered by
+ * in_row(r) = r if rpg_in == 0 else (r / rpg_in) * rpg_out + r % rpg_in + row_off.
+ * Writes a 16-bit copy (next GEMM's A operand) and/or an fp32 copy.
+ * Replaces blocks.py:35-41 (LayerNorm, eps hard-wired to 1e-5 by get_layernorm blocks.py:790-805),
+ * betr.py:161,315 (adapter LayerNorm, no affine, eps 1e-6) and DINOv2 nn.LayerNorm eps 1e-6
+ * (vision_transformer.py:95,263). */
+int bd_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                 void* out16, int64_t out16_plane, float* out32, int64_t ldo, int rows, int cols,
+                 int rpg_in, int rpg_out, int row_off, int prec, void* stream);
+
+/* In-place q/k RMSNorm on a packed qkv tensor [rows, 3, heads, head_dim] (16-bit):
+ * q,k <- w * x * rsqrt(mean(x^2) + eps) in fp32.  Replaces LlamaRMSNorm, blocks.py:44-56,257. */
+int bd_qk_rmsnorm(void* qkv, int64_t plane, const float* wq, const float* wk, float eps, int rows,
+                  int heads, int head_dim, int prec, void* stream);
+
+/* Multi-head self-attention softmax(scale * Q K^T) V on packed qkv [batch, seq, 3, heads, head_dim]
+ * -> out [batch, seq, heads*head_dim] (16-bit).  head_dim in {64, 96}.
+ * Replaces flash_attn.flash_attn_func / F.scaled_dot_product_attention (blocks.py:259-285) and
+ * xformers.ops.memory_efficient_attention / the naive softmax path (DINOv2 layers/attention.py:56-89). */
+int bd_attention(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch, int seq,
+                 int heads, int head_dim, float scale, int prec, void* stream);
+
+/* (x - mean_c) / std_c, then 14x14 patches -> A operand rows [n*grid*grid, kpad], k = c*p*p + py*p + px,
+ * zero-padded to kpad.  Replaces encoder/dinov2.py:45-46,56 + the unfold inside the patch-embed conv. */
+int bd_im2col_images(const void* images, int img_dtype, void* out16, int64_t out_plane, int n_images,
+                     int size, int patch, int kpad, int prec, void* stream);
+
+/* BETR.patchify (betr.py:211-228): [n, c, size, size] -> [n*grid*grid, kpad], feature (py*p+px)*c + ch. */
+int bd_patchify_heatmaps(const void* heat, int in_dtype, void* out16, int64_t out_plane, int n_images,
+                         int channels, int size, int patch, int kpad, int prec, void* stream);
+
+/* Writes the n_prefix (cls+pos, registers) token rows of every image's token block
+ * (vision_transformer.py:219-230).  prefix: fp32 [n_prefix, dim]. */
+int bd_write_prefix_tokens(float* x, const float* prefix, int n_images, int tokens_per_image,
+                           int n_prefix, int dim, void* stream);
+
+/* Query-view substitution (betr.py:286-290 + :367-399): for every sample b the token rows of view
+ * query_idx[b] become query_token + rgb + pos.  x, rgb: fp32 [B*T*P, dim]; pos: [P, dim]. */
+int bd_query_substitute(float* x, const float* rgb, const float* pos, const float* query_token,
+                        const int32_t* query_idx, int B, int T, int P, int dim, void* stream);
+
+/* Gathers the query view's P token rows per sample (betr.py:303) and casts to the operand dtype. */
+int bd_gather_query_tokens(const float* x, const int32_t* query_idx, void* out16, int64_t out_plane,
+                           int B, int T, int P, int dim, int prec, void* stream);
+
+/* BETR.unpatchify + 2*sigmoid-1 (betr.py:230-247, 432-435): proj fp32 [B*P, p*p*c] ->
+ * logits, heat fp32 [B, c, size, size]. */
+int bd_unpatchify_sigmoid(const float* proj, float* logits, float* heat, int B, int channels, int size,
+                          int patch, void* stream);
+
+/* Heatmap corner decode (box_utils.py:75-110): per (b, c): top-k of (heat+1)/2 over size*size
+ * (ties: lower index first), corner = unweighted mean of the k integer (x, y).
+ * kp_px, kp_norm: fp32 [B*C, 2]; topk_idx: int32 [B*C, k] in selection order (may be NULL). */
+int bd_decode_topk(const float* heat, int n_maps, int height, int width, int k, float* kp_px,
+                   float* kp_norm, int32_t* topk_idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-path entry points
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bd_linear {
+    const void* w;       /* [N, Kpad] 16-bit, nn.Linear layout; BF16X3: hi plane then lo plane */
+    const float* b;      /* [N] */
+} bd_linear;
+
+typedef struct bd_block_weights {
+    const float* ln1_w; const float* ln1_b; const float* ln2_w; const float* ln2_b;
+    bd_linear qkv, proj, fc1, fc2;   /* DINO: LayerScale gamma pre-folded into proj / fc2 */
+    const float* q_norm_w; const float* k_norm_w;   /* [head_dim]; NULL for DINOv2 */
+} bd_block_weights;
+
+typedef struct bd_dino_weights {
+    int depth, dim, heads, n_prefix, grid, patch, kpad;
+    float ln_eps;
+    bd_linear patch_embed;           /* [dim, kpad] */
+    const float* pos_patch;          /* fp32 [grid*grid, dim] (resampled once at load) */
+    const float* prefix_tokens;      /* fp32 [n_prefix, dim]: cls+pos[0], registers */
+    const float* norm_w; const float* norm_b;
+    const bd_block_weights* blocks;  /* [host] array of `depth` */
+} bd_dino_weights;
+
+typedef struct bd_betr_weights {
+    int depth, dim, heads, grid, patch, box_dim, kpad;
+    float ln_eps, adapter_ln_eps, rms_eps;
+    bd_linear adapter_fc1, adapter_fc2, bbox_emb, bbox_proj;
+    const float* pos_table;          /* fp32 [grid*grid, dim] 2-D sincos */
+    const float* query_token;        /* fp32 [dim] */
+    const bd_block_weights* blocks;  /* [host] */
+} bd_betr_weights;
+
+/* DinoV2Wrapper.predict (encoder/dinov2.py:45-60): images [n_images, 3, size, size] in [0,1]
+ * -> x_norm_patchtokens.  feats32: fp32 [n_images*grid*grid, dim] (may be NULL);
+ * feats16: operand-dtype copy consumed by bd_decoder_forward (may be NULL). */
+size_t bd_encoder_workspace_bytes(const bd_dino_weights* w /*[host]*/, int n_images, int prec);
+int bd_encoder_forward(const bd_dino_weights* w /*[host]*/, const void* images, int img_dtype,
+                       int n_images, int size, float* feats32, void* feats16, int64_t feats16_plane,
+                       void* workspace, size_t workspace_bytes, int prec, void* stream);
+
+/* BETR.forward (betr.py:249-308): bbox_feat [B, T, c, size, size] in [-1,1], feats16 from the encoder,
+ * query_idx int32 [B] -> logits, heat fp32 [B, c, size, size]. */
+size_t bd_decoder_workspace_bytes(const bd_betr_weights* w /*[host]*/, int B, int T, int prec);
+int bd_decoder_forward(const bd_betr_weights* w /*[host]*/, const void* bbox_feat, int in_dtype,
+                       const void* feats16, int64_t feats16_plane, const int32_t* query_idx, int B,
+                       int T, int size, float* logits, float* heat, void* workspace,
+                       size_t workspace_bytes, int prec, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Launch tracing (measurement aid for bench.py; off by default; the only library state).
+ * Between bd_trace_begin and bd_trace_end every GEMM (kind 0: M,N,K) and attention (kind 1:
+ * M = batch*heads, N = seq, K = head_dim) launch is bracketed by HIP events on its stream.
+ * bd_trace_end synchronises those events, fills `out` [host] and returns the record count.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bd_trace_record { int kind, M, N, K; float ms; } bd_trace_record;
+int bd_trace_begin(int capacity);
+int bd_trace_end(bd_trace_record* out /*[host]*/, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOXDREAMER_HIP_H */

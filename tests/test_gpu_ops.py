@@ -1,0 +1,174 @@
+"""GPU parity: every exported HIP operator against the CPU oracle / plain torch fp32 on the same
+seeded inputs.  Calls go through the C ABI (ctypes); nothing here falls back to PyTorch compute."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from boxdreamer_amd import hip_ops, synth
+from oracle import boxdreamer_oracle as orc
+
+pytestmark = pytest.mark.gpu
+PRECS = ["bf16", "fp16", "bf16x3"]
+# operand rounding of the mode (relative); bf16x3 keeps ~16 mantissa bits
+EPS = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11, "bf16x3": 2.0 ** -15}
+
+
+def _rand(name, shape, std=1.0, seed=3):
+    return torch.from_numpy(synth.bell_np(name, shape, std, 0.0, seed).astype(np.float32))
+
+
+def _q(x, prec):
+    """round through the operand dtype (what the kernel actually multiplies)"""
+    return hip_ops.from_operand(hip_ops.to_operand(x, prec), prec)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (77, 1568, 768), (1000, 768, 3072)])
+def test_gemm_plain(hip, prec, M, N, K):
+    a, w, b = _rand("a", (M, K)), _rand("w", (N, K), 0.05), _rand("b", (N,), 0.1)
+    a16, w16 = hip_ops.to_operand(a.cuda(), prec), hip_ops.to_operand(w.cuda(), prec)
+    out = hip_ops.gemm(a16, w16, b.cuda(), prec=prec, out_f32=True)
+    ref = (_q(a, prec).double() @ _q(w, prec).double().t() + b.double()).float()
+    err = (out.cpu() - ref).abs().max().item()
+    # operands are exactly representable -> only fp32 accumulation order (and the dropped lo*lo term) differ
+    tol = 2e-5 * K ** 0.5 if prec != "bf16x3" else 2e-5 * K ** 0.5 + 1e-4
+    assert err < tol, (prec, err)
+    # transpose / layout detector: asymmetric operands, exact small integers
+    ai = torch.arange(M * K, dtype=torch.float32).reshape(M, K).remainder(7) - 3
+    wi = torch.arange(N * K, dtype=torch.float32).reshape(N, K).remainder(5) - 2
+    out = hip_ops.gemm(hip_ops.to_operand(ai.cuda(), prec), hip_ops.to_operand(wi.cuda(), prec), None, prec=prec,
+                       out_f32=True)
+    assert torch.equal(out.cpu(), ai @ wi.t())
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_gemm_epilogues(hip, prec):
+    M, N, K, P, TPI, OFF = 512, 256, 128, 256, 261, 5
+    a, w, b = _rand("a2", (M, K)), _rand("w2", (N, K), 0.05), _rand("b2", (N,), 0.1)
+    tab, res = _rand("tab", (P, N)), _rand("res", ((M // P) * TPI, N))
+    a16, w16 = hip_ops.to_operand(a.cuda(), prec), hip_ops.to_operand(w.cuda(), prec)
+    base = (_q(a, prec).double() @ _q(w, prec).double().t() + b.double()).float()
+    # gelu + 16-bit output
+    o = hip_ops.gemm(a16, w16, b.cuda(), prec=prec, act=1)
+    ref = F.gelu(base)
+    assert (hip_ops.from_operand(o, prec).cpu() - ref).abs().max().item() < 3e-3 * (EPS[prec] / 2.0 ** -8) + 2e-4
+    # row remap + table + residual, fp32 in-place style output
+    out_rows = (M // P) * TPI
+    buf = res.clone().cuda()
+    hip_ops.gemm(a16, w16, b.cuda(), prec=prec, out_f32=True, out=buf, resid=buf, addtab=tab.cuda(),
+                 rpg=(P, TPI, OFF), out_rows=out_rows)
+    exp = res.clone()
+    rows = torch.arange(M)
+    orow = (rows // P) * TPI + rows % P + OFF
+    exp[orow] = base + tab[rows % P] + res[orow]
+    assert (buf.cpu() - exp).abs().max().item() < 3e-4
+    untouched = torch.ones(out_rows, dtype=torch.bool); untouched[orow] = False
+    assert torch.equal(buf.cpu()[untouched], res[untouched])
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("affine,eps", [(True, 1e-5), (True, 1e-6), (False, 1e-6)])
+def test_layernorm(hip, prec, affine, eps):
+    x = _rand("lnx", (1001, 768), 2.0) + 0.3
+    g = _rand("lng", (768,), 0.1) + 1 if affine else None
+    b = _rand("lnb", (768,), 0.1) if affine else None
+    o16, o32 = hip_ops.layernorm(x.cuda(), g.cuda() if affine else None, b.cuda() if affine else None, eps,
+                                 prec=prec, want32=True)
+    ref = F.layer_norm(x, (768,), g, b, eps)
+    assert (o32.cpu() - ref).abs().max().item() < 2e-5
+    assert (hip_ops.from_operand(o16, prec).cpu() - ref).abs().max().item() < 8 * EPS[prec] + 1e-5
+    # gathered rows (DINO final norm drops 5 prefix tokens per 261)
+    o16, o32 = hip_ops.layernorm(x.cuda(), None, None, eps, prec=prec, want32=True, rows=3 * 256, rpg=(256, 261, 5))
+    idx = (torch.arange(768) // 256) * 261 + torch.arange(768) % 256 + 5
+    assert (o32.cpu() - F.layer_norm(x[idx], (768,), None, None, eps)).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("hd,heads", [(96, 8), (64, 12)])
+def test_qk_rmsnorm(hip, prec, hd, heads):
+    rows = 333
+    qkv = _rand("rmsq", (rows, 3, heads, hd), 1.5) + 0.1
+    wq, wk = _rand("wq", (hd,), 0.1) + 1, _rand("wk", (hd,), 0.1) + 1
+    t = hip_ops.to_operand(qkv.reshape(rows, -1).cuda(), prec)
+    hip_ops.qk_rmsnorm_(t, wq.cuda(), wk.cuda(), 1e-6, heads, hd, prec=prec)
+    got = hip_ops.from_operand(t, prec).cpu().reshape(rows, 3, heads, hd)
+    src = _q(qkv.reshape(rows, -1), prec).reshape(rows, 3, heads, hd)
+    tol = 8 * EPS[prec] + 1e-5
+    assert (got[:, 0] - orc._rmsnorm(src[:, 0], wq)).abs().max().item() < tol
+    assert (got[:, 1] - orc._rmsnorm(src[:, 1], wk)).abs().max().item() < tol
+    assert torch.equal(got[:, 2], src[:, 2])           # v untouched
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("batch,seq,heads,hd", [(2, 261, 12, 64), (2, 512, 8, 96), (1, 1536, 8, 96), (3, 70, 2, 64)])
+def test_attention(hip, prec, batch, seq, heads, hd):
+    qkv = _rand("attq", (batch, seq, 3, heads, hd), 1.0)
+    qkv[:, :, 0] *= 1.7                                            # non-trivial softmax
+    if seq >= 200:                                                 # force an online-softmax rescale late in the row
+        qkv[:, 150, 1] = qkv[:, 7, 0] * 3.0
+    t = hip_ops.to_operand(qkv.reshape(batch * seq, -1).cuda(), prec)
+    out = hip_ops.attention(t, batch, seq, heads, hd, hd ** -0.5, prec=prec)
+    got = hip_ops.from_operand(out, prec).cpu().reshape(batch, seq, heads, hd)
+    src = _q(qkv.reshape(batch * seq, -1), prec).reshape(batch, seq, 3, heads, hd).double()
+    q, k, v = (src[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = ((q @ k.transpose(-1, -2)) * hd ** -0.5).softmax(-1) @ v
+    ref = ref.permute(0, 2, 1, 3).float()
+    err = (got - ref).abs().max().item()
+    assert err < 6 * EPS[prec] * max(1.0, ref.abs().max().item()) + 2e-5, (prec, err)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_im2col_and_patchify(hip, prec):
+    data = synth.make_batch(seed=21, B=1, T=2)
+    img = data["images"][0]                                          # (2,3,224,224)
+    for dt in (torch.float32, torch.bfloat16):
+        a = hip_ops.im2col_images(img.to(dt).cuda(), prec=prec)
+        mean = torch.tensor(orc._IMAGENET_MEAN).view(1, 3, 1, 1)
+        std = torch.tensor(orc._IMAGENET_STD).view(1, 3, 1, 1)
+        xn = (img.to(dt).float() - mean) / std
+        cols = F.unfold(xn, 14, stride=14).transpose(1, 2).reshape(2 * 256, 588)
+        got = hip_ops.from_operand(a, prec).cpu()
+        assert torch.equal(got[:, 588:], torch.zeros(512, 52))
+        assert (got[:, :588] - cols).abs().max().item() < 8 * EPS[prec] * 3 + 1e-6
+    heat = data["bbox_feat"][0]                                      # (2,8,224,224)
+    a = hip_ops.patchify_heatmaps(heat.cuda(), prec=prec)
+    got = hip_ops.from_operand(a, prec).cpu()
+    ref = orc.patchify(heat, 14, 8).reshape(512, 1568)
+    assert torch.equal(got[:, 1568:], torch.zeros(512, 32))
+    assert (got[:, :1568] - ref).abs().max().item() < 2 * EPS[prec] + 1e-7
+
+
+def test_unpatchify_sigmoid(hip):
+    proj = _rand("proj", (2 * 256, 1568), 2.0)
+    logits, heat = hip_ops.unpatchify_sigmoid(proj.cuda(), 2)
+    ref = orc.unpatchify(proj.reshape(2, 256, 1568), 14, 8)
+    assert torch.equal(logits.cpu(), ref)
+    assert (heat.cpu() - (2 * torch.sigmoid(ref) - 1)).abs().max().item() < 5e-7
+
+
+def test_decode_topk(hip, golden_dir):
+    # adversarial plateaus (the fixture's construction, oracle/make_golden.py) + the reference's answers
+    u = torch.from_numpy(synth.uniform_np("unit.decode", (2, 8, 224 * 224), -1.0, 0.5, 5).astype(np.float32))
+    hm = u.reshape(2, 8, 224, 224).clone()
+    for b in range(2):
+        for c in range(8):
+            ys, n = 10 + 13 * c + b, (20 if c < 4 else 7)
+            hm[b, c, ys, 30:30 + n] = 1.0
+            if c >= 4:
+                hm[b, c, ys + 1, 100:113] = torch.linspace(0.9, 0.6, 13)
+    kp, kn, idx = hip_ops.decode_topk(hm.cuda())
+    g = np.load(f"{golden_dir}/unit_vectors.npz")
+    assert np.array_equal(kp.cpu().numpy(), g["decode_kp"])
+    assert np.abs(kn.cpu().numpy() - g["decode_norm_kp"]).max() < 1e-6
+    on, okp, oidx = orc.recover_bb8_corners(hm)
+    assert torch.equal(idx.cpu().long(), oidx)                       # same order, same tie rule
+    # random smooth-ish maps + exact ties across the rank-20 boundary (lower index must win)
+    hm2 = torch.from_numpy(synth.uniform_np("dec2", (4, 8, 224, 224), -1, 1, 9).astype(np.float32))
+    hm2[0, 0].fill_(0.25)                                            # all equal -> indices 0..19
+    hm2[1, 3, 100, 50:90] = 0.999                                    # 40-way tie over the boundary
+    kp, kn, idx = hip_ops.decode_topk(hm2.cuda())
+    _, okp, oidx = orc.recover_bb8_corners(hm2)
+    assert torch.equal(idx.cpu().long(), oidx)
+    assert torch.equal(kp.cpu(), okp)
+    assert idx[0, 0].cpu().tolist() == list(range(20))
