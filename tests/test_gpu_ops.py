@@ -52,7 +52,8 @@ def test_gemm_epilogues(hip, prec):
     # gelu + 16-bit output
     o = hip_ops.gemm(a16, w16, b.cuda(), prec=prec, act=1)
     ref = F.gelu(base)
-    assert (hip_ops.from_operand(o, prec).cpu() - ref).abs().max().item() < 3e-3 * (EPS[prec] / 2.0 ** -8) + 2e-4
+    # the 16-bit store rounds the result itself: half an operand ulp of the largest value
+    assert (hip_ops.from_operand(o, prec).cpu() - ref).abs().max().item() < EPS[prec] * max(1.0, ref.abs().max().item()) + 2e-4
     # row remap + table + residual, fp32 in-place style output
     out_rows = (M // P) * TPI
     buf = res.clone().cuda()
