@@ -52,12 +52,25 @@ def build_models(prec, device):
     return enc, dec.to(device).eval()
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: min(affinity, cgroup cpu.max quota).  (The GPU box shows 256 logical
+    CPUs but a 16-CPU cgroup quota; 256 torch threads there run 100x slower than 16.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(T: int, budget_s: float = 20.0) -> dict:
     """The oracle (CPU restatement of the reference arithmetic, torch fp32) timed on this box's host cores on a
     bounded sample of the same workload: single poses (B=1) with T views, full depth."""
     from boxdreamer_amd import synth
     from oracle import boxdreamer_oracle as orc
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     torch.set_num_threads(cores)
     bsd, dsd = synth.betr_state_dict(1234, 12), synth.dino_state_dict(4321, 12)
     data = synth.make_batch(seed=11, B=1, T=T)

@@ -1,0 +1,72 @@
+"""Corner decode + pose recovery with the reference's function names
+(/root/reference/src/models/utils/box_utils.py:14-199, heatmap branch only).
+
+`recover_bb8_corners` runs the HIP top-20 decode (bd_decode_topk); `recover_pose_from_bb8` moves the 8 corners,
+the 3-D box and K to the host ONCE per batch and solves PnP there (the reference does a D2H + two OpenCV
+calls per sample inside a Python loop, box_utils.py:139-199)."""
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import hip_ops, pnp
+
+_POOL = None
+
+
+def recover_bb8_corners(bbox_feat: torch.Tensor, bbox_representation: str = "heatmap"):
+    """bbox_feat: [B, T, H, W, 8] in [-1, 1] (the reference's layout, prediction_utils.py:65) ->
+    (normalised [B,T,8,2] in [-1,1], pixel [B,T,8,2])."""
+    if bbox_representation != "heatmap":
+        raise NotImplementedError("the MI355X path implements the heatmap representation only")
+    B, T, H, W, C = bbox_feat.shape
+    heat = bbox_feat.permute(0, 1, 4, 2, 3).contiguous().float()      # [B,T,8,H,W]
+    kp, kn, _ = hip_ops.decode_topk(heat, k=20, want_idx=False)
+    return kn, kp
+
+
+def recover_bb8_corners_chw(heat: torch.Tensor, want_idx: bool = False):
+    """Same decode on the decoder's native [B, 8, H, W] output (no permute round trip)."""
+    kp, kn, idx = hip_ops.decode_topk(heat, k=20, want_idx=want_idx)
+    return kn, kp, idx
+
+
+def solve_poses_host(kp_px: np.ndarray, bbox_3d: np.ndarray, K: np.ndarray, workers: int = 8) -> np.ndarray:
+    """kp_px [N,8,2], bbox_3d [N,8,3], K [N,3,3] (host) -> poses [N,4,4] ([R|t], zeros on failure)."""
+    global _POOL
+    n = kp_px.shape[0]
+    out = np.zeros((n, 4, 4), np.float32)
+
+    def one(i):
+        try:
+            ok, R, t = pnp.solve_pnp_iterative(bbox_3d[i], kp_px[i], K[i])
+        except Exception as e:  # noqa: BLE001  (reference: print and leave zeros, box_utils.py:192-195)
+            print(f"PnP failed due to exception: {e}")
+            return
+        if ok:
+            out[i, :3, :3] = R
+            out[i, :3, 3] = t
+            out[i, 3, 3] = 1.0
+
+    if n <= 2 or workers <= 1:
+        for i in range(n):
+            one(i)
+    else:
+        if _POOL is None:
+            _POOL = ThreadPoolExecutor(max_workers=workers)
+        list(_POOL.map(one, range(n)))
+    return out
+
+
+def recover_pose_from_bb8(bbox_feat, bbox_3d, K, bbox_representation="heatmap"):
+    """box_utils.py:113-199: (poses [B,T,4,4], normalised corners [B,T,8,2])."""
+    B, T = bbox_feat.shape[:2]
+    normalized_keypoints_2d, keypoints_2d = recover_bb8_corners(bbox_feat, bbox_representation)
+    kp = keypoints_2d.reshape(B * T, 8, 2).cpu().numpy()              # ONE device->host sync per batch
+    b3 = bbox_3d.float().reshape(B * T, 8, 3).cpu().numpy()
+    Kh = K.float()
+    Kh = (Kh.reshape(B * T, 3, 3) if Kh.dim() == 4 else Kh.reshape(1, 3, 3).expand(B * T, 3, 3)).cpu().numpy()
+    poses = torch.from_numpy(solve_poses_host(kp, b3, Kh)).reshape(B, T, 4, 4).to(bbox_feat.device)
+    return poses, normalized_keypoints_2d

@@ -1,0 +1,106 @@
+"""Model facade: `BoxDreamer(config).forward(data: dict) -> dict`, the drop-in boundary
+(/root/reference/src/models/BoxDreamerModel.py:21-384).  Same constructor input (`config["modules"]`),
+same batch-dict keys in and out, same `decoder.*` state_dict, same encoder-plugin API -- the internals call
+the gfx950 HIP library.  Only the released configuration (dino encoder, bb8 / heatmap) is implemented;
+tracker / matcher / dense mode / plucker rays are out of the hot path and raise.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .betr import BETR
+from .box_utils import recover_bb8_corners_chw, solve_poses_host
+from .config import setup_camera_params, validate_model_config
+from .encoder import DinoV2Wrapper
+
+
+def _get(cfg, key, default=None):
+    try:
+        return cfg[key]
+    except (KeyError, AttributeError, TypeError):
+        return getattr(cfg, key, default)
+
+
+class BoxDreamer(nn.Module):
+    """BoxDreamer model for predicting 3D object poses from multiple images (MI355X inference path)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        module_configs = dict(config["modules"])
+        self.use_matching = module_configs["use_matching"]
+        self.use_tracking = module_configs["use_tracking"]
+        self.use_keypoints = module_configs["use_keypoints"]
+        self.use_rgb = module_configs["use_rgb"]
+        self.use_pp = module_configs["use_pp"]
+        self.regression_intri = module_configs["regression_intri"]
+        self.roatation_type = module_configs["rotation_type"]
+        self.coordinate = module_configs["coordinate"]
+        self.pose_representation = module_configs["pose_representation"]
+        self.image_size = module_configs["decoder"]["img_size"]
+        self.patch_size = module_configs["decoder"]["patch_size"]
+        self.patchify_rays = module_configs["patchify_rays"]
+        module_configs = validate_model_config(module_configs)
+        self.bbox_representation = module_configs["bbox_representation"]
+        self.dense_cfg = module_configs.get("dense_cfg", None)
+        module_configs, self.camera_dim, self.rotation_length = setup_camera_params(module_configs)
+        self.module_configs = module_configs
+
+        if self.use_tracking:
+            raise NotImplementedError("Tracking is not supported yet")            # BoxDreamerModel.py:74-75
+        if self.use_matching:
+            raise NotImplementedError("LoFTR matching is outside the MI355X hot path")
+        if self.dense_cfg is not None and _get(self.dense_cfg, "enable", False):
+            raise NotImplementedError("dense-reference mode is a 'next' row (SURVEY.md §8 f4)")
+        if self.pose_representation != "bb8" or self.roatation_type is not None:
+            raise NotImplementedError("only pose_representation='bb8' (rotation_type null) is on the hot path")
+        self.tracker = None
+        self.matcher = None
+        if self.use_rgb:
+            name = module_configs["encoder"]["name"]
+            if name != "dino":
+                raise NotImplementedError(f"encoder '{name}' is not used by the released checkpoint; only 'dino'")
+            dino = module_configs["encoder"]["dino"]
+            self.rgb_encoder = DinoV2Wrapper(_get(dino, "ckpt_path"), dict(_get(dino, "cfg") or {}))
+        else:
+            raise NotImplementedError("use_rgb=False (from-scratch embeddings) is outside the hot path")
+        dec_cfg = {k: v for k, v in dict(module_configs["decoder"]).items()}
+        self.decoder = BETR(**dec_cfg)
+
+    def forward(self, data):
+        images = data["images"]
+        B, T = images.shape[:2]
+        query_idx = data["query_idx"]
+        camera_mask = torch.zeros((B, T), dtype=torch.bool, device=images.device)
+        camera_mask[torch.arange(B, device=images.device), query_idx.to(images.device).long()] = True
+        data["camera_mask"] = camera_mask.clone()
+        pose_feat = data["bbox_feat"]
+
+        if images.device != self.rgb_encoder.get_device():
+            self.rgb_encoder.to_device(images.device)                            # BoxDreamerModel.py:279-282
+        rgb_feature = self.rgb_encoder.predict(images)
+        query_ret = self.decoder(pose_feat, images, camera_mask, rgb_feature, None)
+
+        data["pred_bbox"] = data["bbox_feat"].clone()                            # BoxDreamerModel.py:341-344
+        data["pred_bbox"][camera_mask] = query_ret.to(data["pred_bbox"].dtype)
+
+        pred_poses = data["poses"].clone()
+        if not self.training:
+            pred_poses = self._process_evaluation(pred_poses, data, query_ret, camera_mask)
+        data["pred_poses"] = pred_poses
+        data["pred_intrinsics"] = data["intrinsics"]
+        return data
+
+    def _process_evaluation(self, pred_poses, data, query_ret, camera_mask):
+        """prediction_utils.py:63-101 for bb8/heatmap: decode corners on the GPU, one D2H, host PnP."""
+        B = query_ret.shape[0]
+        norm_kp, kp_px, _ = recover_bb8_corners_chw(query_ret)                  # [B,8,2] each
+        bbox_3d = data["bbox_3d"][camera_mask].float()
+        K = data["non_ndc_intrinsics"][camera_mask].float()
+        poses = solve_poses_host(kp_px.cpu().numpy(), bbox_3d.cpu().numpy(), K.cpu().numpy())
+        pred_poses[camera_mask] = torch.from_numpy(poses).to(pred_poses.device).to(pred_poses.dtype)
+        data["regression_boxes"] = data["bbox_proj_crop"].clone()
+        data["regression_boxes"][camera_mask] = norm_kp.to(data["regression_boxes"].dtype)
+        data["pred_corners_px"] = kp_px
+        return torch.nan_to_num(pred_poses, nan=0.0, posinf=0.0, neginf=0.0)

@@ -1,0 +1,38 @@
+"""CPU: the multi-GPU sweep's only collective (all-gather of predicted corners) with world_size 2 on gloo."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from boxdreamer_amd import synth
+from boxdreamer_amd.dist import gather_corners, gather_corners_ragged, shard_batch, shard_range
+
+
+def _worker(rank, world, port, n_total):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(n_total * 16, dtype=torch.float32).reshape(n_total, 8, 2)
+        # equal shards
+        lo, hi = shard_range(n_total - n_total % world, rank, world)
+        eq = gather_corners(full[lo:hi].clone(), world)
+        assert torch.equal(eq, full[: n_total - n_total % world])
+        # ragged shards
+        lo, hi = shard_range(n_total, rank, world)
+        rg = gather_corners_ragged(full[lo:hi].clone(), n_total)
+        assert torch.equal(rg, full)
+        # a sharded batch dict keeps per-sample alignment
+        data = synth.make_batch(5, B=4, T=2, size=28)
+        mine = shard_batch(data, rank, world)
+        marker = mine["bbox_proj_crop"][:, 0].contiguous()                 # (B_local, 8, 2)
+        allm = gather_corners(marker, world)
+        assert torch.equal(allm, data["bbox_proj_crop"][:, 0])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_corner_allgather_world2():
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, 7), nprocs=2, join=True)

@@ -1,0 +1,80 @@
+"""GPU: the drop-in boundary `BoxDreamer(config).forward(data) -> data` (BoxDreamerModel.py:112-191) end to end,
+constructed from the reference's own config layout (configs/model/transformer.yaml:10-71)."""
+import copy
+
+import pytest
+import torch
+
+from boxdreamer_amd import synth
+from boxdreamer_amd.model import BoxDreamer
+from oracle import boxdreamer_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(prec, depth=2):
+    return {"modules": {
+        "use_keypoints": False, "use_matching": False, "use_tracking": False, "use_rgb": True, "use_pp": True,
+        "ref_type": "all", "regression_intri": True, "rotation_type": None, "coordinate": "object",
+        "pose_representation": "bb8", "bbox_representation": "heatmap", "patchify_rays": True, "stage": "decoder_only",
+        "dense_cfg": {"enable": False},
+        "decoder": {"d_model": 768, "nhead": 8, "num_decoder_layers": depth, "camera_emb": "MLP", "track_emb": None,
+                    "match_emb": None, "decoder_only": True, "patch_size": 14, "img_size": 224, "diff_emb": False,
+                    "nvs_supervision": False, "ray_supervision": True, "use_mask": False, "hip_precision": prec},
+        "encoder": {"name": "dino", "dino": {"ckpt_path": None, "cfg": {"model_type": "dinov2_vitb14_reg", "freeze": True,
+                                                                        "synthetic_seed": 4321, "depth": depth,
+                                                                        "hip_precision": prec}}},
+    }}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_forward_dict_contract(hip, dtype):
+    model = BoxDreamer(_config("bf16x3"))
+    # checkpoints carry the decoder under "decoder." (Lightning adds "BoxDreamer." on top, demo.py:564-573 strips it)
+    sd = {"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}
+    missing, unexpected = model.load_state_dict(sd, strict=True), None
+    model = model.cuda().eval()
+    B, T = 2, 3
+    data = synth.make_batch(seed=8, B=B, T=T, dtype=dtype)
+    data["query_idx"] = torch.tensor([2, 0])
+    keys_in = set(data)
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    inputs = copy.deepcopy({k: v.clone() for k, v in dev.items()})
+    out = model(dev)
+    assert out is dev
+    for k in ("camera_mask", "pred_bbox", "regression_boxes", "pred_poses", "pred_intrinsics"):
+        assert k in out
+    for k in keys_in:                                   # inputs are not modified
+        assert torch.equal(out[k], inputs[k])
+    cm = out["camera_mask"].cpu()
+    assert cm.dtype == torch.bool and cm.sum(1).tolist() == [1, 1] and cm[0, 2] and cm[1, 0]
+    assert out["pred_bbox"].dtype == dtype and out["pred_bbox"].shape == (B, T, 8, 224, 224)
+    assert torch.equal(out["pred_bbox"][~out["camera_mask"]], inputs["bbox_feat"][~out["camera_mask"]])
+    o = orc.boxdreamer_forward({**data, "images": data["images"].float(), "bbox_feat": data["bbox_feat"].float()},
+                               synth.betr_state_dict(1234, 2), synth.dino_state_dict(4321, 2))
+    assert (model.decoder.last_logits.cpu() - o["logits"]).abs().max().item() <= 1e-3
+    tol = 1e-4 if dtype == torch.float32 else 8e-3
+    assert (out["pred_bbox"][out["camera_mask"]].float().cpu() - o["heat"]).abs().max().item() <= tol
+    assert (out["pred_corners_px"].cpu() - o["corners_px"]).abs().max().item() <= 224 / 20 * 2
+    rb = out["regression_boxes"].float().cpu()
+    assert (rb[cm] - o["corners_norm"]).abs().max().item() <= (0.2 if dtype == torch.float32 else 0.25)
+    assert torch.equal(rb[~cm], data["bbox_proj_crop"].float()[~cm])
+    pp = out["pred_poses"].float().cpu()
+    assert pp.shape == (B, T, 4, 4) and torch.isfinite(pp).all()
+    assert torch.equal(pp[~cm], data["poses"].float()[~cm])             # reference views keep their GT pose
+    # train mode: no evaluation post-process (BoxDreamerModel.py:166-185)
+    model.train()
+    dev2 = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    out2 = model(dev2)
+    assert "regression_boxes" not in out2 and torch.equal(out2["pred_poses"], dev2["poses"])
+
+
+def test_unsupported_configs_raise():
+    cfg = _config("bf16")
+    cfg["modules"]["use_tracking"] = True
+    with pytest.raises(NotImplementedError):
+        BoxDreamer(cfg)
+    cfg = _config("bf16")
+    cfg["modules"]["encoder"]["name"] = "resnet"
+    with pytest.raises(NotImplementedError):
+        BoxDreamer(cfg)

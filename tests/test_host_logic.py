@@ -1,0 +1,176 @@
+"""CPU: host-side logic of the product package (no compute kernels are launched here)."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from boxdreamer_amd import _lib, config, pack, pnp, synth
+from boxdreamer_amd.betr import BETR
+from boxdreamer_amd.dist import shard_batch, shard_range
+from oracle import boxdreamer_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BETR_KW = dict(d_model=768, nhead=8, num_decoder_layers=12, decoder_only=True, patch_size=14, img_size=224,
+               diff_emb=False, nvs_supervision=False, ray_supervision=True, use_mask=False, use_pretrained=True,
+               patchify_rays=True, pose_representation="bb8", bbox_representation="heatmap")
+
+
+def test_synth_is_bit_stable():
+    """The generator must give the same bits on every box (fixtures were made from these tensors)."""
+    u = synth.uniform_np("images", (4, 5), 0, 1, 7)
+    assert u.min() >= 0 and u.max() < 1
+    a = synth.betr_state_dict(depth=1)["attn.0.mlp.fc1.weight"]
+    b = synth.betr_state_dict(depth=1)["attn.0.mlp.fc1.weight"]
+    assert torch.equal(a, b)
+    assert abs(float(a.std()) - 0.02) < 5e-4 and float(a.abs().max()) <= 0.02 * 3.47
+    d = synth.make_batch(seed=7, B=1, T=2)
+    assert d["images"].shape == (1, 2, 3, 224, 224) and float(d["images"][..., :16, :].abs().max()) == 0.0
+    assert float(d["bbox_feat"].max()) == 1.0 and float(d["bbox_feat"].min()) >= -1.0
+    assert torch.equal(d["images"], d["images"].to(torch.bfloat16).float())      # pre-rounded to the run precision
+
+
+def test_synth_checksums(golden_dir):
+    """Checksums of the seeded tensors the golden fixtures depend on."""
+    path = os.path.join(golden_dir, "synth_checksums.json")
+    cur = {
+        "betr.qkv0": hashlib.sha256(synth.betr_state_dict(1234, 1)["attn.0.attn.qkv.weight"].numpy().tobytes()).hexdigest(),
+        "dino.pos": hashlib.sha256(synth.dino_state_dict(4321, 1)["pos_embed"].numpy().tobytes()).hexdigest(),
+        "batch.images": hashlib.sha256(synth.make_batch(7, 1, 2)["images"].numpy().tobytes()).hexdigest(),
+    }
+    if not os.path.exists(path):                     # first run in the build container records them
+        json.dump(cur, open(path, "w"), indent=1)
+    assert cur == json.load(open(path))
+
+
+def test_state_dict_contract(golden_dir):
+    man = json.load(open(os.path.join(golden_dir, "state_dict_manifest.json")))
+    m = BETR(**BETR_KW)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == man["betr"]
+    m.load_state_dict(synth.betr_state_dict(1234, 12), strict=True)
+    assert {k: list(v.shape) for k, v in synth.dino_state_dict(4321, 12).items()} == man["dino"]
+    with pytest.raises(NotImplementedError):
+        BETR(**{**BETR_KW, "bbox_representation": "voting"})
+
+
+def test_pack_linear_and_planes():
+    w = torch.from_numpy(synth.bell_np("w", (12, 588), 0.05, 0, 1).astype(np.float32))
+    g = torch.from_numpy(synth.bell_np("g", (12,), 0.1, 1.0, 1).astype(np.float32))
+    p = pack.pack_linear_weight(w, "bf16", kpad=640, row_scale=g)
+    assert p.shape == (12, 640) and p.dtype == torch.bfloat16 and float(p[:, 588:].abs().max()) == 0
+    assert torch.equal(p[:, :588], (w * g[:, None]).to(torch.bfloat16))
+    p3 = pack.pack_linear_weight(w, "bf16x3")
+    assert p3.shape == (2, 12, 640)
+    rec = p3[0].float() + p3[1].float()
+    assert (rec[:, :588] - w).abs().max() <= 2.0 ** -16 * float(w.abs().max())
+    assert pack.pack_linear_weight(w, "fp16").dtype == torch.float16
+    with pytest.raises(ValueError):
+        pack.pack_linear_weight(w, "bf16", kpad=600)
+
+
+def test_pack_tables_match_oracle():
+    assert torch.equal(pack.sincos_table(768, 16), orc.sincos_pos_embed(768, 16))
+    dsd = synth.dino_state_dict(4321, 1)
+    prefix, pos_patch = pack.dino_pos_tables(dsd["pos_embed"], dsd["cls_token"], dsd["register_tokens"], 16)
+    ref = orc.dino_pos_embed(dsd, 16)
+    assert prefix.shape == (5, 768) and pos_patch.shape == (256, 768)
+    assert torch.allclose(pos_patch, ref[0, 1:], atol=1e-7)
+    assert torch.allclose(prefix[0], dsd["cls_token"][0, 0] + ref[0, 0], atol=1e-7)
+    assert torch.equal(prefix[1:], dsd["register_tokens"][0])
+
+
+def test_pack_structs_on_cpu():
+    pk = pack.pack_betr(synth.betr_state_dict(1234, 2), "bf16x3", "cpu", 8)
+    w = pk.struct
+    assert (w.depth, w.dim, w.heads, w.grid, w.patch, w.box_dim, w.kpad) == (2, 768, 8, 16, 14, 8, 1600)
+    assert abs(w.ln_eps - 1e-5) < 1e-12 and abs(w.adapter_ln_eps - 1e-6) < 1e-12
+    assert w.blocks[1].q_norm_w and w.blocks[1].fc2.w
+    pk = pack.pack_dino(synth.dino_state_dict(4321, 2), "bf16", "cpu", 12)
+    assert (pk.struct.depth, pk.struct.n_prefix, pk.struct.kpad, pk.struct.grid) == (2, 5, 640, 16)
+    assert not pk.struct.blocks[0].q_norm_w
+    # LayerScale folded into proj: packed bias == gamma * bias
+    dsd = synth.dino_state_dict(4321, 1)
+    pb = pack.pack_bias(dsd["blocks.0.attn.proj.bias"], dsd["blocks.0.ls1.gamma"])
+    assert torch.equal(pb, dsd["blocks.0.attn.proj.bias"] * dsd["blocks.0.ls1.gamma"])
+
+
+def test_config_validation():
+    cfg = {"use_matching": False, "use_tracking": False, "use_keypoints": False, "use_rgb": True, "use_pp": True,
+           "regression_intri": True, "rotation_type": None, "coordinate": "object", "pose_representation": "bb8",
+           "bbox_representation": "cornernet", "patchify_rays": True,
+           "decoder": {"d_model": 768, "nhead": 8, "num_decoder_layers": 12, "decoder_only": True, "patch_size": 14,
+                       "img_size": 224, "diff_emb": True, "nvs_supervision": False, "ray_supervision": True,
+                       "use_mask": False},
+           "encoder": {"name": "dino", "dino": {"ckpt_path": None, "cfg": {"model_type": "dinov2_vitb14_reg"}}}}
+    v = config.validate_model_config(cfg)
+    assert v["bbox_representation"] == "heatmap"
+    v, cam, rot = config.setup_camera_params(v)
+    assert (cam, rot) == (0, 0) and v["decoder"]["use_pretrained"] is True and v["decoder"]["diff_emb"] is False
+    assert v["decoder"]["pose_representation"] == "bb8" and v["decoder"]["bbox_representation"] == "heatmap"
+    with pytest.raises(AssertionError):
+        config.validate_model_config({**cfg, "decoder": {**cfg["decoder"], "patch_size": 16}})
+
+
+def test_shard_range_and_batch():
+    for n in (1, 7, 32, 256):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    d = synth.make_batch(3, B=4, T=2)
+    s = shard_batch(d, 1, 2)
+    assert s["images"].shape[0] == 2 and torch.equal(s["images"], d["images"][2:4]) and s["query_idx"].shape == (2,)
+
+
+def test_pnp_recovers_pose():
+    rng = np.random.default_rng(0)
+    K = np.array([[270.0, 0, 112], [0, 270, 112], [0, 0, 1]])
+    for _ in range(4):
+        p3 = rng.uniform(-0.5, 0.5, (8, 3))
+        R = pnp.rodrigues(rng.normal(size=3) * 0.8)
+        t = np.array([0.1, -0.2, 4.0])
+        pc = p3 @ R.T + t
+        p2 = pc[:, :2] / pc[:, 2:3] * 270 + 112
+        ok, R2, t2 = pnp.solve_pnp_iterative(p3, p2, K)
+        assert ok and np.abs(R2 - R).max() < 1e-5 and np.abs(t2 - t).max() < 1e-5
+
+
+def test_c_abi_loads_and_exports_every_declared_symbol():
+    """The shared library must export exactly what include/boxdreamer_hip.h declares (no compute calls)."""
+    hdr = open(os.path.join(ROOT, "include", "boxdreamer_hip.h")).read()
+    declared = set(re.findall(r"\b(bd_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.EXPORTS)
+    assert lib.bd_abi_version() == 1 and lib.bd_target_arch() == b"gfx950"
+    # argument validation happens before any launch: NULL / bad shapes are rejected on a GPU-less box
+    g = _lib.GemmArgs()
+    assert lib.bd_gemm(ctypes.byref(g), 0, None) == -5
+    assert lib.bd_decode_topk(None, 1, 224, 224, 20, None, None, None, None) == -5
+    assert lib.bd_encoder_workspace_bytes(None, 1, 0) == 0
+    pk = pack.pack_dino(synth.dino_state_dict(4321, 1), "bf16", "cpu", 12)
+    need = lib.bd_encoder_workspace_bytes(pk.struct, 192, 0)
+    assert 0.8e9 < need < 1.2e9                                   # ~0.9 GB of activations at B*T = 192
+    pkb = pack.pack_betr(synth.betr_state_dict(1234, 1), "bf16", "cpu", 8)
+    assert lib.bd_decoder_workspace_bytes(pkb.struct, 32, 6, 2) > lib.bd_decoder_workspace_bytes(pkb.struct, 32, 6, 0)
+
+
+def test_product_path_fails_loudly_without_gpu_and_never_touches_the_oracle():
+    if not torch.cuda.is_available():
+        m = BETR(**{**BETR_KW, "num_decoder_layers": 1}).eval()
+        x = torch.zeros(1, 2, 8, 224, 224)
+        with pytest.raises(_lib.HipLibraryError):
+            m(x, torch.zeros(1, 2, 3, 224, 224), torch.tensor([[False, True]]), torch.zeros(1, 2, 256, 768))
+    pkg = os.path.join(ROOT, "boxdreamer_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f"{f} imports the oracle"
+            assert "/root/reference" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# ", ""), f
