@@ -14,6 +14,8 @@
 // NS = 1: one operand plane (bf16 or f16).  NS = 2: split-bf16 "x3" mode -- A and W each carry a
 // hi and a lo plane and every fragment pair issues hi*hi + hi*lo + lo*hi (fp32-class accuracy
 // from bf16 MFMA), BK halves so the LDS image stays 64 KiB.
+#include <stdlib.h>
+
 #include "bd_common.h"
 
 namespace {
@@ -21,14 +23,204 @@ namespace {
 constexpr int BM = 128;
 constexpr int BN = 128;
 
+
+// Workgroup -> output tile.  (1) XCD-aware bijective remap: XCD x (= blockIdx % 8, private 4 MiB L2) owns a
+// contiguous run of logical ids.  (2) Grouped raster inside that run: ids walk GROUP_M M-tiles down, then step
+// one N-tile across, so the ~64 workgroups resident on an XCD cover a compact ~8 x 8 patch -- 8 A row-panels
+// + 8 W tiles (~3 MB at K = 768) stay L2-resident instead of streaming every W tile through it.
+constexpr int GROUP_M = 8;
+__device__ __forceinline__ void tile_coords(int M, int N, int& m0, int& n0) {
+    const int tilesM = (M + BM - 1) / BM, tilesN = (N + BN - 1) / BN;
+    const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int per_group = GROUP_M * tilesN;
+    const int g = wg / per_group, in_g = wg % per_group;
+    const int gm0 = g * GROUP_M;
+    const int gh = (tilesM - gm0) < GROUP_M ? (tilesM - gm0) : GROUP_M;     // last group may be shorter
+    m0 = (gm0 + in_g % gh) * BM;
+    n0 = (in_g / gh) * BN;
+}
+
 template <int BK> __device__ __forceinline__ int swz_chunk(int row, int c) {
     constexpr int CH = BK / 8;            // 16-byte chunks per tile row
     constexpr int RPB = 16 / CH;          // tile rows per 256-byte LDS bank row
     return c ^ ((row / RPB) & (CH - 1));
 }
 
+// ---- epilogue shared by both mainloops: C fragment (col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+template <class T, int NS, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wm0, int wn0, int lane) {
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int M = p.M, N = p.N;
+    const float* bias = p.bias;
+    const float* resid = p.resid;
+    const float* addtab = p.addtab;
+    const int act = p.act, out_f32 = p.out_f32, rpg_in = p.rpg_in, rpg_out = p.rpg_out, row_off = p.row_off;
+    const int tab_rows = p.tab_rows;
+    const int64_t ldr = p.ldr, ldo = p.ldo, out_plane = p.out_plane;
+    float bj[NI];
+    int gcs[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        gcs[j] = wn0 + j * 32 + lrow;
+        bj[j] = (bias && gcs[j] < N) ? bias[gcs[j]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gr = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            if (gr < M) {
+                int64_t orow = gr;
+                if (rpg_in > 0) orow = (int64_t)(gr / rpg_in) * rpg_out + gr % rpg_in + row_off;
+                const float* tab = addtab ? addtab + (int64_t)(gr % tab_rows) * N : nullptr;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int gc = gcs[j];
+                    if (gc < N) {
+                        float v = acc[i][j][r] + bj[j];
+                        if (act == BD_ACT_GELU) v = gelu_erf(v);
+                        if (tab) v += tab[gc];
+                        if (resid) v += resid[orow * ldr + gc];
+                        if (out_f32) {
+                            ((float*)p.out)[orow * ldo + gc] = v;
+                        } else {
+                            T* o = (T*)p.out + orow * ldo + gc;
+                            const T hi = from_f32<T>(v);
+                            o[0] = hi;
+                            if (NS == 2) o[out_plane] = from_f32<T>(v - to_f32<T>(hi));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+
+// ---- wide epilogue (LDS-DMA kernels): accumulators -> this wave's private LDS scratch -> row-contiguous
+// 16-byte accesses.  The MFMA C fragment gives each lane one column and 16 scattered rows (64 two-/four-byte
+// stores per lane, each half-wave touching half a cache line): measured store-issue- and load-latency-bound
+// (~27 us per tile round vs 1.3 us per K-slab).  Here every 32-row chunk of the wave tile is written to LDS with
+// conflict-free ds_write_b32 (one row per half-wave), read back with ds_read_b128 as 4 (fp32 out) or 8 (16-bit
+// out) consecutive columns per lane, the residual / table rows are fetched as float4 in one batch, and the result
+// leaves as full-line 16-byte stores.  Same-wave LDS traffic is ordered, so no workgroup barrier is needed.
+template <class T, int NS, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], unsigned char* scratch,
+                                                  int wm0, int wn0, int lane) {
+    constexpr int COLS = NI * 32;                      // wave-tile width (fp32 words per scratch row)
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int M = p.M, N = p.N;
+    const float* bias = p.bias;
+    const float* resid = p.resid;
+    const float* addtab = p.addtab;
+    const int act = p.act, rpg_in = p.rpg_in, rpg_out = p.rpg_out, row_off = p.row_off, tab_rows = p.tab_rows;
+    const int64_t ldr = p.ldr, ldo = p.ldo, out_plane = p.out_plane;
+    float* sc = (float*)scratch;
+    if (p.out_f32) {
+        constexpr int LPR = COLS / 4;                  // lanes per row (float4 each)
+        constexpr int RPI = 64 / LPR;                  // rows per pass
+        constexpr int PASSES = 32 / RPI;
+        const int c4 = lane % LPR, rsub = lane / LPR;
+        const int gc = wn0 + c4 * 4;
+        const bool cok = gc < N;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && cok) bv = *(const float4*)(bias + gc);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sc[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
+            float4 rv[PASSES], tv[PASSES];
+            int64_t orow[PASSES];
+            bool ok[PASSES];
+#pragma unroll
+            for (int t = 0; t < PASSES; ++t) {          // batch the global reads
+                const int gr = wm0 + i * 32 + t * RPI + rsub;
+                ok[t] = cok && gr < M;
+                const int grc = gr < M ? gr : M - 1;
+                orow[t] = rpg_in > 0 ? (int64_t)(grc / rpg_in) * rpg_out + grc % rpg_in + row_off : (int64_t)grc;
+                rv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                tv[t] = rv[t];
+                if (resid && ok[t]) rv[t] = *(const float4*)(resid + orow[t] * ldr + gc);
+                if (addtab && ok[t]) tv[t] = *(const float4*)(addtab + (int64_t)(grc % tab_rows) * N + gc);
+            }
+#pragma unroll
+            for (int t = 0; t < PASSES; ++t) {
+                const float4 a = *(const float4*)(sc + (t * RPI + rsub) * COLS + c4 * 4);
+                float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
+                if (act == BD_ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                const float4 o = make_float4(v[0] + tv[t].x + rv[t].x, v[1] + tv[t].y + rv[t].y,
+                                             v[2] + tv[t].z + rv[t].z, v[3] + tv[t].w + rv[t].w);
+                if (ok[t]) *(float4*)((float*)p.out + orow[t] * ldo + gc) = o;
+            }
+        }
+    } else {
+        constexpr int LPR = COLS / 8;                  // lanes per row (8 columns = 16 bytes of output each)
+        constexpr int RPI = 64 / LPR;
+        constexpr int PASSES = 32 / RPI;
+        typedef typename Op16<T>::vec8 vec8;
+        const int c8 = lane % LPR, rsub = lane / LPR;
+        const int gc = wn0 + c8 * 8;
+        const bool cok = gc < N;
+        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bias && cok) {
+            const float4 b0 = *(const float4*)(bias + gc), b1 = *(const float4*)(bias + gc + 4);
+            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sc[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
+#pragma unroll
+            for (int t = 0; t < PASSES; ++t) {
+                const int gr = wm0 + i * 32 + t * RPI + rsub;
+                const float* src = sc + (t * RPI + rsub) * COLS + c8 * 8;
+                const float4 a0 = *(const float4*)src, a1 = *(const float4*)(src + 4);
+                float v[8] = {a0.x + bv[0], a0.y + bv[1], a0.z + bv[2], a0.w + bv[3],
+                              a1.x + bv[4], a1.y + bv[5], a1.z + bv[6], a1.w + bv[7]};
+                if (act == BD_ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                }
+                if (cok && gr < M) {
+                    const int64_t orow = rpg_in > 0 ? (int64_t)(gr / rpg_in) * rpg_out + gr % rpg_in + row_off : (int64_t)gr;
+                    if (addtab) {
+                        const float* tp = addtab + (int64_t)(gr % tab_rows) * N + gc;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += tp[e];
+                    }
+                    if (resid) {
+                        const float* rp = resid + orow * ldr + gc;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rp[e];
+                    }
+                    vec8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        hi[e] = from_f32<T>(v[e]);
+                        if (NS == 2) lo[e] = from_f32<T>(v[e] - to_f32<T>(hi[e]));
+                    }
+                    T* o = (T*)p.out + orow * ldo + gc;
+                    *(vec8*)o = hi;
+                    if (NS == 2) *(vec8*)(o + out_plane) = lo;
+                }
+            }
+        }
+    }
+}
+
 template <class T, int NS, int BK>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const bd_gemm_args p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel_regstage(const bd_gemm_args p) {
     typedef typename Op16<T>::vec8 vec8;
     constexpr int CH = BK / 8;
     constexpr int CPT = BM * CH / 256;               // chunks per thread per plane tile
@@ -42,16 +234,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const bd_gemm_args p) {
     const int wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
 
-    // XCD-aware bijective remap of the 1-D grid: XCD x (= bid % 8) gets a contiguous run of tiles.
-    const int tilesN = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int wg;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int m0 = (wg / tilesN) * BM;
-    const int n0 = (wg % tilesN) * BN;
+    int m0, n0;
+    tile_coords(p.M, p.N, m0, n0);
 
     const T* Ap = (const T*)p.A;
     const T* Wp = (const T*)p.W;
@@ -139,60 +323,168 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const bd_gemm_args p) {
         __syncthreads();
     }
 
-    // ---- epilogue: C fragment (col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-    const int M = p.M, N = p.N;
-    const float* bias = p.bias;
-    const float* resid = p.resid;
-    const float* addtab = p.addtab;
-    const int act = p.act, out_f32 = p.out_f32, rpg_in = p.rpg_in, rpg_out = p.rpg_out, row_off = p.row_off;
-    const int tab_rows = p.tab_rows;
-    const int64_t ldr = p.ldr, ldo = p.ldo, out_plane = p.out_plane;
-    float bj[2];
-    int gcs[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        gcs[j] = n0 + wn * 64 + j * 32 + lrow;
-        bj[j] = (bias && gcs[j] < N) ? bias[gcs[j]] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-            if (gr < M) {
-                int64_t orow = gr;
-                if (rpg_in > 0) orow = (int64_t)(gr / rpg_in) * rpg_out + gr % rpg_in + row_off;
-                const float* tab = addtab ? addtab + (int64_t)(gr % tab_rows) * N : nullptr;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int gc = gcs[j];
-                    if (gc < N) {
-                        float v = acc[i][j][r] + bj[j];
-                        if (act == BD_ACT_GELU) v = gelu_erf(v);
-                        if (tab) v += tab[gc];
-                        if (resid) v += resid[orow * ldr + gc];
-                        if (out_f32) {
-                            ((float*)p.out)[orow * ldo + gc] = v;
-                        } else {
-                            T* o = (T*)p.out + orow * ldo + gc;
-                            const T hi = from_f32<T>(v);
-                            o[0] = hi;
-                            if (NS == 2) o[out_plane] = from_f32<T>(v - to_f32<T>(hi));
-                        }
-                    }
-                }
-            }
-        }
-    }
+    gemm_epilogue<T, NS, 2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 #undef LOAD_SLAB
 #undef STORE_SLAB
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA mainloop (default): tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 -- no staging VGPRs, no
+// ds_write pass.  An LDS-DMA wave-instruction writes 1 KiB at  M0-base + lane*16  (lane-linear), so the XOR
+// swizzle is applied on the SOURCE side: the lane that owns LDS slot (row, c') fetches logical chunk
+// c = c' ^ swz(row) of that row (same 128-byte line, so coalescing is unchanged), and fragment reads apply the
+// same involution.  One __syncthreads() per K-slab: it waits vmcnt(0) (slab kt landed) and fences the
+// buffer about to be overwritten; the DMA for slab kt+1 is issued right after it and flies under slab kt's MFMAs.
+//
+// Tile geometry is a template: WM x WN waves, each owning an (MI*32) x (NI*32) sub-tile.
+//   <2,4,4,2>: 256x256 tile, 8 waves, 128 KiB LDS, 1 workgroup/CU -- 128 FLOP per LDS-DMA byte: the CU's
+//              64 B/clk vector-memory path needs only half the MFMA time (the 128x128 tile needs all of it,
+//              which is what capped the first version at ~20 % MFMA utilisation, profiles/r1_gemm_pmc.md)
+//   <2,4,4,1>: 256x128 for N = 768 outputs (better wave quantisation: 1152 instead of 576 tiles)
+//   <2,2,2,2>: 128x128 for small problems
+template <int BM_, int BN_>
+__device__ __forceinline__ void tile_coords_t(int M, int N, int group_m, int& m0, int& n0) {
+    const int tilesM = (M + BM_ - 1) / BM_, tilesN = (N + BN_ - 1) / BN_;
+    const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int per_group = group_m * tilesN;
+    const int g = wg / per_group, in_g = wg % per_group;
+    const int gm0 = g * group_m;
+    const int gh = (tilesM - gm0) < group_m ? (tilesM - gm0) : group_m;
+    m0 = (gm0 + in_g % gh) * BM_;
+    n0 = (in_g / gh) * BN_;
+}
+
+template <class T, int NS, int BK, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 2 : 2)) void gemm_kernel_glds(const bd_gemm_args p) {
+    typedef typename Op16<T>::vec8 vec8;
+    constexpr int NWAVE = WM * WN;
+    constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32;
+    constexpr int CH = BK / 8;                        // 16-byte chunks per tile row
+    constexpr int RPP = 64 / CH;                      // tile rows per 1-KiB DMA piece
+    constexpr int A_BYTES = TBM * BK * 2, W_BYTES = TBN * BK * 2;
+    constexpr int PPW_A = A_BYTES / 1024 / NWAVE, PPW_W = W_BYTES / 1024 / NWAVE;
+    static_assert(PPW_A >= 1 && PPW_W >= 1 && A_BYTES % (1024 * NWAVE) == 0 && W_BYTES % (1024 * NWAVE) == 0, "tile/DMA split");
+    constexpr int STAGE_BYTES = (A_BYTES + W_BYTES) * NS;   // A planes then W planes
+    constexpr int KS = BK / 16;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    int m0, n0;
+    tile_coords_t<TBM, TBN>(p.M, p.N, TBM >= 256 ? 4 : 8, m0, n0);
+
+    // per-lane DMA sources: piece j covers tile rows j*RPP .. j*RPP+RPP-1
+    const T* ga[PPW_A];
+    const T* gw[PPW_W];
+#pragma unroll
+    for (int i = 0; i < PPW_A; ++i) {
+        const int row = (wid * PPW_A + i) * RPP + lane / CH;
+        int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
+        ga[i] = (const T*)p.A + (int64_t)ar * p.lda + swz_chunk<BK>(row, lane % CH) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PPW_W; ++i) {
+        const int row = (wid * PPW_W + i) * RPP + lane / CH;
+        int wr = n0 + row; wr = wr < p.N ? wr : p.N - 1;
+        gw[i] = (const T*)p.W + (int64_t)wr * p.ldw + swz_chunk<BK>(row, lane % CH) * 8;
+    }
+    const int64_t a_plane = p.a_plane, w_plane = p.w_plane;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#define DMA_SLAB(buf, k0)                                                                                     \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                          \
+        _Pragma("unroll") for (int i = 0; i < PPW_A; ++i)                                                     \
+            __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + s * a_plane + (k0)),                            \
+                (lptr_t)(lds + (buf) * STAGE_BYTES + s * A_BYTES + (wid * PPW_A + i) * 1024), 16, 0, 0);      \
+        _Pragma("unroll") for (int i = 0; i < PPW_W; ++i)                                                     \
+            __builtin_amdgcn_global_load_lds((gptr_t)(gw[i] + s * w_plane + (k0)),                            \
+                (lptr_t)(lds + (buf) * STAGE_BYTES + NS * A_BYTES + s * W_BYTES + (wid * PPW_W + i) * 1024), 16, 0, 0); \
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int nk = p.K / BK;
+    DMA_SLAB(0, 0)
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                                   // slab kt landed; buffer (kt+1)&1 is free
+        if (kt + 1 < nk) { DMA_SLAB((kt + 1) & 1, (kt + 1) * BK) }
+        const unsigned char* base = lds + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            vec8 a[NS][MI], b[NS][NI];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int r = wm * (MI * 32) + i * 32 + lrow;
+                    a[s][i] = as_vec8<T>(*(const u128*)(base + s * A_BYTES + r * (BK * 2) + (swz_chunk<BK>(r, ks * 2 + lhalf) << 4)));
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int r = wn * (NI * 32) + j * 32 + lrow;
+                    b[s][j] = as_vec8<T>(*(const u128*)(base + NS * A_BYTES + s * W_BYTES + r * (BK * 2) + (swz_chunk<BK>(r, ks * 2 + lhalf) << 4)));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if (NS == 2) {
+                        acc[i][j] = Op16<T>::mfma(a[NS - 1][i], b[0][j], acc[i][j]);   // lo * hi
+                        acc[i][j] = Op16<T>::mfma(a[0][i], b[NS - 1][j], acc[i][j]);   // hi * lo
+                    }
+                    acc[i][j] = Op16<T>::mfma(a[0][i], b[0][j], acc[i][j]);            // hi * hi
+                }
+        }
+    }
+#undef DMA_SLAB
+    // wide epilogue needs 16-byte aligned rows: N % 8 == 0 and aligned leading dimensions (else scalar path)
+    const bool wide = (p.N % 8 == 0) && (p.ldo % 8 == 0) && (((uintptr_t)p.out & 15) == 0) &&
+                      (!p.resid || ((p.ldr % 4 == 0) && ((uintptr_t)p.resid & 15) == 0)) &&
+                      (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.addtab || ((uintptr_t)p.addtab & 15) == 0) &&
+                      (p.out_f32 || NS == 1 || (p.out_plane % 8 == 0));
+    if (wide) {
+        __syncthreads();                                   // every wave is done with the operand slabs
+        gemm_epilogue_lds<T, NS, MI, NI>(p, acc, lds + wid * (32 * NI * 32 * 4), m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+    } else {
+        gemm_epilogue<T, NS, MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+    }
+}
+
+int gemm_impl() {   // BD_GEMM_IMPL=0 selects the register-staged mainloop (A/B measurements only)
+    static const int impl = [] { const char* e = getenv("BD_GEMM_IMPL"); return e ? atoi(e) : 1; }();
+    return impl;
+}
+
+template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_glds(const bd_gemm_args& a, hipStream_t s) {
+    constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32;
+    const int tiles = ((a.M + TBM - 1) / TBM) * ((a.N + TBN - 1) / TBN);
+    hipLaunchKernelGGL((gemm_kernel_glds<T, NS, BK, WM, WN, MI, NI>), dim3(tiles), dim3(WM * WN * 64), 0, s, a);
+}
+
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
-    hipLaunchKernelGGL((gemm_kernel<T, NS, BK>), dim3(tiles), dim3(256), 0, s, a);
+    const int impl = gemm_impl();
+    if (impl == 0) {
+        const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+        hipLaunchKernelGGL((gemm_kernel_regstage<T, NS, BK>), dim3(tiles), dim3(256), 0, s, a);
+    } else if (impl == 2 || a.M < 1024 || a.N < 1536) {
+        launch_glds<T, NS, BK, 2, 2, 2, 2>(a, s);                 // 128 x 128 (2 workgroups / CU): N = 768 outputs
+    } else if (impl == 3) {
+        launch_glds<T, NS, BK, 2, 4, 4, 1>(a, s);                 // 256 x 128 (measurement only)
+    } else {
+        launch_glds<T, NS, BK, 2, 4, 4, 2>(a, s);                 // 256 x 256 (1 workgroup / CU): wide outputs
+    }
     bd_trace_close(s, slot);
     BD_CHECK_LAUNCH();
     return BD_OK;

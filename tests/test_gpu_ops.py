@@ -24,7 +24,8 @@ def _q(x, prec):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (77, 1568, 768), (1000, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (77, 1568, 768), (1000, 768, 3072),
+                                   (2048, 768, 128), (1500, 1536, 192), (1300, 1568, 64), (2304, 2304, 768)])
 def test_gemm_plain(hip, prec, M, N, K):
     a, w, b = _rand("a", (M, K)), _rand("w", (N, K), 0.05), _rand("b", (N,), 0.1)
     a16, w16 = hip_ops.to_operand(a.cuda(), prec), hip_ops.to_operand(w.cuda(), prec)
