@@ -31,6 +31,15 @@ struct AttnArgs {
 
 constexpr int KT = 64;   // keys per tile
 
+// 16-byte chunk swizzle of V^T row d (128-byte rows: every row aliases the same 32 banks).
+//  * ds_read_b128 (O^T A operand): a 16-lane group reads 16 consecutive rows, same logical chunk -> the 8 rows of
+//    equal parity must land on 8 distinct chunks: (d >> 1) & 7 does that, and XOR-ing in (d >> 4), constant over an
+//    aligned 16-row group, keeps it a bijection;
+//  * ds_write_b64 (transposing stage): the lanes of a group hold d = 8*dc + const for 12 consecutive dc -> with
+//    (d >> 1) alone only 2 of 8 chunks are used (6-way conflict: 43 % of LDS cycles in profiles/r1_attn_pmc.md);
+//    the (d >> 4) term spreads them over all 8 (<= 2-way).
+__device__ __forceinline__ int vswz(int d) { return ((d >> 1) ^ (d >> 4)) & 7; }
+
 template <class T, int NS, int HD, int NW>
 __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const AttnArgs p) {
     typedef typename Op16<T>::vec8 vec8;
@@ -47,7 +56,9 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
     constexpr int QB = NW * 32;
     constexpr int DM = HD / 32;                  // O^T M-tiles
     constexpr int KS = HD / 16;                  // k-steps of S^T
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NS * PLANE_BYTES];
+    constexpr int BUF_BYTES = NS * PLANE_BYTES;
+    constexpr int NBUF = NS == 1 ? 2 : 1;      // strict mode keeps one buffer (two planes already fill the LDS budget)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * BUF_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lq = lane & 31, lh = lane >> 5;
@@ -65,7 +76,7 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
     const int bh = wg / nqb;
     const int head = bh % heads, b = bh / heads;
 
-    const int64_t ld = (int64_t)3 * heads * HD;            // elements per token row
+    const int ld = 3 * heads * HD;                         // elements per token row (32-bit offsets inside a sample)
     const T* base = (const T*)p.qkv + (int64_t)b * seq * ld + head * HD;
     const T* qbase = base;
     const T* kbase = base + heads * HD;
@@ -80,18 +91,22 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            qf[s][ks] = as_vec8<T>(*(const u128*)(qbase + s * plane + (int64_t)qrow * ld + ks * 16 + lh * 8));
+            qf[s][ks] = as_vec8<T>(*(const u128*)(qbase + s * plane + (unsigned)(qrow * ld + ks * 16 + lh * 8)));
 
     // ---- loader coordinates
     int kc_row[KCPT], kc_col[KCPT];
+    unsigned kc_off[KCPT];                                  // element offset of the chunk in tile 0
 #pragma unroll
     for (int i = 0; i < KCPT; ++i) {
         const int c = tid + NT * i;
         kc_row[i] = c / DCH;
         kc_col[i] = c % DCH;
+        kc_off[i] = (unsigned)(kc_row[i] * ld + kc_col[i] * 8);
     }
     const int vm_kq = tid / DCH, vm_dc = tid % DCH;     // key quad (0..15), d chunk
     const bool vm_active = tid < VMT;
+    const unsigned vm_off = (unsigned)(vm_kq * 4 * ld + vm_dc * 8);
+    const bool ragged = (seq % KT) != 0;
     // destination of the micro-tile in the V^T image: 16-key group g, permuted quad
     int vdst;
     {
@@ -105,20 +120,22 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
     _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                          \
         _Pragma("unroll") for (int i = 0; i < KCPT; ++i) {                                    \
             if (KCH % NT == 0 || tid + NT * i < KCH) {                                        \
-                int kr = (kt) * KT + kc_row[i]; kr = kr < seq ? kr : seq - 1;                 \
-                rk[s][i] = *(const u128*)(kbase + s * plane + (int64_t)kr * ld + kc_col[i] * 8); \
+                unsigned off = kc_off[i] + (unsigned)((kt) * KT * ld);                        \
+                if (ragged && (kt) * KT + kc_row[i] >= seq) off = (unsigned)((seq - 1) * ld + kc_col[i] * 8); \
+                rk[s][i] = *(const u128*)(kbase + s * plane + off);                           \
             }                                                                                 \
         }                                                                                     \
         if (vm_active) {                                                                      \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                   \
-                int vr = (kt) * KT + vm_kq * 4 + j; vr = vr < seq ? vr : seq - 1;             \
-                rv[s][j] = *(const u128*)(vbase + s * plane + (int64_t)vr * ld + vm_dc * 8);  \
+                unsigned off = vm_off + (unsigned)(((kt) * KT + j) * ld);                     \
+                if (ragged && (kt) * KT + vm_kq * 4 + j >= seq) off = (unsigned)((seq - 1) * ld + vm_dc * 8); \
+                rv[s][j] = *(const u128*)(vbase + s * plane + off);                           \
             }                                                                                 \
         }                                                                                     \
     }
-#define STORE_TILE()                                                                          \
+#define STORE_TILE(buf)                                                                        \
     _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                          \
-        unsigned char* kl = lds + s * PLANE_BYTES;                                            \
+        unsigned char* kl = lds + (buf) * BUF_BYTES + s * PLANE_BYTES;                        \
         unsigned char* vl = kl + K_BYTES;                                                     \
         _Pragma("unroll") for (int i = 0; i < KCPT; ++i)                                      \
             if (KCH % NT == 0 || tid + NT * i < KCH)                                          \
@@ -130,8 +147,8 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
                 uint2 lo, hi;                                                                 \
                 lo.x = (a0 & 0xffffu) | (a1 << 16); lo.y = (a2 & 0xffffu) | (a3 << 16);       \
                 hi.x = (a0 >> 16) | (a1 & 0xffff0000u); hi.y = (a2 >> 16) | (a3 & 0xffff0000u); \
-                *(uint2*)(vl + d * 128 + (vdst ^ (((d >> 1) & 7) << 4))) = lo;                \
-                *(uint2*)(vl + (d + 1) * 128 + (vdst ^ ((((d + 1) >> 1) & 7) << 4))) = hi;    \
+                *(uint2*)(vl + d * 128 + (vdst ^ (vswz(d) << 4))) = lo;                \
+                *(uint2*)(vl + (d + 1) * 128 + (vdst ^ (vswz(d + 1) << 4))) = hi;    \
             }                                                                                 \
         }                                                                                     \
     }
@@ -146,10 +163,11 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
 
     const int nt = (seq + KT - 1) / KT;
     LOAD_TILE(0)
-    STORE_TILE()
+    STORE_TILE(0)
     __syncthreads();
     for (int kt = 0; kt < nt; ++kt) {
         if (kt + 1 < nt) { LOAD_TILE(kt + 1) }
+        const unsigned char* cur = lds + (NBUF == 2 ? (kt & 1) : 0) * BUF_BYTES;
 
         // ---- S^T = K . Q^T  (two 32-key M-tiles)
         f32x16 sacc[2];
@@ -162,7 +180,7 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
                 vec8 kf[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
-                    kf[s] = as_vec8<T>(*(const u128*)(lds + s * PLANE_BYTES + (km * 32 + lq) * KSTRIDE + (ks * 2 + lh) * 16));
+                    kf[s] = as_vec8<T>(*(const u128*)(cur + s * PLANE_BYTES + (km * 32 + lq) * KSTRIDE + (ks * 2 + lh) * 16));
                 if (NS == 2) {
                     sacc[km] = Op16<T>::mfma(kf[NS - 1], qf[0][ks], sacc[km]);
                     sacc[km] = Op16<T>::mfma(kf[0], qf[NS - 1][ks], sacc[km]);
@@ -170,39 +188,45 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
                 sacc[km] = Op16<T>::mfma(kf[0], qf[0][ks], sacc[km]);
             }
         }
-        // ---- online softmax (base-2), per query = per lane pair (l, l^32)
+        // ---- online softmax (base-2), per query = per lane pair (l, l^32).  Scores stay raw; the softmax scale
+        // (times log2 e) is folded into the exponent:  p = exp2(s*sc - m*sc)  = one FMA + v_exp_f32 per score.
         float tmax = -INFINITY;
         const bool tail = (kt + 1) * KT > seq;
+        if (tail) {
+#pragma unroll
+            for (int km = 0; km < 2; ++km)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * KT + km * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= seq) sacc[km][r] = -INFINITY;
+                }
+        }
 #pragma unroll
         for (int km = 0; km < 2; ++km)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = sacc[km][r] * sc;
-                if (tail) {
-                    const int key = kt * KT + km * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (key >= seq) s = -INFINITY;
-                }
-                sacc[km][r] = s;
-                tmax = fmaxf(tmax, s);
-            }
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[km][r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
+        const float m_new = fmaxf(m_run, tmax);                     // raw-score units (sc > 0)
+        if (!__all(m_new == m_run)) {                               // some row's max moved: rescale O and l
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            m_run = m_new;
+        }
+        const float mneg = -m_run * sc;
         float psum = 0.f;
 #pragma unroll
         for (int km = 0; km < 2; ++km)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(sacc[km][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[km][r], sc, mneg));
                 sacc[km][r] = pv;
                 psum += pv;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < DM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T . P^T   (four 16-key groups)
 #pragma unroll
@@ -221,8 +245,8 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
                 vec8 vf[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
-                    vf[s] = as_vec8<T>(*(const u128*)(lds + s * PLANE_BYTES + K_BYTES + d * 128 +
-                                                        (((g * 2 + lh) ^ ((d >> 1) & 7)) << 4)));
+                    vf[s] = as_vec8<T>(*(const u128*)(cur + s * PLANE_BYTES + K_BYTES + d * 128 +
+                                                        (((g * 2 + lh) ^ vswz(d)) << 4)));
                 if (NS == 2) {
                     oacc[dm] = Op16<T>::mfma(vf[NS - 1], pf[0], oacc[dm]);
                     oacc[dm] = Op16<T>::mfma(vf[0], pf[NS - 1], oacc[dm]);
@@ -230,8 +254,9 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
                 oacc[dm] = Op16<T>::mfma(vf[0], pf[0], oacc[dm]);
             }
         }
-        __syncthreads();
-        if (kt + 1 < nt) { STORE_TILE() }
+        // the other buffer was last read in iteration kt-1, which every wave left through the barrier below
+        if (NBUF == 1) __syncthreads();                      // single buffer: everyone must be done reading first
+        if (kt + 1 < nt) { STORE_TILE(NBUF == 2 ? ((kt + 1) & 1) : 0) }
         __syncthreads();
     }
 #undef LOAD_TILE

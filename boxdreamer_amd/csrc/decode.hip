@@ -4,10 +4,12 @@
 // unweighted mean of the k integer (x, y) = (idx % W, idx / W).  `torch.topk` leaves the order of
 // equal values unspecified; this kernel pins: larger value first, then LOWER index first.
 //
-// One 256-thread workgroup per map, k selection rounds.  In each round every thread scans its
-// strided share of the map (coalesced, L2-resident: 200 KB per map) for the best element that comes
-// strictly AFTER the previous pick in (value desc, index asc) order, then a wave shuffle + LDS
-// reduction picks the workgroup's winner.  Deterministic, no atomics, no sorting network.
+// One 256-thread workgroup per map.  Every thread owns a CONTIGUOUS slice of the map and keeps one candidate:
+// the best element of its slice that comes strictly after the last global pick in (value desc, index asc) order.
+// A round = one workgroup arg-max over the 256 candidates (wave shuffles + 4 LDS slots); only the thread that won
+// rescans its slice (float4 loads, L1/L2-resident) for its next candidate.  k rounds -> one full pass over the map
+// plus k short slice rescans, instead of k full passes (first version: 1.34 ms for 256 maps; profiles/).
+// Deterministic, no atomics, exact tie rule.
 #include "bd_common.h"
 
 namespace {
@@ -16,26 +18,48 @@ __device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
     return (v > bv) || (v == bv && i < bi);
 }
 
+// best element of [lo, hi) strictly after (pv, pi); slices are 16-byte aligned when VEC
+template <bool VEC>
+__device__ __forceinline__ void scan_slice(const float* __restrict__ h, int lo, int hi, float pv, int pi, float& bv, int& bi) {
+    bv = -INFINITY;
+    bi = 0x7fffffff;
+    if (VEC) {
+        for (int i = lo; i < hi; i += 4) {
+            const float4 q = *(const float4*)(h + i);
+            const float e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = (e[j] + 1.0f) / 2.0f;              // box_utils.py:79
+                const bool after = (v < pv) || (v == pv && i + j > pi);
+                if (after && better(v, i + j, bv, bi)) { bv = v; bi = i + j; }
+            }
+        }
+    } else {
+        for (int i = lo; i < hi; ++i) {
+            const float v = (h[i] + 1.0f) / 2.0f;
+            const bool after = (v < pv) || (v == pv && i > pi);
+            if (after && better(v, i, bv, bi)) { bv = v; bi = i; }
+        }
+    }
+}
+
+template <bool VEC>
 __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ heat, int hw, int width, int height,
                                                      int k, float* __restrict__ kp_px, float* __restrict__ kp_norm,
                                                      int32_t* __restrict__ topk_idx) {
     __shared__ float sv[4];
     __shared__ int si[4];
-    __shared__ float pick_v;
-    __shared__ int pick_i;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* h = heat + (int64_t)blockIdx.x * hw;
-    float pv = INFINITY;
-    int pi = -1;
+    const int per = VEC ? hw / 256 : (hw + 255) / 256;
+    const int lo = tid * per, hi = (lo + per) < hw ? (lo + per) : hw;
+    float cv;
+    int ci;
+    scan_slice<VEC>(h, lo, hi, INFINITY, -1, cv, ci);
     float sx = 0.f, sy = 0.f;
     for (int round = 0; round < k; ++round) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int i = tid; i < hw; i += 256) {
-            const float v = (h[i] + 1.0f) / 2.0f;             // box_utils.py:79
-            const bool after = (v < pv) || (v == pv && i > pi);
-            if (after && better(v, i, bv, bi)) { bv = v; bi = i; }
-        }
+        float bv = cv;
+        int bi = ci;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(bv, o);
@@ -44,17 +68,16 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
         }
         if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
         __syncthreads();
-        if (tid == 0) {
-            float fv = sv[0]; int fi = si[0];
-            for (int w = 1; w < 4; ++w) if (better(sv[w], si[w], fv, fi)) { fv = sv[w]; fi = si[w]; }
-            pick_v = fv; pick_i = fi;
-            if (topk_idx) topk_idx[(int64_t)blockIdx.x * k + round] = fi;
-        }
+        float fv = sv[0];
+        int fi = si[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (better(sv[w], si[w], fv, fi)) { fv = sv[w]; fi = si[w]; }
         __syncthreads();
-        pv = pick_v; pi = pick_i;
-        sx += (float)(pi % width);
-        sy += (float)(pi / width);
-        __syncthreads();
+        if (tid == 0 && topk_idx) topk_idx[(int64_t)blockIdx.x * k + round] = fi;
+        sx += (float)(fi % width);
+        sy += (float)(fi / width);
+        if (fi >= lo && fi < hi) scan_slice<VEC>(h, lo, hi, fv, fi, cv, ci);    // only the winner refills
     }
     if (tid == 0) {
         const float mx = sx / (float)k, my = sy / (float)k;    // xs.float().mean(dim=2)
@@ -73,8 +96,13 @@ extern "C" int bd_decode_topk(const float* heat, int n_maps, int height, int wid
                               float* kp_norm, int32_t* topk_idx, void* stream) {
     if (!heat || !kp_px) return BD_ERR_NULL;
     if (n_maps <= 0 || height <= 0 || width <= 0 || k <= 0 || (int64_t)k > (int64_t)height * width) return BD_ERR_SHAPE;
-    hipLaunchKernelGGL(decode_kernel, dim3(n_maps), dim3(256), 0, (hipStream_t)stream, heat, height * width, width,
-                       height, k, kp_px, kp_norm, topk_idx);
+    const int hw = height * width;
+    if (hw % 1024 == 0 && ((uintptr_t)heat & 15) == 0)      // 256 slices of a multiple of 4 floats: float4 scans
+        hipLaunchKernelGGL(decode_kernel<true>, dim3(n_maps), dim3(256), 0, (hipStream_t)stream, heat, hw, width, height,
+                           k, kp_px, kp_norm, topk_idx);
+    else
+        hipLaunchKernelGGL(decode_kernel<false>, dim3(n_maps), dim3(256), 0, (hipStream_t)stream, heat, hw, width, height,
+                           k, kp_px, kp_norm, topk_idx);
     BD_CHECK_LAUNCH();
     return BD_OK;
 }
