@@ -466,124 +466,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 2 : 2)) void gemm_ker
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Multi-stage LDS-DMA ring (NS = 1): STAGES slabs of depth BK; STAGES-1 slabs are in flight while one is being
-// multiplied.  Per slab: counted  s_waitcnt vmcnt(N)  (this wave's pieces of slab kt have landed, newer slabs may
-// still fly) -> raw s_barrier (everyone's pieces landed; everyone finished reading slab kt-1) -> issue the DMA for
-// slab kt+STAGES-1 into the buffer slab kt-1 just vacated -> MFMAs on slab kt.  Never drains to vmcnt(0) in the
-// steady state.  (The 2-stage kernel above waits for the ONLY in-flight slab every iteration: measured 45 % of
-// the MFMA rate in its mainloop, profiles/r1_gemm_ksweep.txt.)
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
-
-template <class T, int BK, int STAGES, int WM, int WN, int MI, int NI>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_ring(const bd_gemm_args p) {
-    typedef typename Op16<T>::vec8 vec8;
-    constexpr int NS = 1;
-    constexpr int NWAVE = WM * WN;
-    constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32;
-    constexpr int CH = BK / 8, RPP = 64 / CH;
-    constexpr int A_BYTES = TBM * BK * 2, W_BYTES = TBN * BK * 2;
-    constexpr int PPW_A = A_BYTES / 1024 / NWAVE, PPW_W = W_BYTES / 1024 / NWAVE;
-    static_assert(PPW_A >= 1 && PPW_W >= 1 && A_BYTES % (1024 * NWAVE) == 0 && W_BYTES % (1024 * NWAVE) == 0, "tile/DMA split");
-    constexpr int PPS = PPW_A + PPW_W;                 // DMA instructions per wave per slab
-    constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-    constexpr int KS = BK / 16;
-    static_assert(STAGES >= 2 && STAGES <= 5, "ring depth");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[STAGES * STAGE_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / WN, wn = wid % WN;
-    int m0, n0;
-    tile_coords_t<TBM, TBN>(p.M, p.N, TBM >= 256 ? 4 : 8, m0, n0);
-
-    const T* ga[PPW_A];
-    const T* gw[PPW_W];
-#pragma unroll
-    for (int i = 0; i < PPW_A; ++i) {
-        const int row = (wid * PPW_A + i) * RPP + lane / CH;
-        int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
-        ga[i] = (const T*)p.A + (int64_t)ar * p.lda + swz_chunk<BK>(row, lane % CH) * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < PPW_W; ++i) {
-        const int row = (wid * PPW_W + i) * RPP + lane / CH;
-        int wr = n0 + row; wr = wr < p.N ? wr : p.N - 1;
-        gw[i] = (const T*)p.W + (int64_t)wr * p.ldw + swz_chunk<BK>(row, lane % CH) * 8;
-    }
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-#define DMA_SLAB(buf, k0)                                                                                     \
-    {                                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < PPW_A; ++i)                                                     \
-            __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + (k0)),                                          \
-                (lptr_t)(lds + (buf) * STAGE_BYTES + (wid * PPW_A + i) * 1024), 16, 0, 0);                    \
-        _Pragma("unroll") for (int i = 0; i < PPW_W; ++i)                                                     \
-            __builtin_amdgcn_global_load_lds((gptr_t)(gw[i] + (k0)),                                          \
-                (lptr_t)(lds + (buf) * STAGE_BYTES + A_BYTES + (wid * PPW_W + i) * 1024), 16, 0, 0);          \
-    }
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int lrow = lane & 31, lhalf = lane >> 5;
-    const int nk = p.K / BK;
-#pragma unroll
-    for (int st = 0; st < STAGES - 1; ++st)
-        if (st < nk) DMA_SLAB(st, st * BK)
-
-    int buf = 0;                                            // buffer of slab kt
-    for (int kt = 0; kt < nk; ++kt) {
-        // slabs issued so far: min(nk, kt + STAGES - 1); slab kt must have landed -> allow the newer ones to fly
-        const int newer = (nk - 1 - kt) < (STAGES - 2) ? (nk - 1 - kt) : (STAGES - 2);
-        if (newer >= 3) wait_vmcnt<3 * PPS>();
-        else if (newer == 2) wait_vmcnt<2 * PPS>();
-        else if (newer == 1) wait_vmcnt<1 * PPS>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        {
-            const int nxt = kt + STAGES - 1;
-            const int nbuf = buf == 0 ? STAGES - 1 : buf - 1;   // == (kt - 1) mod STAGES == nxt mod STAGES
-            if (nxt < nk) DMA_SLAB(nbuf, nxt * BK)
-        }
-        const unsigned char* base = lds + buf * STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            vec8 a[MI], b[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int r = wm * (MI * 32) + i * 32 + lrow;
-                a[i] = as_vec8<T>(*(const u128*)(base + r * (BK * 2) + (swz_chunk<BK>(r, ks * 2 + lhalf) << 4)));
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int r = wn * (NI * 32) + j * 32 + lrow;
-                b[j] = as_vec8<T>(*(const u128*)(base + A_BYTES + r * (BK * 2) + (swz_chunk<BK>(r, ks * 2 + lhalf) << 4)));
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = Op16<T>::mfma(a[i], b[j], acc[i][j]);
-        }
-        buf = buf + 1 == STAGES ? 0 : buf + 1;
-    }
-#undef DMA_SLAB
-    const bool wide = (p.N % 8 == 0) && (p.ldo % 8 == 0) && (((uintptr_t)p.out & 15) == 0) &&
-                      (!p.resid || ((p.ldr % 4 == 0) && ((uintptr_t)p.resid & 15) == 0)) &&
-                      (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.addtab || ((uintptr_t)p.addtab & 15) == 0);
-    if (wide) {
-        __syncthreads();
-        gemm_epilogue_lds<T, NS, MI, NI>(p, acc, lds + wid * (32 * NI * 32 * 4), m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
-    } else {
-        gemm_epilogue<T, NS, MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
-    }
-}
-
 int gemm_impl() {   // BD_GEMM_IMPL=0 selects the register-staged mainloop (A/B measurements only)
     static const int impl = [] { const char* e = getenv("BD_GEMM_IMPL"); return e ? atoi(e) : 1; }();
     return impl;
@@ -595,30 +477,12 @@ template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_g
     hipLaunchKernelGGL((gemm_kernel_glds<T, NS, BK, WM, WN, MI, NI>), dim3(tiles), dim3(WM * WN * 64), 0, s, a);
 }
 
-template <class T, int BK, int STAGES, int WM, int WN, int MI, int NI> void launch_ring(const bd_gemm_args& a, hipStream_t s) {
-    constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32;
-    const int tiles = ((a.M + TBM - 1) / TBM) * ((a.N + TBN - 1) / TBN);
-    hipLaunchKernelGGL((gemm_kernel_ring<T, BK, STAGES, WM, WN, MI, NI>), dim3(tiles), dim3(WM * WN * 64), 0, s, a);
-}
-
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     const int impl = gemm_impl();
     if (impl == 0) {
         const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
         hipLaunchKernelGGL((gemm_kernel_regstage<T, NS, BK>), dim3(tiles), dim3(256), 0, s, a);
-    } else if (NS == 1 && impl >= 10 && a.M >= 1024 && a.K % 64 == 0) {   // ring variants (measurement)
-        if constexpr (NS == 1) {
-            const bool wideN = a.N >= 1536;
-            if (impl == 10) { if (wideN) launch_ring<T, 32, 4, 2, 4, 4, 2>(a, s); else launch_ring<T, 32, 4, 2, 2, 2, 2>(a, s); }
-            else if (impl == 11) { if (wideN) launch_ring<T, 64, 2, 2, 4, 4, 2>(a, s); else launch_ring<T, 64, 2, 2, 2, 2, 2>(a, s); }
-            else if (impl == 12) { if (wideN) launch_ring<T, 32, 5, 2, 4, 4, 2>(a, s); else launch_ring<T, 32, 5, 2, 2, 2, 2>(a, s); }
-            else if (impl == 13) { if (wideN) launch_ring<T, 32, 3, 2, 4, 4, 2>(a, s); else launch_ring<T, 64, 3, 2, 4, 4, 1>(a, s); }
-            else if (impl == 20) launch_glds<T, 1, 32, 2, 2, 4, 2>(a, s);     // 256x128, 4 waves, 48 KiB: 2 workgroups / CU
-            else if (impl == 21) launch_ring<T, 32, 3, 2, 2, 4, 2>(a, s);     // same, 3-deep ring (72 KiB)
-            else if (impl == 22) launch_glds<T, 1, 32, 2, 2, 2, 4>(a, s);     // 128x256, 4 waves
-            else { if (wideN) launch_ring<T, 32, 4, 2, 4, 4, 2>(a, s); else launch_ring<T, 64, 2, 2, 2, 2, 2>(a, s); }
-        }
     } else if (impl == 2 || a.M < 1024 || a.N < 1536) {
         launch_glds<T, NS, BK, 2, 2, 2, 2>(a, s);                 // 128 x 128 (2 workgroups / CU): N = 768 outputs
     } else if (impl == 3) {
