@@ -1,0 +1,82 @@
+"""Reference-feature caching across queries ("next" row f1 of SURVEY.md §8).
+
+In the test / demo loops the SAME N posed reference crops accompany every query frame of an object, but the reference
+re-encodes them for every query (/root/reference/src/models/BoxDreamerModel.py:274-285; SURVEY.md §7 "hard parts").
+DINOv2 features are per-image and input-independent of the other views, so they can be computed once per object:
+per pose the encoder then runs on 1 crop instead of T (T=6: 282 -> 47 GFLOP of the 638 GFLOP/pose).
+
+Usage (caller side):
+    cache = RefFeatureCache(model.rgb_encoder)
+    ref_feats = cache.encode(ref_images)                      # (B, T-1, 3, H, W) -> tagged features, once per object
+    data["cached_rgb_feat"], data["cached_rgb_mask"] = cache.place(ref_feats, query_idx, T)
+    model(data)                                               # encodes only the views whose mask is False
+Results are bit-identical to the uncached forward (tests/test_gpu_facade.py).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+class RefFeatureCache:
+    def __init__(self, encoder):
+        self.encoder = encoder                                 # a DinoV2Wrapper
+
+    def encode(self, images: torch.Tensor) -> torch.Tensor:
+        """(B, R, 3, H, W) -> (B, R, P, C) fp32 features tagged with their operand-dtype copy."""
+        return self.encoder.predict(images)
+
+    @staticmethod
+    def _feats16_view(feats: torch.Tensor):
+        tag = getattr(feats, "_bd_feats16", None)
+        if tag is None:
+            raise ValueError("features were not produced by the HIP encoder (no operand-dtype copy attached)")
+        return tag
+
+    def place(self, ref_feats: torch.Tensor, query_idx: torch.Tensor, T: int):
+        """Scatter R = T-1 cached reference features into a (B, T, P, C) layout leaving the query slot empty.
+        Returns (features, valid_mask (B, T) bool)."""
+        B, R, P, C = ref_feats.shape
+        assert R == T - 1
+        f16, pid = self._feats16_view(ref_feats)
+        dev = ref_feats.device
+        valid = torch.ones((B, T), dtype=torch.bool, device=dev)
+        valid[torch.arange(B, device=dev), query_idx.to(dev).long()] = False
+        full32 = torch.zeros((B, T, P, C), dtype=torch.float32, device=dev)
+        full32[valid] = ref_feats.reshape(B * R, P, C)
+        np_ = _lib.planes(pid)
+        if np_ == 2:
+            full16 = torch.zeros((2, B, T, P, C), dtype=f16.dtype, device=dev)
+            full16[:, valid] = f16.reshape(2, B * R, P, C)
+            full16 = full16.reshape(2, B * T * P, C)
+        else:
+            full16 = torch.zeros((B, T, P, C), dtype=f16.dtype, device=dev)
+            full16[valid] = f16.reshape(B * R, P, C)
+            full16 = full16.reshape(B * T * P, C)
+        full32._bd_feats16 = (full16, pid)
+        return full32, valid
+
+
+def merge_cached_features(encoder, images: torch.Tensor, cached: torch.Tensor, valid: torch.Tensor) -> torch.Tensor:
+    """Encode only the views with valid == False and write them into (a copy of) the cached layout."""
+    B, T = images.shape[:2]
+    f16, pid = RefFeatureCache._feats16_view(cached)
+    miss = ~valid
+    new = encoder.predict(images[miss])                       # (n_miss, P, C), tagged
+    n16, npid = RefFeatureCache._feats16_view(new)
+    if npid != pid:
+        raise ValueError("cached features were produced in a different precision mode")
+    P, C = cached.shape[2:]
+    out32 = cached.clone()
+    out32[miss] = new
+    if _lib.planes(pid) == 2:
+        out16 = f16.clone().reshape(2, B, T, P, C)
+        out16[:, miss] = n16.reshape(2, -1, P, C)
+        out16 = out16.reshape(2, B * T * P, C)
+    else:
+        out16 = f16.clone().reshape(B, T, P, C)
+        out16[miss] = n16.reshape(-1, P, C)
+        out16 = out16.reshape(B * T * P, C)
+    out32._bd_feats16 = (out16, pid)
+    return out32

@@ -133,6 +133,69 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict
     }
 }
 
+
+// Corner heatmap rendering -- the dataset-side producer of `bbox_feat` ("next" row f2):
+// make_bbox_features(type='heatmap'), src/datasets/utils/base/bbox_utils.py:263-303.
+// corners [groups*group, 8, 2] pixel (x, y) -> out [groups*group, 8, H, W] in [-1, 1].
+// v = exp(-dist / (dist_to_centroid/10)^2); divided by the max over the whole call-group for that corner index
+// (the reference's bbox_map[..., i].max() spans all views of the sample); then 2v - 1.  The max is the value at the
+// pixel nearest to the corner (exp(-d/s) is monotone in d), so it is evaluated analytically with the SAME arithmetic
+// instead of a reduction over H*W pixels.
+__device__ __forceinline__ float corner_value(float bx, float by, float px, float py, float scale) {
+    const float dx = bx - px, dy = by - py;
+    const float d = sqrtf(dx * dx + dy * dy);
+    return expf(-d / scale);
+}
+
+__global__ __launch_bounds__(256) void render_heat_kernel(const float* __restrict__ corners, int group, int H, int W,
+                                                          void* __restrict__ out, int out_dtype) {
+    __shared__ float s_max;
+    const int map = blockIdx.y;                       // (view, corner)
+    const int view = map >> 3, ci = map & 7;
+    const int g0 = (view / group) * group;            // first view of this call-group
+    if (threadIdx.x == 0) {
+        float gmax = -INFINITY;
+        for (int v = g0; v < g0 + group; ++v) {
+            const float* c = corners + (int64_t)v * 16;
+            float cx = 0.f, cy = 0.f;
+            for (int k = 0; k < 8; ++k) { cx += c[2 * k]; cy += c[2 * k + 1]; }
+            cx /= 8.0f; cy /= 8.0f;                   // bbox.mean(dim=1)
+            const float bx = c[2 * ci], by = c[2 * ci + 1];
+            const float ex = cx - bx, ey = cy - by;
+            const float dis = sqrtf(ex * ex + ey * ey);
+            const float sc = (dis / 10.0f) * (dis / 10.0f);
+            const float nx = fminf(fmaxf(rintf(bx), 0.f), (float)(W - 1));
+            const float ny = fminf(fmaxf(rintf(by), 0.f), (float)(H - 1));
+            float best = corner_value(bx, by, nx, ny, sc);
+            // rint ties / clamping: also probe the 4 neighbours so the true arg-min pixel is always covered
+            const float ox[4] = {-1.f, 1.f, 0.f, 0.f}, oy[4] = {0.f, 0.f, -1.f, 1.f};
+            for (int k = 0; k < 4; ++k) {
+                const float qx = nx + ox[k], qy = ny + oy[k];
+                if (qx >= 0.f && qx <= (float)(W - 1) && qy >= 0.f && qy <= (float)(H - 1))
+                    best = fmaxf(best, corner_value(bx, by, qx, qy, sc));
+            }
+            gmax = fmaxf(gmax, best);
+        }
+        s_max = gmax;
+    }
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= H * W) return;
+    const float* c = corners + (int64_t)view * 16;
+    float cx = 0.f, cy = 0.f;
+    for (int k = 0; k < 8; ++k) { cx += c[2 * k]; cy += c[2 * k + 1]; }
+    cx /= 8.0f; cy /= 8.0f;
+    const float bx = c[2 * ci], by = c[2 * ci + 1];
+    const float ex = cx - bx, ey = cy - by;
+    const float dis = sqrtf(ex * ex + ey * ey);
+    const float sc = (dis / 10.0f) * (dis / 10.0f);
+    const float v = corner_value(bx, by, (float)(pix % W), (float)(pix / W), sc) / s_max * 2.0f - 1.0f;
+    const int64_t o = (int64_t)map * H * W + pix;
+    if (out_dtype == BD_DTYPE_F32) ((float*)out)[o] = v;
+    else if (out_dtype == BD_DTYPE_BF16) ((__bf16*)out)[o] = (__bf16)v;
+    else ((_Float16*)out)[o] = (_Float16)v;
+}
+
 inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
 
 }  // namespace
@@ -213,6 +276,18 @@ extern "C" int bd_unpatchify_sigmoid(const float* proj, float* logits, float* he
     const int64_t total = (int64_t)B * size * size;
     hipLaunchKernelGGL(unpatchify_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, proj, logits, heat,
                        B, size, patch);
+    BD_CHECK_LAUNCH();
+    return BD_OK;
+}
+
+extern "C" int bd_render_corner_heatmaps(const float* corners, int n_groups, int group, int height, int width,
+                                         void* out, int out_dtype, void* stream) {
+    if (!corners || !out) return BD_ERR_NULL;
+    if (n_groups <= 0 || group <= 0 || height <= 0 || width <= 0) return BD_ERR_SHAPE;
+    if (out_dtype < 0 || out_dtype > 2) return BD_ERR_DTYPE;
+    const dim3 grid((unsigned)((height * width + 255) / 256), (unsigned)(n_groups * group * 8));
+    hipLaunchKernelGGL(render_heat_kernel, grid, dim3(256), 0, (hipStream_t)stream, corners, group, height, width, out,
+                       out_dtype);
     BD_CHECK_LAUNCH();
     return BD_OK;
 }

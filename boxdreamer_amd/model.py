@@ -11,6 +11,7 @@ import torch.nn as nn
 
 from .betr import BETR
 from .box_utils import recover_bb8_corners_chw, solve_poses_host
+from .cache import merge_cached_features
 from .config import setup_camera_params, validate_model_config
 from .encoder import DinoV2Wrapper
 
@@ -79,7 +80,11 @@ class BoxDreamer(nn.Module):
 
         if images.device != self.rgb_encoder.get_device():
             self.rgb_encoder.to_device(images.device)                            # BoxDreamerModel.py:279-282
-        rgb_feature = self.rgb_encoder.predict(images)
+        if "cached_rgb_feat" in data:       # "next" row f1: references encoded once per object (boxdreamer_amd/cache.py)
+            rgb_feature = merge_cached_features(self.rgb_encoder, images, data["cached_rgb_feat"],
+                                                data["cached_rgb_mask"])
+        else:
+            rgb_feature = self.rgb_encoder.predict(images)
         query_ret = self.decoder(pose_feat, images, camera_mask, rgb_feature, None)
 
         data["pred_bbox"] = data["bbox_feat"].clone()                            # BoxDreamerModel.py:341-344

@@ -139,6 +139,14 @@ int bd_unpatchify_sigmoid(const float* proj, float* logits, float* heat, int B, 
 int bd_decode_topk(const float* heat, int n_maps, int height, int width, int k, float* kp_px,
                    float* kp_norm, int32_t* topk_idx, void* stream);
 
+/* Corner heatmap rendering, the producer of `bbox_feat` one step BEFORE the path ("next" row f2):
+ * make_bbox_features(type='heatmap'), src/datasets/utils/base/bbox_utils.py:263-303 (called per sample at
+ * src/datasets/base.py:689-693).  corners: fp32 [n_groups*group, 8, 2] pixel (x, y); each consecutive run of `group`
+ * views is one reference call (the per-corner max spans the run).  out: [n_groups*group, 8, height, width] in
+ * out_dtype (BD_DTYPE_*). */
+int bd_render_corner_heatmaps(const float* corners, int n_groups, int group, int height, int width,
+                              void* out, int out_dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Whole-path entry points
  * ---------------------------------------------------------------------------------------- */

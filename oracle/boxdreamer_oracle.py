@@ -227,6 +227,31 @@ def recover_bb8_corners(heat: torch.Tensor, k: int = 20):
     return norm, kp, idx
 
 
+# ----------------------------------------------------------------------------- input rendering ("next" row f2)
+
+def make_bbox_features(bbox: torch.Tensor, size) -> torch.Tensor:
+    """'heatmap' branch of make_bbox_features, src/datasets/utils/base/bbox_utils.py:263-303 (the dataset-side
+    producer of `bbox_feat`, called at src/datasets/base.py:689-693): bbox (B,8,2) pixel (x,y) -> (B,8,H,W) fp32.
+    Per corner: exp(-dist / (dist_to_centroid / 10)^2) / max, mapped to [-1, 1]; all torch fp32 like the reference."""
+    H, W = size
+    B = bbox.shape[0]
+    bbox = bbox.float().view(B, 8, 2)
+    out = torch.zeros((B, H, W, 8), dtype=torch.float32)
+    ix = torch.arange(W, dtype=torch.float32)
+    iy = torch.arange(H, dtype=torch.float32)
+    center = bbox.mean(dim=1)
+    for i in range(8):
+        dx = bbox[:, i, 0].view(B, 1, 1).expand(B, H, W) - ix.view(1, 1, W).expand(B, H, W)
+        dy = bbox[:, i, 1].view(B, 1, 1).expand(B, H, W) - iy.view(1, H, 1).expand(B, H, W)
+        d = torch.sqrt(dx ** 2 + dy ** 2)
+        dis = torch.sqrt((center[:, 0] - bbox[:, i, 0]) ** 2 + (center[:, 1] - bbox[:, i, 1]) ** 2)
+        scale = (dis / 10) ** 2
+        v = torch.exp(-d / scale.unsqueeze(-1).unsqueeze(-1))
+        v = v / v.max()          # NOTE: the reference normalises by the max over the WHOLE batch (bbox_map[..., i].max())
+        out[..., i] = v * 2 - 1
+    return out.permute(0, 3, 1, 2)
+
+
 # ----------------------------------------------------------------------------- facade
 
 def boxdreamer_forward(data: dict, betr_sd: dict, dino_sd: dict, nhead: int = 8,

@@ -154,6 +154,15 @@ def unit_vectors(betr, dino):
     out["decode_heat_seed"] = np.int64(5)
     out["decode_kp"] = kp[:, 0].numpy()
     out["decode_norm_kp"] = nk[:, 0].numpy()
+    # make_bbox_features (dataset-side producer of bbox_feat; "next" row f2) -- the real reference function
+    mbf = ref_import.load_make_bbox_features()
+    corners = torch.from_numpy(synth.uniform_np("unit.corners", (3, 8, 2), 20.0, 204.0, 17).astype(np.float32))
+    corners[1, 2] = torch.tensor([100.0, 57.0])                   # a corner exactly on a pixel centre
+    corners[2, 5] = torch.tensor([-3.25, 230.5])                  # and one outside the crop
+    ref_h = mbf(corners, type="heatmap", shape=(224, 224))
+    assert float((orc.make_bbox_features(corners, (224, 224)) - ref_h).abs().max()) <= 1e-6
+    out["bbox_features_strided"] = ref_h.reshape(-1)[::11].numpy()
+    out["bbox_features_max_per_map"] = ref_h.reshape(3, 8, -1).max(-1)[0].numpy()
     np.savez_compressed(os.path.join(GOLD, "unit_vectors.npz"), **out)
 
 

@@ -113,3 +113,17 @@ def build_dino(depth=12):
     if depth != 12:                      # reduced-depth fixtures: keep the first `depth` blocks
         m.blocks = m.blocks[:depth]
     return m.eval()
+
+
+def load_make_bbox_features():
+    """The dataset-side `make_bbox_features` (src/datasets/utils/base/bbox_utils.py:215-303).  Its module imports cv2 /
+    PIL / a sibling `preprocess` module at import time only; the heatmap branch is pure torch."""
+    load()
+    for pkg, path in (("src.datasets", REF + "/src/datasets"), ("src.datasets.utils", REF + "/src/datasets/utils"),
+                      ("src.datasets.utils.base", REF + "/src/datasets/utils/base")):
+        if pkg not in sys.modules:
+            _mk(pkg, path)
+    if "src.datasets.utils.preprocess" not in sys.modules:
+        _mk("src.datasets.utils.preprocess").generate_cornernet_heatmap = None
+    import importlib
+    return importlib.import_module("src.datasets.utils.base.bbox_utils").make_bbox_features

@@ -78,3 +78,28 @@ def test_unsupported_configs_raise():
     cfg["modules"]["encoder"]["name"] = "resnet"
     with pytest.raises(NotImplementedError):
         BoxDreamer(cfg)
+
+
+def test_reference_feature_cache_is_bit_identical(hip):
+    """"next" row f1: encoding the references once and only the query per pose gives the same bits."""
+    from boxdreamer_amd.cache import RefFeatureCache
+    for prec in ("bf16", "bf16x3"):
+        model = BoxDreamer(_config(prec))
+        model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
+        model = model.cuda().eval()
+        B, T = 2, 4
+        data = synth.make_batch(seed=9, B=B, T=T)
+        data["query_idx"] = torch.tensor([3, 1])
+        dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+        ref = model(dict(dev))
+        logits_ref = model.decoder.last_logits.clone()
+        cache = RefFeatureCache(model.rgb_encoder)
+        cm = ref["camera_mask"]
+        ref_imgs = dev["images"][~cm].reshape(B, T - 1, 3, 224, 224)
+        feats = cache.encode(ref_imgs)
+        d2 = dict(dev)
+        d2["cached_rgb_feat"], d2["cached_rgb_mask"] = cache.place(feats, dev["query_idx"], T)
+        out = model(d2)
+        assert torch.equal(model.decoder.last_logits, logits_ref)
+        assert torch.equal(out["pred_bbox"], ref["pred_bbox"])
+        assert torch.equal(out["regression_boxes"], ref["regression_boxes"])

@@ -174,3 +174,25 @@ def test_decode_topk(hip, golden_dir):
     assert torch.equal(idx.cpu().long(), oidx)
     assert torch.equal(kp.cpu(), okp)
     assert idx[0, 0].cpu().tolist() == list(range(20))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_render_corner_heatmaps(hip, golden_dir, dtype):
+    """bd_render_corner_heatmaps vs the oracle restatement of make_bbox_features and the reference's own output."""
+    from boxdreamer_amd.bbox_features import make_bbox_features
+    corners = torch.from_numpy(synth.uniform_np("unit.corners", (3, 8, 2), 20.0, 204.0, 17).astype(np.float32))
+    corners[1, 2] = torch.tensor([100.0, 57.0])
+    corners[2, 5] = torch.tensor([-3.25, 230.5])
+    got = make_bbox_features(corners.cuda(), type="heatmap", shape=(224, 224), dtype=dtype).float().cpu()
+    ref = orc.make_bbox_features(corners, (224, 224))
+    tol = 4e-6 if dtype == torch.float32 else 2.0 ** -8
+    assert (got - ref).abs().max().item() <= tol
+    if dtype == torch.float32:
+        g = np.load(f"{golden_dir}/unit_vectors.npz")
+        assert np.abs(got.reshape(-1)[::11].numpy() - g["bbox_features_strided"]).max() <= 4e-6
+        assert got.max().item() == 1.0
+    # several samples in one launch: the normalisation max is per group of views, as in per-sample dataset calls
+    two = torch.cat([corners, corners.flip(0) * 0.9 + 5.0])
+    got2 = make_bbox_features(two.cuda(), shape=(224, 224), group=3).cpu()
+    ref2 = torch.cat([orc.make_bbox_features(two[:3], (224, 224)), orc.make_bbox_features(two[3:], (224, 224))])
+    assert (got2 - ref2).abs().max().item() <= 4e-6
