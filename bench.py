@@ -117,6 +117,10 @@ def main():
     ap.add_argument("--cache-refs", action="store_true",
                     help="'next' row f1: reference features encoded once outside the timed region; per step the encoder "
                          "sees only the query crops (different algorithmic FLOPs -> reported as its own metric)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="split the per-GPU batch into this many independent sub-batches, each on its own HIP stream "
+                         "(samples are independent units; overlaps memory-bound phases of one with MFMA phases of another)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (latency mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -140,6 +144,11 @@ def main():
     lib = _lib.load()
     B, T, prec = args.batch, args.views, args.prec
     enc, dec = build_models(prec, device)
+    nstream = max(1, args.streams)
+    lanes = [(enc, dec, torch.cuda.current_stream(device))]
+    for _ in range(nstream - 1):
+        e2, d2 = build_models(prec, device)
+        lanes.append((e2, d2, torch.cuda.Stream(device=device)))
     # synthetic batch: every rank gets its own shard (different seed), values pre-rounded to bf16 as the
     # reference dataset does; tensors are bf16 on device (the dataset's `precision`), resident before timing.
     one = synth.make_batch(seed=100 + rank, B=min(B, 4), T=T)
@@ -154,17 +163,49 @@ def main():
         cache = RefFeatureCache(enc)
         qidx = torch.full((B,), T - 1, dtype=torch.long, device=device)
         cached = cache.place(cache.encode(images[:, : T - 1]), qidx, T)
+        if max(1, args.streams) > 1:
+            raise SystemExit("--cache-refs with --streams > 1 is not wired up")
+
+    from boxdreamer_amd.dist import shard_range
+    spans = [shard_range(B, i, nstream) for i in range(nstream)]
+    kp_all = torch.empty((B, 8, 2), dtype=torch.float32, device=device)
+
+    def run_span(e, d, lo, hi):
+        if cached is not None:
+            feats = merge_cached_features(e, images[lo:hi], cached[0][lo:hi], cached[1][lo:hi])
+        else:
+            feats = e.predict(images[lo:hi])
+        heat = d(bbox[lo:hi], images[lo:hi], mask[lo:hi], feats, None)
+        kp, kn, _ = hip_ops.decode_topk(heat, want_idx=False)
+        kp_all[lo:hi] = kp
+
+    graphed = None
+    if args.graph:
+        if nstream > 1 or args.cache_refs:
+            raise SystemExit("--graph is wired for the plain single-stream step")
+        from boxdreamer_amd.graph import GraphedPath
+        graphed = GraphedPath(enc, dec, B, T, 224, torch.bfloat16, device)
+        graphed.set_inputs(images, bbox)
 
     def step():
-        if cached is not None:
-            feats = merge_cached_features(enc, images, cached[0], cached[1])
+        if graphed is not None:
+            kp = graphed.replay()[1]
+            return gather_corners(kp, world) if world > 1 else kp
+        main = torch.cuda.current_stream(device)
+        if nstream == 1:
+            run_span(enc, dec, 0, B)
         else:
-            feats = enc.predict(images)
-        heat = dec(bbox, images, mask, feats, None)
-        kp, kn, _ = hip_ops.decode_topk(heat, want_idx=False)
+            for (e, d, st), (lo, hi) in zip(lanes, spans):
+                if st is not main:
+                    st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    run_span(e, d, lo, hi)
+            for _, _, st in lanes:
+                if st is not main:
+                    main.wait_stream(st)
         if world > 1:
-            return gather_corners(kp, world)
-        return kp
+            return gather_corners(kp_all, world)
+        return kp_all
 
     for _ in range(args.warmup):
         step()
@@ -226,7 +267,7 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": f"configs[1]: 1 query + {T - 1} ref, 224x224, batch {B}/GPU, DINOv2 ViT-B/14-reg "
                                        f"+ BETR-12 + top-20 decode, random-init weights, inputs bf16 in HBM",
-                           "global_batch": B * world, "views": T, "parallelism": f"dp{world}",
+                           "global_batch": B * world, "views": T, "parallelism": f"dp{world}", "streams_per_gpu": nstream, "hip_graph": bool(args.graph),
                            "gflop_per_pose": round(fpp / 1e9, 2)},
                 "poses_per_s_per_gpu": round(value / world, 2),
                 "roofline": roofline}

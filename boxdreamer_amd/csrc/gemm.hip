@@ -483,12 +483,19 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
     if (impl == 0) {
         const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
         hipLaunchKernelGGL((gemm_kernel_regstage<T, NS, BK>), dim3(tiles), dim3(256), 0, s, a);
-    } else if (impl == 2 || a.M < 1024 || a.N < 1536) {
-        launch_glds<T, NS, BK, 2, 2, 2, 2>(a, s);                 // 128 x 128 (2 workgroups / CU): N = 768 outputs
     } else if (impl == 3) {
         launch_glds<T, NS, BK, 2, 4, 4, 1>(a, s);                 // 256 x 128 (measurement only)
     } else {
-        launch_glds<T, NS, BK, 2, 4, 4, 2>(a, s);                 // 256 x 256 (1 workgroup / CU): wide outputs
+        // tile by occupancy: the big tile only when it still fills the 256 CUs ~1.5x over; the small one for
+        // latency-mode problems (batch 1: M = 1536) where 128 x 128 would leave most CUs idle
+        const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
+        const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        if (impl != 2 && a.N >= 1536 && t256 >= 384)
+            launch_glds<T, NS, BK, 2, 4, 4, 2>(a, s);             // 256 x 256, 1 workgroup / CU
+        else if (t128 >= 192 || impl == 2)
+            launch_glds<T, NS, BK, 2, 2, 2, 2>(a, s);             // 128 x 128, 2 workgroups / CU
+        else
+            launch_glds<T, NS, BK, 2, 2, 1, 1>(a, s);             // 64 x 64
     }
     bd_trace_close(s, slot);
     BD_CHECK_LAUNCH();

@@ -1,0 +1,57 @@
+"""HIP-graph capture of the whole hot path (encoder -> decoder -> corner decode) for a fixed shape.
+
+The path is ~300 short-to-medium kernel launches per step; at small batch (the demo loop runs batch 1,
+/root/reference/src/demo/demo.py:1451-1506) host launch cost and inter-kernel gaps dominate.  All entry points enqueue on the
+caller's stream, never synchronise and never allocate, so the sequence is capturable as is: inputs are copied into static
+buffers, the graph is replayed, outputs are read from static buffers.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hip_ops
+
+
+class GraphedPath:
+    def __init__(self, encoder, decoder, B: int, T: int, size: int = 224, in_dtype: torch.dtype = torch.bfloat16,
+                 device=None, want_idx: bool = False):
+        self.encoder, self.decoder = encoder, decoder
+        dev = torch.device("cuda") if device is None else torch.device(device)
+        self.images = torch.zeros((B, T, 3, size, size), dtype=in_dtype, device=dev)
+        self.bbox_feat = torch.zeros((B, T, 8, size, size), dtype=in_dtype, device=dev)
+        self.mask = torch.zeros((B, T), dtype=torch.bool, device=dev)
+        self.mask[:, T - 1] = True
+        self.want_idx = want_idx
+        # warm-up on a side stream (allocates workspaces / packs weights outside the capture), then capture
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._run()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._run()
+
+    def _run(self):
+        feats = self.encoder.predict(self.images)
+        heat = self.decoder(self.bbox_feat, self.images, self.mask, feats, None)
+        kp, kn, idx = hip_ops.decode_topk(heat, want_idx=self.want_idx)
+        return heat, kp, kn, idx
+
+    def set_inputs(self, images: torch.Tensor, bbox_feat: torch.Tensor, query_idx: torch.Tensor | None = None):
+        self.images.copy_(images, non_blocking=True)
+        self.bbox_feat.copy_(bbox_feat, non_blocking=True)
+        if query_idx is not None:
+            self.mask.zero_()
+            self.mask[torch.arange(self.mask.shape[0], device=self.mask.device), query_idx.to(self.mask.device).long()] = True
+
+    def replay(self):
+        """Replays the captured step on the current stream; returns (heat, kp_px, kp_norm, idx) static tensors."""
+        self.graph.replay()
+        return self.out
+
+    def __call__(self, images, bbox_feat, query_idx=None):
+        self.set_inputs(images, bbox_feat, query_idx)
+        return self.replay()

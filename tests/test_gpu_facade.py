@@ -103,3 +103,22 @@ def test_reference_feature_cache_is_bit_identical(hip):
         assert torch.equal(model.decoder.last_logits, logits_ref)
         assert torch.equal(out["pred_bbox"], ref["pred_bbox"])
         assert torch.equal(out["regression_boxes"], ref["regression_boxes"])
+
+
+def test_hip_graph_replay_matches_eager(hip):
+    from boxdreamer_amd import hip_ops
+    from boxdreamer_amd.graph import GraphedPath
+    model = BoxDreamer(_config("bf16"))
+    model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
+    model = model.cuda().eval()
+    B, T = 2, 3
+    g = GraphedPath(model.rgb_encoder, model.decoder, B, T, 224, torch.float32, "cuda", want_idx=True)
+    for seed, qi in ((8, [2, 0]), (9, [1, 1])):
+        data = synth.make_batch(seed=seed, B=B, T=T)
+        qidx = torch.tensor(qi)
+        heat, kp, kn, idx = g(data["images"].cuda(), data["bbox_feat"].cuda(), qidx)
+        mask = torch.zeros(B, T, dtype=torch.bool); mask[torch.arange(B), qidx] = True
+        img, bf = data["images"].cuda(), data["bbox_feat"].cuda()
+        ref = model.decoder(bf, img, mask.cuda(), model.rgb_encoder.predict(img), None)
+        rkp, _, ridx = hip_ops.decode_topk(ref)
+        assert torch.equal(heat, ref) and torch.equal(kp, rkp) and torch.equal(idx, ridx)
