@@ -134,31 +134,38 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     sc[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
-            float4 rv[PASSES], tv[PASSES];
-            int64_t orow[PASSES];
-            bool ok[PASSES];
+            // global reads are issued in batches of PB passes (register budget: 2 float4 per pass in flight)
+            constexpr int PB = PASSES > 4 ? 4 : PASSES;
 #pragma unroll
-            for (int t = 0; t < PASSES; ++t) {          // batch the global reads
-                const int gr = wm0 + i * 32 + t * RPI + rsub;
-                ok[t] = cok && gr < M;
-                const int grc = gr < M ? gr : M - 1;
-                orow[t] = rpg_in > 0 ? (int64_t)(grc / rpg_in) * rpg_out + grc % rpg_in + row_off : (int64_t)grc;
-                rv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                tv[t] = rv[t];
-                if (resid && ok[t]) rv[t] = *(const float4*)(resid + orow[t] * ldr + gc);
-                if (addtab && ok[t]) tv[t] = *(const float4*)(addtab + (int64_t)(grc % tab_rows) * N + gc);
-            }
+            for (int t0 = 0; t0 < PASSES; t0 += PB) {
+                float4 rv[PB], tv[PB];
+                int64_t orow[PB];
+                bool ok[PB];
 #pragma unroll
-            for (int t = 0; t < PASSES; ++t) {
-                const float4 a = *(const float4*)(sc + (t * RPI + rsub) * COLS + c4 * 4);
-                float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
-                if (act == BD_ACT_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                for (int u = 0; u < PB; ++u) {
+                    const int t = t0 + u;
+                    const int gr = wm0 + i * 32 + t * RPI + rsub;
+                    ok[u] = cok && gr < M;
+                    const int grc = gr < M ? gr : M - 1;
+                    orow[u] = rpg_in > 0 ? (int64_t)(grc / rpg_in) * rpg_out + grc % rpg_in + row_off : (int64_t)grc;
+                    rv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    tv[u] = rv[u];
+                    if (resid && ok[u]) rv[u] = *(const float4*)(resid + orow[u] * ldr + gc);
+                    if (addtab && ok[u]) tv[u] = *(const float4*)(addtab + (int64_t)(grc % tab_rows) * N + gc);
                 }
-                const float4 o = make_float4(v[0] + tv[t].x + rv[t].x, v[1] + tv[t].y + rv[t].y,
-                                             v[2] + tv[t].z + rv[t].z, v[3] + tv[t].w + rv[t].w);
-                if (ok[t]) *(float4*)((float*)p.out + orow[t] * ldo + gc) = o;
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    const int t = t0 + u;
+                    const float4 a = *(const float4*)(sc + (t * RPI + rsub) * COLS + c4 * 4);
+                    float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
+                    if (act == BD_ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    }
+                    const float4 o = make_float4(v[0] + tv[u].x + rv[u].x, v[1] + tv[u].y + rv[u].y,
+                                                 v[2] + tv[u].z + rv[u].z, v[3] + tv[u].w + rv[u].w);
+                    if (ok[u]) *(float4*)((float*)p.out + orow[u] * ldo + gc) = o;
+                }
             }
         }
     } else {
@@ -464,6 +471,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 2 : 2)) void gemm_ker
         gemm_epilogue<T, NS, MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
     }
 }
+
 
 
 int gemm_impl() {   // BD_GEMM_IMPL=0 selects the register-staged mainloop (A/B measurements only)
