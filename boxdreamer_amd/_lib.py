@@ -76,7 +76,7 @@ EXPORTS = [
     "bd_im2col_images", "bd_patchify_heatmaps", "bd_write_prefix_tokens", "bd_query_substitute",
     "bd_gather_query_tokens", "bd_unpatchify_sigmoid", "bd_decode_topk",
     "bd_encoder_workspace_bytes", "bd_encoder_forward", "bd_decoder_workspace_bytes", "bd_decoder_forward",
-    "bd_trace_begin", "bd_trace_end", "bd_render_corner_heatmaps",
+    "bd_trace_begin", "bd_trace_end", "bd_render_corner_heatmaps", "bd_attention_q", "bd_gather_query_rows_f32",
 ]
 
 _lib = None
@@ -115,6 +115,8 @@ def load() -> C.CDLL:
     lib.bd_decoder_workspace_bytes.argtypes = [C.POINTER(BetrWeights), i, i, i]
     lib.bd_decoder_workspace_bytes.restype = sz
     lib.bd_decoder_forward.argtypes = [C.POINTER(BetrWeights), vp, i, vp, i64, vp, i, i, i, vp, vp, vp, sz, i, vp]
+    lib.bd_attention_q.argtypes = [vp, i64, vp, i64, i, i, i, i, f, vp, i, i, vp]
+    lib.bd_gather_query_rows_f32.argtypes = [vp, vp, vp, i, i, i, i, vp]
     lib.bd_render_corner_heatmaps.argtypes = [vp, i, i, i, i, vp, i, vp]
     lib.bd_trace_begin.argtypes = [i]
     lib.bd_trace_end.argtypes = [C.POINTER(TraceRecord), i]

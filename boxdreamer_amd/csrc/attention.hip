@@ -27,6 +27,8 @@ struct AttnArgs {
     void* out; int64_t out_plane;
     int batch, seq, heads;
     float scale_log2e;
+    const int32_t* q_view;   // optional: queries are rows [q_view[b]*q_len, +q_len) of every sequence, output compact
+    int q_len;               // number of query rows per sequence (== seq when q_view is NULL)
 };
 
 constexpr int KT = 64;   // keys per tile
@@ -63,7 +65,8 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lq = lane & 31, lh = lane >> 5;
     const int seq = p.seq, heads = p.heads;
-    const int nqb = (seq + QB - 1) / QB;
+    const int q_len = p.q_len;
+    const int nqb = (q_len + QB - 1) / QB;
 
     // XCD-aware remap: consecutive work items (same batch*head, consecutive q-blocks) share K/V and
     // are kept on one XCD's L2.
@@ -84,8 +87,9 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
     const int64_t plane = p.qkv_plane;
 
     // ---- Q fragments (B operand of S^T): lane (q, h) holds Q[q][ks*16 + h*8 .. +7]
-    const int q0 = qb * QB + wid * 32;
-    int qrow = q0 + lq; qrow = qrow < seq ? qrow : seq - 1;
+    const int q0 = qb * QB + wid * 32;                     // local query index (within the query range)
+    const int qbase_row = p.q_view ? p.q_view[b] * q_len : 0;
+    int qrow = q0 + lq; qrow = (qrow < q_len ? qrow : q_len - 1) + qbase_row;
     vec8 qf[NS][KS];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -266,8 +270,8 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int q = q0 + lq;
-    if (q < seq) {
-        T* orow = (T*)p.out + ((int64_t)b * seq + q) * (heads * HD) + head * HD;
+    if (q < q_len) {
+        T* orow = (T*)p.out + ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
 #pragma unroll
         for (int dm = 0; dm < DM; ++dm)
 #pragma unroll
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(NW * 64, (NS == 1 ? 2 : 1)) void attn_kernel(const 
 }
 
 template <class T, int NS, int HD, int NW> int launch(const AttnArgs& a, hipStream_t s) {
-    const int nqb = (a.seq + NW * 32 - 1) / (NW * 32);
+    const int nqb = (a.q_len + NW * 32 - 1) / (NW * 32);
     const int slot = bd_trace_open(s, 1, a.batch * a.heads, a.seq, HD);
     hipLaunchKernelGGL((attn_kernel<T, NS, HD, NW>), dim3(nqb * a.heads * a.batch), dim3(NW * 64), 0, s, a);
     bd_trace_close(s, slot);
@@ -298,7 +302,7 @@ template <class T, int NS, int HD, int NW> int launch(const AttnArgs& a, hipStre
 
 template <class T, int NS> int dispatch(const AttnArgs& a, int head_dim, hipStream_t s) {
     // 3 waves (96-query blocks) when that tiles the sequence with less waste (DINOv2: 261 -> 3 x 96)
-    const int waste4 = ((a.seq + 127) / 128) * 128 - a.seq, waste3 = ((a.seq + 95) / 96) * 96 - a.seq;
+    const int waste4 = ((a.q_len + 127) / 128) * 128 - a.q_len, waste3 = ((a.q_len + 95) / 96) * 96 - a.q_len;
     const bool use3 = waste3 < waste4;
     if (head_dim == 96) return use3 ? launch<T, NS, 96, 3>(a, s) : launch<T, NS, 96, 4>(a, s);
     if (head_dim == 64) return use3 ? launch<T, NS, 64, 3>(a, s) : launch<T, NS, 64, 4>(a, s);
@@ -307,12 +311,14 @@ template <class T, int NS> int dispatch(const AttnArgs& a, int head_dim, hipStre
 
 }  // namespace
 
-extern "C" int bd_attention(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch,
-                            int seq, int heads, int head_dim, float scale, int prec, void* stream) {
+extern "C" int bd_attention_q(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch, int seq,
+                              int heads, int head_dim, float scale, const int32_t* q_view, int q_len, int prec,
+                              void* stream) {
     if (!qkv || !out) return BD_ERR_NULL;
     if (batch <= 0 || seq <= 0 || heads <= 0) return BD_ERR_SHAPE;
+    if (q_view ? (q_len <= 0 || q_len > seq || seq % q_len) : (q_len != seq)) return BD_ERR_SHAPE;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return BD_ERR_ALIGN;
-    AttnArgs a{qkv, qkv_plane, out, out_plane, batch, seq, heads, scale * 1.4426950408889634f};
+    AttnArgs a{qkv, qkv_plane, out, out_plane, batch, seq, heads, scale * 1.4426950408889634f, q_view, q_len};
     hipStream_t s = (hipStream_t)stream;
     switch (prec) {
         case BD_PREC_BF16: return dispatch<__bf16, 1>(a, head_dim, s);
@@ -320,4 +326,9 @@ extern "C" int bd_attention(const void* qkv, int64_t qkv_plane, void* out, int64
         case BD_PREC_BF16X3: return dispatch<__bf16, 2>(a, head_dim, s);
         default: return BD_ERR_DTYPE;
     }
+}
+
+extern "C" int bd_attention(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch,
+                            int seq, int heads, int head_dim, float scale, int prec, void* stream) {
+    return bd_attention_q(qkv, qkv_plane, out, out_plane, batch, seq, heads, head_dim, scale, nullptr, seq, prec, stream);
 }

@@ -2,6 +2,8 @@
 // (BETR.forward) as straight-line sequences of kernel launches on the caller's stream.
 // No allocation, no synchronisation, no state: the caller provides one workspace blob that is
 // carved here (256-byte aligned slices).
+#include <stdlib.h>
+
 #include "bd_common.h"
 
 namespace {
@@ -66,6 +68,41 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
     {
         bd_gemm_args g = gemm_args(b.h, 4 * D, p4D, w.fc2, 4 * D, D, b.x, D, 0, 1, M, 4 * D, BD_ACT_NONE);
         g.resid = b.x; g.ldr = D;
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    return BD_OK;
+}
+
+// Last decoder block: its output is consumed for the query view only (betr.py:303), so only K/V need every token.
+// LN1 + QKV (+ q/k RMSNorm) run on all rows; attention takes queries from the query view's P rows and writes a
+// compact [B*P, D] result; proj, LN2 and the MLP then run on B*P rows (1/T of the work).  Row-wise arithmetic is
+// unchanged, so the result is bit-identical to the full-width block.  xc: fp32 [B*P, D] compact residual stream.
+int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, float* xc, const int32_t* query_idx, int B,
+                              int T, int P, int D, int heads, float ln_eps, float rms_eps, int prec, void* stream) {
+    const int hd = D / heads, M = B * T * P, Mq = B * P;
+    const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D;
+    const int64_t qD = (int64_t)Mq * D, q4D = (int64_t)Mq * 4 * D;
+    BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
+    {
+        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, 0, M, D, BD_ACT_NONE);
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    if (w.q_norm_w) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, prec, stream));
+    BD_TRY(bd_attention_q(b.qkv, p3D, b.ao, qD, B, T * P, heads, hd, 1.0f / sqrtf((float)hd), query_idx, P, prec, stream));
+    BD_TRY(bd_gather_query_rows_f32(b.x, query_idx, xc, B, T, P, D, stream));
+    {
+        bd_gemm_args g = gemm_args(b.ao, D, qD, w.proj, D, D, xc, D, 0, 1, Mq, D, BD_ACT_NONE);
+        g.resid = xc; g.ldr = D;
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    BD_TRY(bd_layernorm(xc, D, w.ln2_w, w.ln2_b, ln_eps, b.xn, qD, nullptr, 0, Mq, D, 0, 0, 0, prec, stream));
+    {
+        bd_gemm_args g = gemm_args(b.xn, D, qD, w.fc1, D, 4 * D, b.h, 4 * D, q4D, 0, Mq, D, BD_ACT_GELU);
+        BD_TRY(bd_gemm(&g, prec, stream));
+    }
+    {
+        bd_gemm_args g = gemm_args(b.h, 4 * D, q4D, w.fc2, 4 * D, D, xc, D, 0, 1, Mq, 4 * D, BD_ACT_NONE);
+        g.resid = xc; g.ldr = D;
         BD_TRY(bd_gemm(&g, prec, stream));
     }
     return BD_OK;
@@ -199,10 +236,18 @@ extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_fea
     }
     BD_TRY(bd_query_substitute(d.blk.x, d.rgb, w->pos_table, w->query_token, query_idx, B, T, P, D, stream));
     // K9: joint self-attention over all T*P tokens of a sample
-    for (int i = 0; i < w->depth; ++i)
+    static const bool full_last = getenv("BD_FULL_LAST_BLOCK") != nullptr;   // A/B measurements only
+    for (int i = 0; i + (full_last ? 0 : 1) < w->depth; ++i)
         BD_TRY(run_block(w->blocks[i], d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, prec, stream));
-    // K10: head on the query view's tokens (no final norm, betr.py:298-306)
-    BD_TRY(bd_gather_query_tokens(d.blk.x, query_idx, d.qtok, (int64_t)Mq * D, B, T, P, D, prec, stream));
+    if (full_last) {
+        BD_TRY(bd_gather_query_tokens(d.blk.x, query_idx, d.qtok, (int64_t)Mq * D, B, T, P, D, prec, stream));
+    } else {
+        // last block: query-view rows only past the K/V projection; d.t2 (dead since the adapter) holds the compact stream
+        BD_TRY(run_last_block_query_only(w->blocks[w->depth - 1], d.blk, d.t2, query_idx, B, T, P, D, w->heads,
+                                         w->ln_eps, w->rms_eps, prec, stream));
+        // K10: head on the query view's tokens (no final norm, betr.py:298-306)
+        BD_TRY(bd_gather_query_tokens(d.t2, nullptr, d.qtok, (int64_t)Mq * D, B, 1, P, D, prec, stream));
+    }
     {
         bd_gemm_args g = gemm_args(d.qtok, D, (int64_t)Mq * D, w->bbox_proj, D, F, d.proj, F, 0, 1, Mq, D, BD_ACT_NONE);
         BD_TRY(bd_gemm(&g, prec, stream));

@@ -494,16 +494,23 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
     } else if (impl == 3) {
         launch_glds<T, NS, BK, 2, 4, 4, 1>(a, s);                 // 256 x 128 (measurement only)
     } else {
-        // tile by occupancy: the big tile only when it still fills the 256 CUs ~1.5x over; the small one for
-        // latency-mode problems (batch 1: M = 1536) where 128 x 128 would leave most CUs idle
-        const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
-        const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-        if (impl != 2 && a.N >= 1536 && t256 >= 384)
+        // Tile choice = best estimated efficiency: wave quantisation over the resident slots (256x256: one workgroup
+        // per CU; 128x128: two; 64x64: four) times the measured relative mainloop efficiency of the tile
+        // (profiles/r1_gemm_experiments.md: 128x128 ~0.87 of 256x256 on the wide shapes; 64x64 ~0.55).
+        auto eff = [&](int tm, int tn, int slots, double base) {
+            const double tiles = (double)((a.M + tm - 1) / tm) * ((a.N + tn - 1) / tn);
+            const double rounds = (double)(((int64_t)tiles + slots - 1) / slots);
+            return base * tiles / (rounds * slots);
+        };
+        const double e256 = (a.N >= 1536 && impl != 2) ? eff(256, 256, 256, 1.0) : 0.0;
+        const double e128 = eff(128, 128, 512, 0.87);
+        const double e64 = impl == 2 ? 0.0 : eff(64, 64, 1024, 0.55);
+        if (e256 >= e128 && e256 >= e64)
             launch_glds<T, NS, BK, 2, 4, 4, 2>(a, s);             // 256 x 256, 1 workgroup / CU
-        else if (t128 >= 192 || impl == 2)
+        else if (e128 >= e64)
             launch_glds<T, NS, BK, 2, 2, 2, 2>(a, s);             // 128 x 128, 2 workgroups / CU
         else
-            launch_glds<T, NS, BK, 2, 2, 1, 1>(a, s);             // 64 x 64
+            launch_glds<T, NS, BK, 2, 2, 1, 1>(a, s);             // 64 x 64 (latency mode: batch 1, M = 1536)
     }
     bd_trace_close(s, slot);
     BD_CHECK_LAUNCH();

@@ -106,10 +106,22 @@ __global__ __launch_bounds__(256) void gather_query_kernel(const float* __restri
     if (t >= total) return;
     const int c = (int)(t % cpr), tok = (int)((t / cpr) % P);
     const int b = (int)(t / ((int64_t)cpr * P));
-    const float* src = x + (((int64_t)b * T_ + qidx[b]) * P + tok) * dim + c * 8;
+    const float* src = x + (((int64_t)b * T_ + (qidx ? qidx[b] : 0)) * P + tok) * dim + c * 8;
     const float4 a = *(const float4*)src, bb = *(const float4*)(src + 4);
     const float v[8] = {a.x, a.y, a.z, a.w, bb.x, bb.y, bb.z, bb.w};
     store8<T, NS>(out + ((int64_t)b * P + tok) * dim + c * 8, plane, v);
+}
+
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ x, const int32_t* __restrict__ qidx,
+                                                              float* __restrict__ out, int B, int T_, int P, int dim) {
+    const int cpr = dim / 4;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)B * P * cpr;
+    if (t >= total) return;
+    const int c = (int)(t % cpr), tok = (int)((t / cpr) % P);
+    const int b = (int)(t / ((int64_t)cpr * P));
+    *(float4*)(out + ((int64_t)b * P + tok) * dim + c * 4) =
+        *(const float4*)(x + (((int64_t)b * T_ + qidx[b]) * P + tok) * dim + c * 4);
 }
 
 // one thread per output pixel (b, y, x): reads the pixel's 8 consecutive channel features, writes 8 planes
@@ -258,9 +270,20 @@ extern "C" int bd_query_substitute(float* x, const float* rgb, const float* pos,
     return BD_OK;
 }
 
+extern "C" int bd_gather_query_rows_f32(const float* x, const int32_t* query_idx, float* out, int B, int T, int P,
+                                        int dim, void* stream) {
+    if (!x || !query_idx || !out) return BD_ERR_NULL;
+    if (B <= 0 || T <= 0 || P <= 0 || dim % 4) return BD_ERR_SHAPE;
+    const int64_t total = (int64_t)B * P * (dim / 4);
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, query_idx, out,
+                       B, T, P, dim);
+    BD_CHECK_LAUNCH();
+    return BD_OK;
+}
+
 extern "C" int bd_gather_query_tokens(const float* x, const int32_t* query_idx, void* out16, int64_t out_plane,
                                       int B, int T, int P, int dim, int prec, void* stream) {
-    if (!x || !query_idx || !out16) return BD_ERR_NULL;
+    if (!x || !out16) return BD_ERR_NULL;                   /* query_idx == NULL: view 0 (x already compact) */
     if (B <= 0 || T <= 0 || P <= 0 || dim % 8) return BD_ERR_SHAPE;
     const int64_t total = (int64_t)B * P * (dim / 8);
     hipStream_t s = (hipStream_t)stream;

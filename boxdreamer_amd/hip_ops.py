@@ -93,6 +93,15 @@ def attention(qkv16, batch, seq, heads, head_dim, scale, *, prec="bf16"):
     return out
 
 
+def attention_q(qkv16, batch, seq, heads, head_dim, scale, q_view, q_len, *, prec="bf16"):
+    """Attention with queries restricted to rows [q_view[b]*q_len, +q_len) of each sequence; compact output."""
+    lib = _lib.load()
+    out = _alloc16(batch * q_len, heads * head_dim, prec, qkv16.device)
+    check(lib.bd_attention_q(ptr(qkv16), _plane(qkv16, prec), ptr(out), _plane(out, prec), batch, seq, heads, head_dim,
+                             scale, ptr(q_view), q_len, prec_id(prec), stream()), "bd_attention_q")
+    return out
+
+
 def im2col_images(images, patch=14, kpad=640, *, prec="bf16"):
     lib = _lib.load()
     images = images.contiguous()

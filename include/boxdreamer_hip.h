@@ -105,6 +105,12 @@ int bd_qk_rmsnorm(void* qkv, int64_t plane, const float* wq, const float* wk, fl
 int bd_attention(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch, int seq,
                  int heads, int head_dim, float scale, int prec, void* stream);
 
+/* Same, but only the rows [q_view[b]*q_len, +q_len) of every sequence act as queries (keys/values: all `seq` rows);
+ * out is compact [batch, q_len, heads*head_dim].  Used for the LAST decoder block, whose output is consumed for the
+ * query view only (betr.py:303).  q_view == NULL requires q_len == seq (plain attention). */
+int bd_attention_q(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch, int seq,
+                   int heads, int head_dim, float scale, const int32_t* q_view, int q_len, int prec, void* stream);
+
 /* (x - mean_c) / std_c, then 14x14 patches -> A operand rows [n*grid*grid, kpad], k = c*p*p + py*p + px,
  * zero-padded to kpad.  Replaces encoder/dinov2.py:45-46,56 + the unfold inside the patch-embed conv. */
 int bd_im2col_images(const void* images, int img_dtype, void* out16, int64_t out_plane, int n_images,
@@ -124,7 +130,12 @@ int bd_write_prefix_tokens(float* x, const float* prefix, int n_images, int toke
 int bd_query_substitute(float* x, const float* rgb, const float* pos, const float* query_token,
                         const int32_t* query_idx, int B, int T, int P, int dim, void* stream);
 
-/* Gathers the query view's P token rows per sample (betr.py:303) and casts to the operand dtype. */
+/* fp32 copy of the query view's P token rows per sample: x [B*T*P, dim] -> out [B*P, dim]. */
+int bd_gather_query_rows_f32(const float* x, const int32_t* query_idx, float* out, int B, int T, int P, int dim,
+                             void* stream);
+
+/* Gathers the query view's P token rows per sample (betr.py:303) and casts to the operand dtype
+ * (query_idx == NULL: view 0, i.e. a pure cast of an already compact [B*P, dim] tensor with T = 1). */
 int bd_gather_query_tokens(const float* x, const int32_t* query_idx, void* out16, int64_t out_plane,
                            int B, int T, int P, int dim, int prec, void* stream);
 

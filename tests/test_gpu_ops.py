@@ -196,3 +196,19 @@ def test_render_corner_heatmaps(hip, golden_dir, dtype):
     got2 = make_bbox_features(two.cuda(), shape=(224, 224), group=3).cpu()
     ref2 = torch.cat([orc.make_bbox_features(two[:3], (224, 224)), orc.make_bbox_features(two[3:], (224, 224))])
     assert (got2 - ref2).abs().max().item() <= 4e-6
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_attention_query_range(hip, prec):
+    """bd_attention_q (last decoder block): queries from one 256-row view per sample, keys/values from all rows."""
+    batch, T, P, heads, hd = 3, 4, 256, 8, 96
+    seq = T * P
+    qkv = _rand("attqr", (batch, seq, 3, heads, hd), 1.0)
+    qv = torch.tensor([3, 0, 2], dtype=torch.int32)
+    t = hip_ops.to_operand(qkv.reshape(batch * seq, -1).cuda(), prec)
+    out = hip_ops.attention_q(t, batch, seq, heads, hd, hd ** -0.5, qv.cuda(), P, prec=prec)
+    got = hip_ops.from_operand(out, prec).cpu().reshape(batch, P, heads, hd)
+    full = hip_ops.from_operand(hip_ops.attention(t, batch, seq, heads, hd, hd ** -0.5, prec=prec), prec).cpu()
+    full = full.reshape(batch, seq, heads, hd)
+    for b in range(batch):
+        assert torch.equal(got[b], full[b, qv[b] * P:(qv[b] + 1) * P])       # bit-identical to the full-width kernel
