@@ -246,9 +246,15 @@ def main():
         peak = PEAK_MFMA_TFLOPS[prec]
         gemm_tf = sum(f for f, _ in g) / max(sum(ms for _, ms in g), 1e-9) / 1e9 if g else 0.0
         attn_tf = sum(f for f, _ in a) / max(sum(ms for _, ms in a), 1e-9) / 1e9 if a else 0.0
-        roofline = {"bound": "mfma", "kernel": "gemm_kernel (128x128xBK MFMA 32x32x16)",
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+        if os.path.exists(tpath) and prec == "bf16" and B == 32 and T == 6:
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
+        roofline = {"bound": "mfma", "kernel": "gemm_kernel_glds (256x256 / 128x128 tiles, LDS-DMA operands, v_mfma_f32_32x32x16)",
                     "achieved": round(gemm_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tf / peak, 4),
-                    "traffic": None,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_flops_per_launch": round(sum(f for f, _ in g) / max(len(g), 1)),
                     "launches": len(g), "avg_launch_ms": round(sum(ms for _, ms in g) / max(len(g), 1), 4),
                     "mfma_passes_per_algorithmic_flop": passes,
                     "attention_achieved": round(attn_tf, 2),

@@ -124,3 +124,29 @@ def test_query_view_position(hip):
     dec(bf, img, mask.cuda(), enc.predict(img), None)
     o = _oracle(data, 2, 2)
     assert (dec.last_logits.cpu() - o["logits"]).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("size,T,B", [(112, 3, 2), (84, 2, 1), (224, 2, 3)])
+def test_other_crop_sizes_and_view_counts(hip, size, T, B):
+    """img_size is a config value in the reference (configs/model/transformer.yaml:46); any multiple of 14 works:
+    grid = size/14, DINO sequence = grid^2 + 5 (ragged tail tiles), BETR sequence = T * grid^2, decode over size^2."""
+    prec, dd, bd = "bf16x3", 2, 2
+    enc = DinoV2Wrapper(None, {"model_type": "dinov2_vitb14_reg", "synthetic_seed": 4321, "depth": dd,
+                               "hip_precision": prec})
+    dec = BETR(d_model=768, nhead=8, num_decoder_layers=bd, decoder_only=True, patch_size=14, img_size=size,
+               diff_emb=False, nvs_supervision=False, ray_supervision=True, use_mask=False, use_pretrained=True,
+               patchify_rays=True, pose_representation="bb8", bbox_representation="heatmap", hip_precision=prec)
+    dec.load_state_dict(synth.betr_state_dict(seed=1234, depth=bd), strict=True)
+    dec = dec.cuda().eval()
+    data = synth.make_batch(seed=31, B=B, T=T, size=size)
+    data["query_idx"] = torch.arange(B) % T
+    mask = torch.zeros(B, T, dtype=torch.bool); mask[torch.arange(B), data["query_idx"]] = True
+    img, bf = data["images"].cuda(), data["bbox_feat"].cuda()
+    heat = dec(bf, img, mask.cuda(), enc.predict(img), None)
+    kp, kn, idx = hip_ops.decode_topk(heat)
+    o = orc.boxdreamer_forward(data, synth.betr_state_dict(1234, bd), synth.dino_state_dict(4321, dd))
+    assert heat.shape == (B, 8, size, size)
+    assert (dec.last_logits.cpu() - o["logits"]).abs().max().item() <= 1e-3
+    assert (heat.cpu() - o["heat"]).abs().max().item() <= 1e-3
+    same = (idx.cpu().long().sort(-1)[0] == o["topk_idx"].sort(-1)[0]).all(-1).float().mean().item()
+    assert same >= 0.9
