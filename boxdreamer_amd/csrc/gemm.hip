@@ -82,7 +82,7 @@ __device__ __forceinline__ void gemm_epilogue(const bd_gemm_args& p, f32x16 (&ac
                         if (act == BD_ACT_GELU) v = gelu_erf(v);
                         if (tab) v += tab[gc];
                         if (resid) v += resid[orow * ldr + gc];
-                        if (out_f32) {
+                        if (out_f32 == 1) {
                             ((float*)p.out)[orow * ldo + gc] = v;
                         } else {
                             T* o = (T*)p.out + orow * ldo + gc;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
     const int act = p.act, rpg_in = p.rpg_in, rpg_out = p.rpg_out, row_off = p.row_off, tab_rows = p.tab_rows;
     const int64_t ldr = p.ldr, ldo = p.ldo, out_plane = p.out_plane;
     float* sc = (float*)scratch;
-    if (p.out_f32) {
+    if (p.out_f32 == 1) {
         constexpr int LPR = COLS / 4;                  // lanes per row (float4 each)
         constexpr int RPI = 64 / LPR;                  // rows per pass
         constexpr int PASSES = 32 / RPI;
@@ -134,37 +134,36 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     sc[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
-            // global reads are issued in batches of PB passes (register budget: 2 float4 per pass in flight)
+            // global reads are issued in batches of PB passes (register budget: 2 x 4 floats per pass in flight);
+            // native vector types only -- HIP's float4 struct in a local array lands in scratch
             constexpr int PB = PASSES > 4 ? 4 : PASSES;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 bv4 = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
             for (int t0 = 0; t0 < PASSES; t0 += PB) {
-                float4 rv[PB], tv[PB];
+                f32x4 rv[PB], tv[PB];
                 int64_t orow[PB];
                 bool ok[PB];
 #pragma unroll
                 for (int u = 0; u < PB; ++u) {
-                    const int t = t0 + u;
-                    const int gr = wm0 + i * 32 + t * RPI + rsub;
+                    const int gr = wm0 + i * 32 + (t0 + u) * RPI + rsub;
                     ok[u] = cok && gr < M;
                     const int grc = gr < M ? gr : M - 1;
                     orow[u] = rpg_in > 0 ? (int64_t)(grc / rpg_in) * rpg_out + grc % rpg_in + row_off : (int64_t)grc;
-                    rv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    tv[u] = rv[u];
-                    if (resid && ok[u]) rv[u] = *(const float4*)(resid + orow[u] * ldr + gc);
-                    if (addtab && ok[u]) tv[u] = *(const float4*)(addtab + (int64_t)(grc % tab_rows) * N + gc);
+                    rv[u] = zero4;
+                    tv[u] = zero4;
+                    if (resid && ok[u]) rv[u] = *(const f32x4*)(resid + orow[u] * ldr + gc);
+                    if (addtab && ok[u]) tv[u] = *(const f32x4*)(addtab + (int64_t)(grc % tab_rows) * N + gc);
                 }
 #pragma unroll
                 for (int u = 0; u < PB; ++u) {
-                    const int t = t0 + u;
-                    const float4 a = *(const float4*)(sc + (t * RPI + rsub) * COLS + c4 * 4);
-                    float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
+                    f32x4 v = *(const f32x4*)(sc + ((t0 + u) * RPI + rsub) * COLS + c4 * 4) + bv4;
                     if (act == BD_ACT_GELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                     }
-                    const float4 o = make_float4(v[0] + tv[u].x + rv[u].x, v[1] + tv[u].y + rv[u].y,
-                                                 v[2] + tv[u].z + rv[u].z, v[3] + tv[u].w + rv[u].w);
-                    if (ok[u]) *(float4*)((float*)p.out + orow[u] * ldo + gc) = o;
+                    v = v + tv[u] + rv[u];
+                    if (ok[u]) *(f32x4*)((float*)p.out + orow[u] * ldo + gc) = v;
                 }
             }
         }
@@ -211,15 +210,22 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += rp[e];
                     }
-                    vec8 hi, lo;
+                    if (p.out_f32 == 2) {                 // f16 single plane (strict mode's attention operands)
+                        f16x8 h;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        hi[e] = from_f32<T>(v[e]);
-                        if (NS == 2) lo[e] = from_f32<T>(v[e] - to_f32<T>(hi[e]));
+                        for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
+                        *(f16x8*)((_Float16*)p.out + orow * ldo + gc) = h;
+                    } else {
+                        vec8 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            hi[e] = from_f32<T>(v[e]);
+                            if (NS == 2) lo[e] = from_f32<T>(v[e] - to_f32<T>(hi[e]));
+                        }
+                        T* o = (T*)p.out + orow * ldo + gc;
+                        *(vec8*)o = hi;
+                        if (NS == 2) *(vec8*)(o + out_plane) = lo;
                     }
-                    T* o = (T*)p.out + orow * ldo + gc;
-                    *(vec8*)o = hi;
-                    if (NS == 2) *(vec8*)(o + out_plane) = lo;
                 }
             }
         }
@@ -428,7 +434,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 2 : 2)) void gemm_ker
         const unsigned char* base = lds + (kt & 1) * STAGE_BYTES;
         // fragments are double-buffered in registers: the ds_read_b128s of k-step ks+1 are in flight while the
         // MFMAs of k-step ks issue (the compiler's counted lgkmcnt keeps them apart)
-        vec8 a[2][NS][MI], b[2][NS][NI];
+        constexpr int FB = NS == 1 ? 2 : 1;              // x3 mode: one fragment set (two would spill next to 128 accumulators)
+        vec8 a[FB][NS][MI], b[FB][NS][NI];
 #define LOAD_FRAGS(ks, slot)                                                                                   \
         _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                       \
             _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                   \
@@ -440,11 +447,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 2 : 2)) void gemm_ker
                 b[slot][s][j] = as_vec8<T>(*(const u128*)(base + NS * A_BYTES + s * W_BYTES + r * (BK * 2) + (swz_chunk<BK>(r, (ks) * 2 + lhalf) << 4))); \
             }                                                                                                  \
         }
-        LOAD_FRAGS(0, 0)
+        if (FB == 2) { LOAD_FRAGS(0, 0) }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int cur = ks & 1;
-            if (ks + 1 < KS) { LOAD_FRAGS(ks + 1, cur ^ 1) }
+            const int cur = FB == 2 ? (ks & 1) : 0;
+            if (FB == 2) { if (ks + 1 < KS) { LOAD_FRAGS(ks + 1, (cur ^ 1) & (FB - 1)) } }
+            else { LOAD_FRAGS(ks, 0) }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -526,6 +534,9 @@ extern "C" int bd_gemm(const bd_gemm_args* args, int prec, void* stream) {
     if ((a.lda % 8) || (a.ldw % 8) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15)) return BD_ERR_ALIGN;
     if (prec == BD_PREC_BF16X3 && ((a.a_plane % 8) || (a.w_plane % 8))) return BD_ERR_ALIGN;
     if (a.addtab && a.tab_rows <= 0) return BD_ERR_SHAPE;
+    if (a.out_f32 < 0 || a.out_f32 > 2) return BD_ERR_DTYPE;
+    // the f16 single-plane output exists only in the wide (16-byte) epilogue
+    if (a.out_f32 == 2 && ((a.N % 8) || (a.ldo % 8) || ((uintptr_t)a.out & 15) || a.resid || a.addtab)) return BD_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     switch (prec) {
         case BD_PREC_BF16: return launch<__bf16, 1, 64>(a, s);

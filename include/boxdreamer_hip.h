@@ -42,6 +42,7 @@ extern "C" {
 #define BD_PREC_BF16 0
 #define BD_PREC_F16 1
 #define BD_PREC_BF16X3 2
+#define BD_PREC_F16_OUT_BF16X3 3 /* bd_attention[_q] only: f16 qkv (one plane) in, one f16 MFMA pass, split-bf16 (hi, lo) planes out */
 
 #define BD_OK 0
 #define BD_ERR_SHAPE (-1)
@@ -76,7 +77,7 @@ typedef struct bd_gemm_args {
     const float* resid; int64_t ldr;               /* fp32 [*, N] indexed by the OUTPUT row, or NULL */
     const float* addtab; int tab_rows;             /* fp32 [tab_rows, N] or NULL */
     void* out; int64_t ldo; int64_t out_plane;     /* 16-bit (operand dtype of `prec`) or fp32 */
-    int out_f32;                                   /* 1: fp32 output, 0: operand-dtype output */
+    int out_f32;                                   /* 0: operand-dtype output (planes per `prec`), 1: fp32, 2: f16 single plane */
     int M, N, K;
     int act;
     int rpg_in, rpg_out, row_off;
