@@ -24,14 +24,27 @@ __device__ __forceinline__ void scan_slice(const float* __restrict__ h, int lo, 
     bv = -INFINITY;
     bi = 0x7fffffff;
     if (VEC) {
-        for (int i = lo; i < hi; i += 4) {
-            const float4 q = *(const float4*)(h + i);
-            const float e[4] = {q.x, q.y, q.z, q.w};
+        // 7 independent 16-byte loads in flight per step (a 196-float slice = 49 float4 = 7 x 7); a plain loop
+        // serialises on one L2 round trip per float4 (0.48 ms per decode in profiles/r1_bench_bf16_kernel_stats.csv)
+        for (int i0 = lo; i0 < hi; i0 += 28) {
+            float4 q[7];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = (e[j] + 1.0f) / 2.0f;              // box_utils.py:79
-                const bool after = (v < pv) || (v == pv && i + j > pi);
-                if (after && better(v, i + j, bv, bi)) { bv = v; bi = i + j; }
+            for (int u = 0; u < 7; ++u) {
+                const int i = i0 + 4 * u;
+                q[u] = *(const float4*)(h + (i < hi ? i : lo));
+            }
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int i = i0 + 4 * u;
+                if (i < hi) {
+                    const float e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = (e[j] + 1.0f) / 2.0f;              // box_utils.py:79
+                        const bool after = (v < pv) || (v == pv && i + j > pi);
+                        if (after && better(v, i + j, bv, bi)) { bv = v; bi = i + j; }
+                    }
+                }
             }
         }
     } else {
@@ -77,7 +90,26 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
         if (tid == 0 && topk_idx) topk_idx[(int64_t)blockIdx.x * k + round] = fi;
         sx += (float)(fi % width);
         sy += (float)(fi / width);
-        if (fi >= lo && fi < hi) scan_slice<VEC>(h, lo, hi, fv, fi, cv, ci);    // only the winner refills
+        // refill the winner's candidate: its WAVE rescans that thread's slice cooperatively (one batch of coalesced
+        // loads + a shuffle reduce) -- a single thread walking its 196 floats costs ~7 dependent L2 round trips per round
+        const int owner = fi / per;
+        if ((owner >> 6) == wid) {
+            const int slo = owner * per, shi = (slo + per) < hw ? (slo + per) : hw;
+            float rv = -INFINITY;
+            int ri = 0x7fffffff;
+            for (int i = slo + lane; i < shi; i += 64) {
+                const float v = (h[i] + 1.0f) / 2.0f;
+                const bool after = (v < fv) || (v == fv && i > fi);
+                if (after && better(v, i, rv, ri)) { rv = v; ri = i; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(rv, o);
+                const int oi = __shfl_xor(ri, o);
+                if (better(ov, oi, rv, ri)) { rv = ov; ri = oi; }
+            }
+            if (lane == (owner & 63)) { cv = rv; ci = ri; }
+        }
     }
     if (tid == 0) {
         const float mx = sx / (float)k, my = sy / (float)k;    // xs.float().mean(dim=2)
