@@ -171,8 +171,8 @@ def main():
     kp_all = torch.empty((B, 8, 2), dtype=torch.float32, device=device)
 
     def run_span(e, d, lo, hi):
-        if cached is not None:
-            feats = merge_cached_features(e, images[lo:hi], cached[0][lo:hi], cached[1][lo:hi])
+        if cached is not None:          # (single stream only: slicing would drop the attached operand-dtype copy)
+            feats = merge_cached_features(e, images, cached[0], cached[1])
         else:
             feats = e.predict(images[lo:hi])
         heat = d(bbox[lo:hi], images[lo:hi], mask[lo:hi], feats, None)
