@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense, no sparsity)
-PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0}
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0, "fp8": 5000.0}   # fp8 = MX-scaled dense peak
 PEAK_HBM_GBS = 8000.0
 DINO_FLOP_PER_IMAGE = 47_078_313_984          # BASELINE.md §4 / SURVEY.md §8(d)
 
@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--prec", default=os.environ.get("BOXDREAMER_HIP_PREC", "bf16"), choices=["bf16", "fp16", "bf16x3"])
+    ap.add_argument("--prec", default=os.environ.get("BOXDREAMER_HIP_PREC", "bf16"), choices=["bf16", "fp16", "bf16x3", "fp8"])
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
     ap.add_argument("--views", type=int, default=6, help="T = refs + 1")
     ap.add_argument("--cache-refs", action="store_true",
@@ -269,7 +269,7 @@ def main():
         line = {"metric": metric,
                 "value": round(value, 2), "unit": "poses/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3"}[prec],
+                "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3", "fp8": "fp8-e4m3 (Linears) + bf16 (attention)"}[prec],
                 "data": "synthetic",
                 "config": {"workload": f"configs[1]: 1 query + {T - 1} ref, 224x224, batch {B}/GPU, DINOv2 ViT-B/14-reg "
                                        f"+ BETR-12 + top-20 decode, random-init weights, inputs bf16 in HBM",

@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libboxdreamer_hip.so")
 
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
-PREC_BF16, PREC_F16, PREC_BF16X3 = 0, 1, 2
-PREC_NAMES = {"bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16x3": PREC_BF16X3}
+PREC_BF16, PREC_F16, PREC_BF16X3, PREC_F16_OUT_BF16X3, PREC_FP8, PREC_BF16_OUT_FP8 = 0, 1, 2, 3, 4, 5
+PREC_NAMES = {"bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8}
 ACT_NONE, ACT_GELU = 0, 1
 
 _ERR = {-1: "BD_ERR_SHAPE", -2: "BD_ERR_DTYPE", -3: "BD_ERR_ALIGN", -4: "BD_ERR_WORKSPACE", -5: "BD_ERR_NULL"}
@@ -28,7 +28,7 @@ class HipLibraryError(RuntimeError):
 class GemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("a_plane", C.c_int64),
                 ("W", C.c_void_p), ("ldw", C.c_int64), ("w_plane", C.c_int64),
-                ("bias", C.c_void_p),
+                ("bias", C.c_void_p), ("wscale", C.c_void_p),
                 ("resid", C.c_void_p), ("ldr", C.c_int64),
                 ("addtab", C.c_void_p), ("tab_rows", C.c_int),
                 ("out", C.c_void_p), ("ldo", C.c_int64), ("out_plane", C.c_int64),
@@ -39,7 +39,7 @@ class GemmArgs(C.Structure):
 
 
 class Linear(C.Structure):
-    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p)]
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("wscale", C.c_void_p)]
 
 
 class BlockWeights(C.Structure):
@@ -144,7 +144,15 @@ def prec_id(prec) -> int:
 
 
 def op_dtype(prec) -> torch.dtype:
-    return torch.float16 if prec_id(prec) == PREC_F16 else torch.bfloat16
+    pid = prec_id(prec)
+    if pid == PREC_FP8:
+        return torch.float8_e4m3fn          # OCP e4m3 (gfx950), not MI300's fnuz
+    return torch.float16 if pid == PREC_F16 else torch.bfloat16
+
+
+def k_multiple(prec) -> int:
+    """K padding granularity of GEMM operands: one 128-byte tile row per slab."""
+    return 128 if prec_id(prec) == PREC_FP8 else 64
 
 
 def planes(prec) -> int:

@@ -45,7 +45,7 @@ __device__ __forceinline__ int vswz(int d) { return ((d >> 1) ^ (d >> 4)) & 7; }
 // OUTSPLIT: single-pass f16 attention whose result is written as split-bf16 (hi, lo) planes -- the strict mode's
 // attention (its GEMMs stay split-bf16 x3): q/k are RMS-normalised and P is in [0, 1], so one f16 pass costs ~1e-4 on
 // the logits while the x3 attention kernel is register-bound at one wave per SIMD.
-template <class T, int NS, int HD, int NW, bool OUTSPLIT = false>
+template <class T, int NS, int HD, int NW, int OUTMODE = 0>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
     typedef typename Op16<T>::vec8 vec8;
     constexpr int NT = NW * 64;
@@ -274,7 +274,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
     const float inv = 1.0f / l_tot;
     const int q = q0 + lq;
     if (q < q_len) {
-        if (OUTSPLIT) {
+        if (OUTMODE == 2) {
+            fp8e4* orow = (fp8e4*)p.out + ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
+#pragma unroll
+            for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    float v4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = oacc[dm][rq * 4 + j] * inv;
+                    store_cvt<fp8e4, 4>(orow + dm * 32 + 8 * rq + 4 * lh, v4);
+                }
+        } else if (OUTMODE == 1) {
             __bf16* orow = (__bf16*)p.out + ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
 #pragma unroll
             for (int dm = 0; dm < DM; ++dm)
@@ -314,21 +325,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
     }
 }
 
-template <class T, int NS, int HD, int NW, bool OUTSPLIT = false> int launch(const AttnArgs& a, hipStream_t s) {
+template <class T, int NS, int HD, int NW, int OUTMODE = 0> int launch(const AttnArgs& a, hipStream_t s) {
     const int nqb = (a.q_len + NW * 32 - 1) / (NW * 32);
     const int slot = bd_trace_open(s, 1, a.batch * a.heads, a.seq, HD);
-    hipLaunchKernelGGL((attn_kernel<T, NS, HD, NW, OUTSPLIT>), dim3(nqb * a.heads * a.batch), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((attn_kernel<T, NS, HD, NW, OUTMODE>), dim3(nqb * a.heads * a.batch), dim3(NW * 64), 0, s, a);
     bd_trace_close(s, slot);
     BD_CHECK_LAUNCH();
     return BD_OK;
 }
 
-template <class T, int NS, bool OUTSPLIT = false> int dispatch(const AttnArgs& a, int head_dim, hipStream_t s) {
+template <class T, int NS, int OUTMODE = 0> int dispatch(const AttnArgs& a, int head_dim, hipStream_t s) {
     // 3 waves (96-query blocks) when that tiles the sequence with less waste (DINOv2: 261 -> 3 x 96)
     const int waste4 = ((a.q_len + 127) / 128) * 128 - a.q_len, waste3 = ((a.q_len + 95) / 96) * 96 - a.q_len;
     const bool use3 = waste3 < waste4;
-    if (head_dim == 96) return use3 ? launch<T, NS, 96, 3, OUTSPLIT>(a, s) : launch<T, NS, 96, 4, OUTSPLIT>(a, s);
-    if (head_dim == 64) return use3 ? launch<T, NS, 64, 3, OUTSPLIT>(a, s) : launch<T, NS, 64, 4, OUTSPLIT>(a, s);
+    if (head_dim == 96) return use3 ? launch<T, NS, 96, 3, OUTMODE>(a, s) : launch<T, NS, 96, 4, OUTMODE>(a, s);
+    if (head_dim == 64) return use3 ? launch<T, NS, 64, 3, OUTMODE>(a, s) : launch<T, NS, 64, 4, OUTMODE>(a, s);
     return BD_ERR_SHAPE;
 }
 
@@ -347,7 +358,8 @@ extern "C" int bd_attention_q(const void* qkv, int64_t qkv_plane, void* out, int
         case BD_PREC_BF16: return dispatch<__bf16, 1>(a, head_dim, s);
         case BD_PREC_F16: return dispatch<_Float16, 1>(a, head_dim, s);
         case BD_PREC_BF16X3: return dispatch<__bf16, 2>(a, head_dim, s);
-        case BD_PREC_F16_OUT_BF16X3: return dispatch<_Float16, 1, true>(a, head_dim, s);
+        case BD_PREC_F16_OUT_BF16X3: return dispatch<_Float16, 1, 1>(a, head_dim, s);
+        case BD_PREC_BF16_OUT_FP8: return dispatch<__bf16, 1, 2>(a, head_dim, s);
         default: return BD_ERR_DTYPE;
     }
 }

@@ -29,8 +29,48 @@ template <> struct Op16<_Float16> {
     }
 };
 
+// OCP e4m3 element (gfx950 fp8; NOT the MI300 fnuz encoding).  Only ever moved around as raw bytes.
+struct fp8e4 { unsigned char v; };
+typedef __attribute__((__vector_size__(8 * sizeof(int)))) int i32x8;
+
+// fp8 operands go through the block-scaled MFMA with unit (E8M0 = 127) scales: 32x32x64 per instruction at twice the
+// bf16 rate.  A lane supplies 32 consecutive k of its row (8 VGPRs) for its lane half; since A and W fragments are
+// built by the same loader the k labelling inside the instruction is immaterial (tools/mfma_layout_probe.hip).
+template <> struct Op16<fp8e4> {
+    typedef i32x8 vec8;     // "fragment" type of this operand class
+    static __device__ __forceinline__ f32x16 mfma(i32x8 a, i32x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+};
+// element size, K per MFMA, 16-byte chunks per fragment per lane
+template <class T> struct OpGeom { static constexpr int ESZ = 2, KSTEP = 16, CPF = 1; };
+template <> struct OpGeom<fp8e4> { static constexpr int ESZ = 1, KSTEP = 64, CPF = 2; };
+
 template <class T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 template <class T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+
+// store N (4 or 8) consecutive elements converted from fp32
+template <class T, int N> __device__ __forceinline__ void store_cvt(T* dst, const float (&v)[N]) {
+    typedef __attribute__((__vector_size__(N * sizeof(T)))) T vecN;
+    vecN o;
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = (T)v[j];
+    *(vecN*)dst = o;
+}
+template <> __device__ __forceinline__ void store_cvt<fp8e4, 8>(fp8e4* dst, const float (&v)[8]) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    *(uint2*)dst = make_uint2((unsigned)lo, (unsigned)hi);
+}
+template <> __device__ __forceinline__ void store_cvt<fp8e4, 4>(fp8e4* dst, const float (&v)[4]) {
+    int lo = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    *(int*)dst = lo;
+}
 
 template <class T> __device__ __forceinline__ typename Op16<T>::vec8 as_vec8(u128 u);
 template <> __device__ __forceinline__ bf16x8 as_vec8<__bf16>(u128 u) { return __builtin_bit_cast(bf16x8, u); }

@@ -35,6 +35,7 @@ inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const
     g.A = A; g.lda = lda; g.a_plane = a_plane;
     g.W = lin.w; g.ldw = ldw; g.w_plane = (int64_t)N * ldw;
     g.bias = lin.b;
+    g.wscale = lin.wscale;
     g.out = out; g.ldo = ldo; g.out_plane = out_plane; g.out_f32 = out_f32;
     g.M = M; g.N = N; g.K = K; g.act = act;
     return g;
@@ -57,11 +58,13 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
               float ln_eps, float rms_eps, int prec, void* stream) {
     const int hd = D / heads;
     const bool hyb = prec == BD_PREC_BF16X3 && x3_f16_attention();
-    const int aprec_in = hyb ? BD_PREC_F16 : prec, aprec = hyb ? BD_PREC_F16_OUT_BF16X3 : prec;
+    const bool f8 = prec == BD_PREC_FP8;      // e4m3 Linears, bf16 attention
+    const int aprec_in = hyb ? BD_PREC_F16 : (f8 ? BD_PREC_BF16 : prec);
+    const int aprec = hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec);
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D, p4D = (int64_t)M * 4 * D;
     BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
     {
-        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, hyb ? 2 : 0, M, D, BD_ACT_NONE);
+        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, hyb ? 2 : (f8 ? 3 : 0), M, D, BD_ACT_NONE);
         BD_TRY(bd_gemm(&g, prec, stream));
     }
     if (w.q_norm_w) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, aprec_in, stream));
@@ -92,12 +95,14 @@ int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, flo
                               int T, int P, int D, int heads, float ln_eps, float rms_eps, int prec, void* stream) {
     const int hd = D / heads, M = B * T * P, Mq = B * P;
     const bool hyb = prec == BD_PREC_BF16X3 && x3_f16_attention();
-    const int aprec_in = hyb ? BD_PREC_F16 : prec, aprec = hyb ? BD_PREC_F16_OUT_BF16X3 : prec;
+    const bool f8 = prec == BD_PREC_FP8;      // e4m3 Linears, bf16 attention
+    const int aprec_in = hyb ? BD_PREC_F16 : (f8 ? BD_PREC_BF16 : prec);
+    const int aprec = hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec);
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D;
     const int64_t qD = (int64_t)Mq * D, q4D = (int64_t)Mq * 4 * D;
     BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
     {
-        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, hyb ? 2 : 0, M, D, BD_ACT_NONE);
+        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, hyb ? 2 : (f8 ? 3 : 0), M, D, BD_ACT_NONE);
         BD_TRY(bd_gemm(&g, prec, stream));
     }
     if (w.q_norm_w) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, aprec_in, stream));
@@ -160,7 +165,9 @@ DecBufs carve_decoder(const bd_betr_weights* w, int B, int T, int prec, void* ws
     return d;
 }
 
-inline bool bad_prec(int prec) { return prec != BD_PREC_BF16 && prec != BD_PREC_F16 && prec != BD_PREC_BF16X3; }
+inline bool bad_prec(int prec) {
+    return prec != BD_PREC_BF16 && prec != BD_PREC_F16 && prec != BD_PREC_BF16X3 && prec != BD_PREC_FP8;
+}
 
 }  // namespace
 

@@ -6,15 +6,15 @@ namespace {
 
 template <class T, int NS>
 __device__ __forceinline__ void store8(T* dst, int64_t plane, const float (&v)[8]) {
-    typedef typename Op16<T>::vec8 vec8;
-    vec8 hi, lo;
+    if constexpr (NS == 2) {
+        float hi8[8], lo8[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        hi[j] = from_f32<T>(v[j]);
-        if (NS == 2) lo[j] = from_f32<T>(v[j] - to_f32<T>(hi[j]));
+        for (int j = 0; j < 8; ++j) { hi8[j] = to_f32<T>(from_f32<T>(v[j])); lo8[j] = v[j] - hi8[j]; }
+        store_cvt<T, 8>(dst, hi8);
+        store_cvt<T, 8>(dst + plane, lo8);
+    } else {
+        store_cvt<T, 8>(dst, v);
     }
-    *(vec8*)dst = hi;
-    if (NS == 2) *(vec8*)(dst + plane) = lo;
 }
 
 // one thread per 8-wide chunk of an output row [n*grid*grid, kpad]; k = c*p*p + py*p + px
@@ -217,6 +217,7 @@ inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
         case BD_PREC_BF16: hipLaunchKernelGGL((FN<__bf16, 1>), __VA_ARGS__); break;    \
         case BD_PREC_F16: hipLaunchKernelGGL((FN<_Float16, 1>), __VA_ARGS__); break;   \
         case BD_PREC_BF16X3: hipLaunchKernelGGL((FN<__bf16, 2>), __VA_ARGS__); break;  \
+        case BD_PREC_FP8: hipLaunchKernelGGL((FN<fp8e4, 1>), __VA_ARGS__); break;      \
         default: return BD_ERR_DTYPE;                                                  \
     }
 

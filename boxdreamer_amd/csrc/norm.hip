@@ -55,15 +55,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             }
             if (out32) *(float4*)(out32 + (int64_t)r * ldo + c) = make_float4(y[0], y[1], y[2], y[3]);
             if (out16) {
-                typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4;
-                vec4 hi, lo;
+                if constexpr (NS == 2) {
+                    float hi4[4], lo4[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    hi[j] = from_f32<T>(y[j]);
-                    if (NS == 2) lo[j] = from_f32<T>(y[j] - to_f32<T>(hi[j]));
+                    for (int j = 0; j < 4; ++j) { hi4[j] = to_f32<T>(from_f32<T>(y[j])); lo4[j] = y[j] - hi4[j]; }
+                    store_cvt<T, 4>(out16 + (int64_t)r * cols + c, hi4);
+                    store_cvt<T, 4>(out16 + out16_plane + (int64_t)r * cols + c, lo4);
+                } else {
+                    store_cvt<T, 4>(out16 + (int64_t)r * cols + c, y);
                 }
-                *(vec4*)(out16 + (int64_t)r * cols + c) = hi;
-                if (NS == 2) *(vec4*)(out16 + out16_plane + (int64_t)r * cols + c) = lo;
             }
         }
     }
@@ -152,6 +152,7 @@ extern "C" int bd_layernorm(const float* x, int64_t ldx, const float* gamma, con
         case BD_PREC_BF16: return launch_ln<__bf16, 1>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
         case BD_PREC_F16: return launch_ln<_Float16, 1>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
         case BD_PREC_BF16X3: return launch_ln<__bf16, 2>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
+        case BD_PREC_FP8: return launch_ln<fp8e4, 1>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
         default: return BD_ERR_DTYPE;
     }
 }

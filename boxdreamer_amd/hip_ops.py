@@ -26,6 +26,8 @@ def _plane(t: torch.Tensor, prec) -> int:
 def to_operand(x: torch.Tensor, prec) -> torch.Tensor:
     """fp32 [rows, cols] -> operand tensor (test helper; torch ops, not on the product path)."""
     dt = _lib.op_dtype(prec)
+    if prec_id(prec) == _lib.PREC_FP8:
+        return x.float().clamp(-448.0, 448.0).to(dt).contiguous()
     hi = x.to(dt)
     if planes(prec) == 1:
         return hi.contiguous()
@@ -36,9 +38,13 @@ def from_operand(t: torch.Tensor, prec) -> torch.Tensor:
     return t.float() if planes(prec) == 1 else t[0].float() + t[1].float()
 
 
+_OUT_DTYPES = {2: torch.float16, 3: torch.bfloat16}
+
+
 def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, addtab=None, out=None,
-         out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0)):
-    """out[map(r)] = act(A W^T + bias) + addtab[r % rows(addtab)] + resid[map(r)]."""
+         out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0), wscale=None, out_mode=None):
+    """out[map(r)] = act(wscale * (A W^T) + bias) + addtab[r % rows(addtab)] + resid[map(r)].
+    out_mode: None -> operand dtype (or fp32 with out_f32), 2 -> f16 single plane, 3 -> bf16 single plane."""
     lib = _lib.load()
     np_ = planes(prec)
     A2 = a16[0] if np_ == 2 else a16
@@ -46,17 +52,23 @@ def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, add
     M, K = A2.shape
     N = n if n is not None else W2.shape[0]
     rows_out = out_rows if out_rows is not None else M
+    mode = int(out_f32) if out_mode is None else out_mode
     if out is None:
-        out = (torch.empty((rows_out, N), dtype=torch.float32, device=A2.device) if out_f32
-               else _alloc16(rows_out, N, prec, A2.device))
+        if mode == 1:
+            out = torch.empty((rows_out, N), dtype=torch.float32, device=A2.device)
+        elif mode in _OUT_DTYPES:
+            out = torch.empty((rows_out, N), dtype=_OUT_DTYPES[mode], device=A2.device)
+        else:
+            out = _alloc16(rows_out, N, prec, A2.device)
     g = _lib.GemmArgs()
     g.A, g.lda, g.a_plane = ptr(a16), A2.stride(0), _plane(a16, prec)
     g.W, g.ldw, g.w_plane = ptr(w16), W2.stride(0), _plane(w16, prec)
     g.bias = ptr(bias)
+    g.wscale = ptr(wscale)
     g.resid, g.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
     g.addtab, g.tab_rows = ptr(addtab), (addtab.shape[0] if addtab is not None else 0)
-    o2 = out if (out_f32 or np_ == 1) else out[0]
-    g.out, g.ldo, g.out_plane, g.out_f32 = ptr(out), o2.stride(0), (0 if out_f32 else _plane(out, prec)), int(out_f32)
+    o2 = out if (mode or np_ == 1) else out[0]
+    g.out, g.ldo, g.out_plane, g.out_f32 = ptr(out), o2.stride(0), (0 if mode else _plane(out, prec)), mode
     g.M, g.N, g.K, g.act = M, N, K, act
     g.rpg_in, g.rpg_out, g.row_off = rpg
     check(lib.bd_gemm(C.byref(g), prec_id(prec), stream()), "bd_gemm")

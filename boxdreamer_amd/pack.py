@@ -20,6 +20,9 @@ import torch.nn.functional as F
 from . import _lib
 
 
+E4M3_MAX = 448.0
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -27,6 +30,8 @@ def round_up(x: int, m: int) -> int:
 def split_planes(w: torch.Tensor, prec) -> torch.Tensor:
     """fp32 -> operand dtype; BF16X3 -> stacked (hi, lo) planes, shape [2, ...]."""
     dt = _lib.op_dtype(prec)
+    if _lib.prec_id(prec) == _lib.PREC_FP8:
+        return w.clamp(-E4M3_MAX, E4M3_MAX).to(dt).contiguous()
     hi = w.to(dt)
     if _lib.planes(prec) == 1:
         return hi.contiguous()
@@ -35,18 +40,28 @@ def split_planes(w: torch.Tensor, prec) -> torch.Tensor:
 
 
 def pack_linear_weight(weight: torch.Tensor, prec, kpad: int | None = None,
-                       row_scale: torch.Tensor | None = None) -> torch.Tensor:
-    """[N, K] fp32 -> [planes?, N, Kpad] operand dtype (row_scale folds LayerScale)."""
+                       row_scale: torch.Tensor | None = None, return_scale: bool = False):
+    """[N, K] fp32 -> [planes?, N, Kpad] operand dtype (row_scale folds LayerScale).
+
+    FP8: each output channel n is stored as e4m3(w[n, :] / s_n) with s_n = max|w[n, :]| / 448; the GEMM epilogue
+    multiplies the accumulator by s_n.  With return_scale the fp32 [N] scale vector is returned too (None otherwise)."""
     w = weight.detach().float().reshape(weight.shape[0], -1)
     if row_scale is not None:
         w = w * row_scale.detach().float().reshape(-1, 1)
     k = w.shape[1]
-    kp = kpad if kpad is not None else round_up(k, 64)
-    if kp % 64 or kp < k:
+    mult = _lib.k_multiple(prec)
+    kp = kpad if kpad is not None else round_up(k, mult)
+    if kp % mult or kp < k:
         raise ValueError(f"bad kpad {kp} for K={k}")
     if kp != k:
         w = F.pad(w, (0, kp - k))
-    return split_planes(w, prec)
+    scale = None
+    if _lib.prec_id(prec) == _lib.PREC_FP8:
+        scale = (w.abs().amax(dim=1).clamp_min(1e-30) / E4M3_MAX).contiguous()
+        packed = (w / scale[:, None]).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).contiguous()
+    else:
+        packed = split_planes(w, prec)
+    return (packed, scale) if return_scale else packed
 
 
 def pack_bias(bias: torch.Tensor, row_scale: torch.Tensor | None = None) -> torch.Tensor:
@@ -105,8 +120,13 @@ class Packed:
         self.tensors.append(t)
         return C.c_void_p(t.data_ptr())
 
-    def linear(self, w: torch.Tensor, b: torch.Tensor, device) -> _lib.Linear:
-        return _lib.Linear(self.keep(w, device), self.keep(b, device))
+    def linear(self, w, b: torch.Tensor, device) -> _lib.Linear:
+        """w: packed weight, or (packed weight, per-channel scale | None) from pack_linear_weight(return_scale=True)."""
+        scale = None
+        if isinstance(w, tuple):
+            w, scale = w
+        ws = self.keep(scale, device) if scale is not None else C.c_void_p(0)
+        return _lib.Linear(self.keep(w, device), self.keep(b, device), ws)
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.tensors)
@@ -120,11 +140,11 @@ def _pack_block(pk: Packed, sd: dict, p: str, prec, device, ls: bool, qk_norm: b
     bw.ln1_b = pk.keep(sd[p + "norm1.bias"].float(), device)
     bw.ln2_w = pk.keep(sd[p + "norm2.weight"].float(), device)
     bw.ln2_b = pk.keep(sd[p + "norm2.bias"].float(), device)
-    bw.qkv = pk.linear(pack_linear_weight(sd[p + "attn.qkv.weight"], prec), pack_bias(sd[p + "attn.qkv.bias"]), device)
-    bw.proj = pk.linear(pack_linear_weight(sd[p + "attn.proj.weight"], prec, row_scale=g1),
+    bw.qkv = pk.linear(pack_linear_weight(sd[p + "attn.qkv.weight"], prec, return_scale=True), pack_bias(sd[p + "attn.qkv.bias"]), device)
+    bw.proj = pk.linear(pack_linear_weight(sd[p + "attn.proj.weight"], prec, row_scale=g1, return_scale=True),
                         pack_bias(sd[p + "attn.proj.bias"], g1), device)
-    bw.fc1 = pk.linear(pack_linear_weight(sd[p + "mlp.fc1.weight"], prec), pack_bias(sd[p + "mlp.fc1.bias"]), device)
-    bw.fc2 = pk.linear(pack_linear_weight(sd[p + "mlp.fc2.weight"], prec, row_scale=g2),
+    bw.fc1 = pk.linear(pack_linear_weight(sd[p + "mlp.fc1.weight"], prec, return_scale=True), pack_bias(sd[p + "mlp.fc1.bias"]), device)
+    bw.fc2 = pk.linear(pack_linear_weight(sd[p + "mlp.fc2.weight"], prec, row_scale=g2, return_scale=True),
                        pack_bias(sd[p + "mlp.fc2.bias"], g2), device)
     if qk_norm:
         bw.q_norm_w = pk.keep(sd[p + "attn.q_norm.weight"].float(), device)
@@ -140,7 +160,7 @@ def pack_dino(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int
     grid = img_size // patch
     reg = sd.get("register_tokens")
     prefix, pos_patch = dino_pos_tables(sd["pos_embed"], sd["cls_token"], reg, grid)
-    kpad = round_up(3 * patch * patch, 64)
+    kpad = round_up(3 * patch * patch, _lib.k_multiple(prec))
     blocks = (_lib.BlockWeights * depth)()
     for i in range(depth):
         blocks[i] = _pack_block(pk, sd, f"blocks.{i}.", prec, device, ls=f"blocks.{i}.ls1.gamma" in sd, qk_norm=False)
@@ -148,7 +168,7 @@ def pack_dino(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int
     w.depth, w.dim, w.heads, w.n_prefix = depth, dim, heads, prefix.shape[0]
     w.grid, w.patch, w.kpad = grid, patch, kpad
     w.ln_eps = 1e-6                                              # vision_transformer.py:95
-    w.patch_embed = pk.linear(pack_linear_weight(sd["patch_embed.proj.weight"], prec, kpad=kpad),
+    w.patch_embed = pk.linear(pack_linear_weight(sd["patch_embed.proj.weight"], prec, kpad=kpad, return_scale=True),
                               pack_bias(sd["patch_embed.proj.bias"]), device)
     w.pos_patch = pk.keep(pos_patch, device)
     w.prefix_tokens = pk.keep(prefix, device)
@@ -165,7 +185,7 @@ def pack_betr(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int
     dim = sd["bbox_learnable_query"].shape[-1]
     depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("attn."))
     grid = img_size // patch
-    kpad = round_up(patch * patch * box_dim, 64)
+    kpad = round_up(patch * patch * box_dim, _lib.k_multiple(prec))
     blocks = (_lib.BlockWeights * depth)()
     for i in range(depth):
         blocks[i] = _pack_block(pk, sd, f"attn.{i}.", prec, device, ls=False, qk_norm=True)
@@ -174,12 +194,12 @@ def pack_betr(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int
     w.ln_eps = 1e-5              # get_layernorm ignores its eps argument: blocks.py:805
     w.adapter_ln_eps = 1e-6      # betr.py:161
     w.rms_eps = 1e-6             # blocks.py:45
-    w.adapter_fc1 = pk.linear(pack_linear_weight(sd["input_transform.fc1.weight"], prec),
+    w.adapter_fc1 = pk.linear(pack_linear_weight(sd["input_transform.fc1.weight"], prec, return_scale=True),
                               pack_bias(sd["input_transform.fc1.bias"]), device)
-    w.adapter_fc2 = pk.linear(pack_linear_weight(sd["input_transform.fc2.weight"], prec),
+    w.adapter_fc2 = pk.linear(pack_linear_weight(sd["input_transform.fc2.weight"], prec, return_scale=True),
                               pack_bias(sd["input_transform.fc2.bias"]), device)
-    w.bbox_emb = pk.linear(pack_linear_weight(sd["bbox_emb.weight"], prec, kpad=kpad), pack_bias(sd["bbox_emb.bias"]), device)
-    w.bbox_proj = pk.linear(pack_linear_weight(sd["bbox_proj.weight"], prec), pack_bias(sd["bbox_proj.bias"]), device)
+    w.bbox_emb = pk.linear(pack_linear_weight(sd["bbox_emb.weight"], prec, kpad=kpad, return_scale=True), pack_bias(sd["bbox_emb.bias"]), device)
+    w.bbox_proj = pk.linear(pack_linear_weight(sd["bbox_proj.weight"], prec, return_scale=True), pack_bias(sd["bbox_proj.bias"]), device)
     w.pos_table = pk.keep(sincos_table(dim, grid), device)
     w.query_token = pk.keep(sd["bbox_learnable_query"].float().reshape(-1), device)
     w.blocks = C.cast(blocks, C.POINTER(_lib.BlockWeights))

@@ -20,6 +20,7 @@
  *   BD_PREC_BF16    one v_mfma_f32_32x32x16_bf16 pass             (headline mode)
  *   BD_PREC_F16     one v_mfma_f32_32x32x16_f16 pass              (4x finer operand rounding)
  *   BD_PREC_BF16X3  split-bf16 (hi*hi + hi*lo + lo*hi), 3 passes  (strict parity mode)
+ *   BD_PREC_FP8     e4m3 Linears on the block-scaled MFMA (2x rate), bf16 attention  (fast, lossy: tolerance restated)
  * In BF16X3 every 16-bit activation / weight tensor is stored as two planes (hi, then lo at
  * +plane elements); see DESIGN.md "data layout".
  */
@@ -43,6 +44,9 @@ extern "C" {
 #define BD_PREC_F16 1
 #define BD_PREC_BF16X3 2
 #define BD_PREC_F16_OUT_BF16X3 3 /* bd_attention[_q] only: f16 qkv (one plane) in, one f16 MFMA pass, split-bf16 (hi, lo) planes out */
+#define BD_PREC_FP8 4            /* OCP e4m3 operands for every Linear (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales,
+                                    per-output-channel weight scale in the epilogue); attention stays bf16 (configs[4]) */
+#define BD_PREC_BF16_OUT_FP8 5   /* bd_attention[_q] only: bf16 attention whose output is stored as e4m3 */
 
 #define BD_OK 0
 #define BD_ERR_SHAPE (-1)
@@ -68,16 +72,18 @@ const char* bd_target_arch(void); /* "gfx950" */
  *   src/models/sources/DINOv2/layers/attention.py:51-53, layers/mlp.py:29-31,
  *   and the 14x14/s14 patch-embed conv as an im2col GEMM (layers/patch_embed.py:65,75).
  * A: [M, K] 16-bit row-major (lda elements); W: [N, K] 16-bit row-major (nn.Linear layout).
- * K must be a multiple of 64 (callers zero-pad); M, N arbitrary.
+ * K must be a multiple of 64 (128 for BD_PREC_FP8; callers zero-pad); M, N arbitrary.
  * map(r) = r if rpg_in == 0 else (r / rpg_in) * rpg_out + r % rpg_in + row_off. */
 typedef struct bd_gemm_args {
     const void* A; int64_t lda; int64_t a_plane;   /* a_plane: elements between hi/lo planes (BF16X3) */
     const void* W; int64_t ldw; int64_t w_plane;
     const float* bias;                             /* [N] or NULL */
+    const float* wscale;                           /* [N] per-output-channel dequantisation scale (FP8) or NULL */
     const float* resid; int64_t ldr;               /* fp32 [*, N] indexed by the OUTPUT row, or NULL */
     const float* addtab; int tab_rows;             /* fp32 [tab_rows, N] or NULL */
     void* out; int64_t ldo; int64_t out_plane;     /* 16-bit (operand dtype of `prec`) or fp32 */
-    int out_f32;                                   /* 0: operand-dtype output (planes per `prec`), 1: fp32, 2: f16 single plane */
+    int out_f32;                                   /* 0: operand-dtype output (planes per `prec`), 1: fp32, 2: f16 single plane,
+                                                      3: bf16 single plane */
     int M, N, K;
     int act;
     int rpg_in, rpg_out, row_off;
@@ -163,8 +169,9 @@ int bd_render_corner_heatmaps(const float* corners, int n_groups, int group, int
  * Whole-path entry points
  * ---------------------------------------------------------------------------------------- */
 typedef struct bd_linear {
-    const void* w;       /* [N, Kpad] 16-bit, nn.Linear layout; BF16X3: hi plane then lo plane */
+    const void* w;       /* [N, Kpad] operand dtype, nn.Linear layout; BF16X3: hi plane then lo plane */
     const float* b;      /* [N] */
+    const float* wscale; /* [N] per-output-channel scale of an e4m3 weight (FP8 mode) or NULL */
 } bd_linear;
 
 typedef struct bd_block_weights {

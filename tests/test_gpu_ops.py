@@ -212,3 +212,55 @@ def test_attention_query_range(hip, prec):
     full = full.reshape(batch, seq, heads, hd)
     for b in range(batch):
         assert torch.equal(got[b], full[b, qv[b] * P:(qv[b] + 1) * P])       # bit-identical to the full-width kernel
+
+
+# ----------------------------------------------------------------------------- fp8 (e4m3) mode, BASELINE configs[4]
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1500, 1536, 256), (300, 200, 384), (2048, 768, 3072)])
+def test_gemm_fp8(hip, M, N, K):
+    """v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales: exact on small integers (also a layout / transpose
+    detector), and equal to the fp32 product of the DEQUANTISED operands on random data (per-channel weight scales)."""
+    ai = (torch.arange(M * K, dtype=torch.float32).reshape(M, K) * 7).remainder(9) - 4
+    wi = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 5).remainder(7) - 3
+    out = hip_ops.gemm(hip_ops.to_operand(ai.cuda(), "fp8"), hip_ops.to_operand(wi.cuda(), "fp8"), None, prec="fp8",
+                       out_f32=True)
+    assert torch.equal(out.cpu(), ai @ wi.t())
+    from boxdreamer_amd import pack
+    a, w, b = _rand("a8", (M, K), 1.5), _rand("w8", (N, K), 0.03), _rand("b8", (N,), 0.1)
+    w8, sc = pack.pack_linear_weight(w, "fp8", return_scale=True)
+    a8 = hip_ops.to_operand(a.cuda(), "fp8")
+    out = hip_ops.gemm(a8, w8.cuda(), b.cuda(), prec="fp8", out_f32=True, wscale=sc.cuda())
+    ref = (a8.float().cpu().double() @ w8.float().double().t()) * sc.double() + b.double()
+    assert (out.cpu() - ref.float()).abs().max().item() < 2e-4 * K ** 0.5
+    # and the quantisation itself is what e4m3 promises (relative step 2^-3 -> <= 2^-4 rounding error)
+    full = a.double() @ w.double().t() + b.double()
+    rel = ((out.cpu().double() - full).abs().mean() / full.abs().mean()).item()
+    assert rel < 0.08, rel
+    # bf16 single-plane output (qkv for the bf16 attention) and e4m3 output with GELU (fc1 -> fc2)
+    o_bf = hip_ops.gemm(a8, w8.cuda(), b.cuda(), prec="fp8", wscale=sc.cuda(), out_mode=3)
+    assert o_bf.dtype == torch.bfloat16 and (o_bf.float().cpu() - ref.float()).abs().max().item() < 2.0 ** -8 * ref.abs().max().item() + 1e-3
+    if N % 8 == 0:
+        o8 = hip_ops.gemm(a8, w8.cuda(), b.cuda(), prec="fp8", wscale=sc.cuda(), act=1)
+        g = F.gelu(ref.float())
+        assert o8.dtype == torch.float8_e4m3fn
+        assert (o8.float().cpu() - g).abs().max().item() <= 2.0 ** -4 * g.abs().max().item() + 2.0 ** -9
+
+
+def test_layernorm_and_layout_fp8(hip):
+    x = _rand("lnx8", (777, 768), 2.0) + 0.3
+    g, b = _rand("lng8", (768,), 0.1) + 1, _rand("lnb8", (768,), 0.1)
+    o8, o32 = hip_ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-5, prec="fp8", want32=True)
+    ref = F.layer_norm(x, (768,), g, b, 1e-5)
+    assert o8.dtype == torch.float8_e4m3fn
+    assert (o32.cpu() - ref).abs().max().item() < 2e-5
+    err = (o8.float().cpu() - ref).abs()
+    assert (err <= ref.abs() * 2.0 ** -4 + 2.0 ** -10).all()           # RNE to 3 mantissa bits (subnormal floor 2^-9)
+    data = synth.make_batch(seed=21, B=1, T=2)
+    a = hip_ops.im2col_images(data["images"][0].cuda(), kpad=640, prec="fp8")
+    mean = torch.tensor(orc._IMAGENET_MEAN).view(1, 3, 1, 1); std = torch.tensor(orc._IMAGENET_STD).view(1, 3, 1, 1)
+    cols = F.unfold((data["images"][0] - mean) / std, 14, stride=14).transpose(1, 2).reshape(512, 588)
+    got = a.float().cpu()
+    assert torch.equal(got[:, 588:], torch.zeros(512, 52)) and ((got[:, :588] - cols).abs() <= cols.abs() * 2.0 ** -4 + 2.0 ** -10).all()
+    hmap = hip_ops.patchify_heatmaps(data["bbox_feat"][0].cuda(), kpad=1664, prec="fp8").float().cpu()
+    refp = orc.patchify(data["bbox_feat"][0], 14, 8).reshape(512, 1568)
+    assert torch.equal(hmap[:, 1568:], torch.zeros(512, 96)) and ((hmap[:, :1568] - refp).abs() <= refp.abs() * 2.0 ** -4 + 2.0 ** -10).all()

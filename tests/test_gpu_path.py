@@ -150,3 +150,23 @@ def test_other_crop_sizes_and_view_counts(hip, size, T, B):
     assert (heat.cpu() - o["heat"]).abs().max().item() <= 1e-3
     same = (idx.cpu().long().sort(-1)[0] == o["topk_idx"].sort(-1)[0]).all(-1).float().mean().item()
     assert same >= 0.9
+
+
+def test_fp8_mode_restated_tolerance(hip):
+    """BASELINE configs[4]: e4m3 Linears (block-scaled MFMA, unit scales, per-channel weight scales) + bf16 attention.
+    e4m3 carries 3 mantissa bits, so the tolerance is RESTATED from measurement: the heatmap
+    logits (std ~1) must stay within 1.0 max-abs / 0.2 rms of the fp32 oracle at full depth and the decoded corners
+    within a few top-20 swaps."""
+    data, feats, logits, heat, kp, kn, idx = _run("fp8", 1, 6, 12, 12, 11)
+    o = _oracle(data, 12, 12)
+    d = (logits - o["logits"])
+    rep = {"logits_max_abs": d.abs().max().item(), "logits_rms": d.pow(2).mean().sqrt().item(),
+           "logits_ref_rms": o["logits"].pow(2).mean().sqrt().item(),
+           "feat_rms": (feats - o["rgb_feat"]).pow(2).mean().sqrt().item(),
+           "corner_px_max": (kp - o["corners_px"]).abs().max().item()}
+    print("[fp8 full_T6] " + json.dumps(rep))
+    REPORT["full_T6/fp8"] = rep
+    with open("gpurun_out/parity_report.json", "w") as f:
+        json.dump(REPORT, f, indent=1)
+    assert torch.isfinite(logits).all()
+    assert rep["logits_max_abs"] <= 1.0 and rep["logits_rms"] <= 0.2
