@@ -104,6 +104,20 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (x > 0.f ? 2.0f - erfc_abs : erfc_abs);
 }
 
+// GELU for results that are about to be rounded to 16 (or 8) bits:  x * Phi(x)  with  Phi(x) ~ 1 / (1 + 2^(-x p(x^2))),
+// p minimax-fitted against the exact erf form on [-9, 9] (tools/fit_gelu.py): |abs err| <= 5.4e-5, below half an ulp of
+// bf16 for |gelu| > 0.03 and of f16 for |gelu| > 0.2.  7 VALU + v_exp + v_rcp per element against 15 + 2 for the erfc
+// form: the fc1 epilogue is VALU-bound (64 GELUs per lane per 256x128 tile against 192 MFMAs), so this is what lets it
+// hide under the next tile's MFMAs.  Only the single-pass modes use it; the strict split-bf16 mode and every fp32
+// output keep gelu_erf.  The argument is clamped to +-8 where the fitted polynomial is still monotone (Phi saturates).
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+    const float x2 = xc * xc;
+    const float pz = fmaf(x2, fmaf(x2, -1.10189899e-03f, 1.07380689e-01f), 2.30034092f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-(xc * pz)));
+}
+template <bool FAST> __device__ __forceinline__ float gelu_sel(float x) { return FAST ? gelu_fast(x) : gelu_erf(x); }
+
 // trace.hip
 int bd_trace_open(hipStream_t s, int kind, int M, int N, int K);
 void bd_trace_close(hipStream_t s, int slot);

@@ -7,8 +7,8 @@
 // LDS-DMA wave-instruction writes 1 KiB at  M0-base + lane*16  (lane-linear), so the XOR swizzle that makes the
 // ds_read_b128 fragment reads conflict-free is applied on the SOURCE side: the lane that owns LDS slot (row, c')
 // fetches logical chunk c = c' ^ swz(row) of that row (same 128-byte line: coalescing unchanged), and fragment reads
-// apply the same involution.  One __syncthreads() per K-slab: it waits vmcnt(0) (slab kt landed) and fences the
-// buffer about to be overwritten; the DMA for slab kt+1 is issued right after it and flies under slab kt's MFMAs.
+// apply the same involution.  One barrier per K-slab (s_waitcnt vmcnt(0) + s_barrier): slab kt landed, and the
+// buffer about to be overwritten is free; the DMA for slab kt+1 is issued right after it and flies under slab kt.
 // Workgroup ids are remapped (XCD-aware, grouped raster) so that each XCD's L2 sees a compact patch of tiles.
 //
 // Operand classes (template T):
@@ -19,8 +19,9 @@
 // Tile geometry (template): WM x WN waves, each owning an (MI*32) x (NI*32) sub-tile:
 //   <2,4,4,2> 256x256, 8 waves, 128 KiB LDS, 1 workgroup/CU (wide outputs: 128 FLOP per LDS-DMA byte)
 //   <2,2,2,2> 128x128, 4 waves, 64 KiB, 2 workgroups/CU (N = 768 outputs)      <2,2,1,1> 64x64 (latency mode)
-// Experiments that did NOT pay (deeper LDS-DMA rings, mid-slab barriers, ping-pong wave groups, 256x128 tiles) and the
-// counters behind the choices: profiles/r1_gemm_experiments.md, profiles/r1_gemm_pmc.md.
+// Experiments that did NOT pay (deeper LDS-DMA rings, mid-slab barriers, ping-pong wave groups, 256x128 tiles at one or
+// two workgroups per CU, a persistent tile loop with the epilogue overlapped, pinned fragment prefetch) and the counters
+// behind the choices: profiles/r1_gemm_experiments.md, profiles/r1_gemm_pmc.md.
 #include <stdlib.h>
 
 #include "bd_common.h"
@@ -47,6 +48,24 @@ __device__ __forceinline__ void tile_coords_t(int M, int N, int group_m, int& m0
     const int gh = (tilesM - gm0) < group_m ? (tilesM - gm0) : group_m;
     m0 = (gm0 + in_g % gh) * BM_;
     n0 = (in_g / gh) * BN_;
+}
+
+// LDS-DMA from inline asm.  With the builtin, hipcc's waitcnt pass sees an LDS write it cannot place: it then (a) puts
+// s_waitcnt vmcnt(0) in front of the first ds_read that follows a pending DMA in the same block (the prefetch latency is
+// exposed every slab) and (b) degrades every ds_read wait to lgkmcnt(0) (no counted waits, so the fragment reads of the
+// next k-step cannot stay in flight under the MFMAs of this one).  Hidden from the compiler the prefetch flies under the
+// slab's MFMAs, fragment waits are counted, and slab_barrier() does the one wait that is really needed.
+// (M0 has no other user in these kernels: gfx9+ DS ops do not read it.)
+__device__ __forceinline__ void glds16(const unsigned char* g, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_off) : "memory");
+}
+__device__ __forceinline__ void slab_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces (and earlier stores) have landed
+    __builtin_amdgcn_s_barrier();                         // ... and everyone else's; the other buffer is free
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p);
 }
 
 // out_f32 codes
@@ -210,9 +229,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = a0[e] * sv[e] + bv[e]; v[4 + e] = a1[e] * sv[4 + e] + bv[4 + e]; }
-                if (act == BD_ACT_GELU) {
+                if (act == BD_ACT_GELU) {              // 16/8-bit result: fitted GELU in the single-pass modes (bd_common.h)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_sel<NS == 1>(v[e]);
                 }
                 if (cok && gr < M) {
                     const int64_t orow = rpg_in > 0 ? (int64_t)(gr / rpg_in) * rpg_out + gr % rpg_in + row_off : (int64_t)gr;
@@ -264,7 +283,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gem
     constexpr int STAGE_BYTES = (A_BYTES + W_BYTES) * NS;   // A planes then W planes
     constexpr int KS = BK / KSTEP;
     static_assert(KS >= 1 && CH * 16 == ROWB && (CH == 4 || CH == 8), "slab geometry");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
+    constexpr int EPI_SCRATCH = NWAVE * 32 * NI * 32 * 4;   // the wide epilogue's per-wave transpose scratch
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES > EPI_SCRATCH ? 2 * STAGE_BYTES : EPI_SCRATCH];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -288,16 +308,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gem
         gw[i] = (const unsigned char*)p.W + ((int64_t)wr * p.ldw) * ESZ + swz_chunk<CH>(row, lane % CH) * 16;
     }
     const int64_t a_plane = p.a_plane * ESZ, w_plane = p.w_plane * ESZ;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned lds_off = lds_offset_of(lds);
 #define DMA_SLAB(buf, kb)                                                                                     \
     _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                          \
         _Pragma("unroll") for (int i = 0; i < PPW_A; ++i)                                                     \
-            __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + s * a_plane + (kb)),                            \
-                (lptr_t)(lds + (buf) * STAGE_BYTES + s * A_BYTES + (wid * PPW_A + i) * 1024), 16, 0, 0);      \
+            glds16(ga[i] + s * a_plane + (kb), lds_off + (buf) * STAGE_BYTES + s * A_BYTES + (wid * PPW_A + i) * 1024); \
         _Pragma("unroll") for (int i = 0; i < PPW_W; ++i)                                                     \
-            __builtin_amdgcn_global_load_lds((gptr_t)(gw[i] + s * w_plane + (kb)),                            \
-                (lptr_t)(lds + (buf) * STAGE_BYTES + NS * A_BYTES + s * W_BYTES + (wid * PPW_W + i) * 1024), 16, 0, 0); \
+            glds16(gw[i] + s * w_plane + (kb), lds_off + (buf) * STAGE_BYTES + NS * A_BYTES + s * W_BYTES + (wid * PPW_W + i) * 1024); \
     }
 
     f32x16 acc[MI][NI];
@@ -312,7 +329,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gem
     const int nk = p.K / BK;
     DMA_SLAB(0, 0)
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                                   // slab kt landed; buffer (kt+1)&1 is free
+        slab_barrier();                                    // slab kt landed; buffer (kt+1)&1 is free
         if (kt + 1 < nk) { DMA_SLAB((kt + 1) & 1, (kt + 1) * ROWB) }
         const unsigned char* base = lds + (kt & 1) * STAGE_BYTES;
         // fragments are double-buffered in registers (one plane only: two sets next to 128 accumulators would
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gem
     }
 }
 
-int gemm_impl() {   // BD_GEMM_IMPL=2: 128x128 tiles only, =3: 256x128 (measurement)
+int gemm_impl() {   // BD_GEMM_IMPL=2: 128x128 tiles only (measurement)
     static const int impl = [] { const char* e = getenv("BD_GEMM_IMPL"); return e ? atoi(e) : 1; }();
     return impl;
 }
@@ -387,9 +404,7 @@ template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_g
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     const int impl = gemm_impl();
-    if (impl == 3) {
-        launch_glds<T, NS, BK, 2, 4, 4, 1>(a, s);                 // 256 x 128 (measurement only)
-    } else {
+    {
         // Tile choice = best estimated efficiency: wave quantisation over the resident slots (256x256: one workgroup
         // per CU; 128x128: two; 64x64: four) times the measured relative mainloop efficiency of the tile
         // (profiles/r1_gemm_experiments.md: 128x128 ~0.87 of 256x256 on the wide shapes; 64x64 ~0.55).

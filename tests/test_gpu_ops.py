@@ -43,6 +43,45 @@ def test_gemm_plain(hip, prec, M, N, K):
     assert torch.equal(out.cpu(), ai @ wi.t())
 
 
+@pytest.mark.parametrize("prec", PRECS + ["fp8"])
+@pytest.mark.parametrize("M,N,K", [(7500, 2304, 768), (9000, 3072, 640), (16500, 1024, 320)])
+def test_gemm_block_sized(hip, prec, M, N, K):
+    """Transformer-block sized Linears (hundreds of 256x256 / 128x128 tiles, several tile rounds per CU, ragged last
+    M-tile): exact on small integers through the 16-bit output path, GELU + bias, and the in-place fp32 residual form."""
+    if prec == "fp8" and K % 128:
+        pytest.skip("fp8 slabs are 128 deep")
+    dev = torch.device("cuda")
+    ai = ((torch.arange(M * K, dtype=torch.float32, device=dev).reshape(M, K) * 7).remainder(5) - 2)
+    wi = ((torch.arange(N * K, dtype=torch.float32, device=dev).reshape(N, K) * 3).remainder(3) - 1)
+    bi = (torch.arange(N, dtype=torch.float32, device=dev).remainder(9) - 4)
+    exact = ai @ wi.t() + bi                                    # small integers: exact in fp32
+    a16, w16 = hip_ops.to_operand(ai, prec), hip_ops.to_operand(wi, prec)
+    if prec == "fp8":
+        o = hip_ops.gemm(a16, w16, bi, prec=prec, out_mode=3)   # bf16 plane (qkv of the fp8 mode)
+        assert o.dtype == torch.bfloat16 and torch.equal(o, exact.to(torch.bfloat16))
+    else:
+        o = hip_ops.gemm(a16, w16, bi, prec=prec)               # operand-dtype output, RNE of the exact value
+        got = hip_ops.from_operand(o, prec)
+        want = hip_ops.from_operand(hip_ops.to_operand(exact, prec), prec)
+        assert torch.equal(got, want)
+    # random data + bias + GELU (fc1), against fp32 math on the dequantised operands
+    a, w, b = _rand("pa", (M, K)).to(dev), _rand("pw", (N, K), 0.05).to(dev), _rand("pb", (N,), 0.1).to(dev)
+    a16, w16 = hip_ops.to_operand(a, prec), hip_ops.to_operand(w, prec)
+    aq, wq = hip_ops.from_operand(a16, prec), hip_ops.from_operand(w16, prec)
+    ref = F.gelu(aq @ wq.t() + b)
+    o = hip_ops.from_operand(hip_ops.gemm(a16, w16, b, prec=prec, act=1), prec) if prec != "fp8" else \
+        hip_ops.gemm(a16, w16, b, prec=prec, act=1).float()
+    eps = 2.0 ** -4 if prec == "fp8" else EPS[prec]
+    assert (o - ref).abs().max().item() <= eps * max(1.0, ref.abs().max().item()) + 3e-4 * K ** 0.5
+    # fp32 output accumulated in place onto the residual stream (proj / fc2)
+    res = _rand("pr", (M, N)).to(dev)
+    buf = res.clone()
+    hip_ops.gemm(a16, w16, b, prec=prec, out_f32=True, out=buf, resid=buf)
+    want = aq @ wq.t() + b + res
+    tol = (2e-4 if prec != "bf16x3" else 4e-4) * K ** 0.5
+    assert (buf - want).abs().max().item() <= tol
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_gemm_epilogues(hip, prec):
     M, N, K, P, TPI, OFF = 512, 256, 128, 256, 261, 5
