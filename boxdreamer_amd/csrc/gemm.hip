@@ -401,6 +401,25 @@ template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_g
     hipLaunchKernelGGL((gemm_kernel_glds<T, NS, BK, WM, WN, MI, NI>), dim3(tiles), dim3(WM * WN * 64), 0, s, a);
 }
 
+int gemm_split() {   // BD_GEMM_SPLIT=k forces k rounds of 256x256 tiles ahead of the 128x128 remainder (measurement); default: model
+    static const int v = [] { const char* e = getenv("BD_GEMM_SPLIT"); return e ? atoi(e) : -1; }();
+    return v;
+}
+
+constexpr int kCUs = 256;   // gfx950: one 256x256 workgroup per CU, two 128x128, four 64x64
+
+// rows [row0, row0 + rows) of the problem as its own launch (no row remap / table: checked by the caller)
+template <class T> bd_gemm_args row_slice(const bd_gemm_args& a, int64_t row0, int rows) {
+    bd_gemm_args sub = a;
+    constexpr int ESZ = OpGeom<T>::ESZ;
+    const int osz = a.out_f32 == OUT_F32 ? 4 : (a.out_f32 == OUT_OPERAND ? ESZ : 2);
+    sub.A = (const unsigned char*)a.A + row0 * a.lda * ESZ;
+    sub.out = (unsigned char*)a.out + row0 * a.ldo * osz;
+    if (a.resid) sub.resid = a.resid + row0 * a.ldr;
+    sub.M = rows;
+    return sub;
+}
+
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     const int impl = gemm_impl();
@@ -413,10 +432,51 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
             const double rounds = (double)(((int64_t)tiles + slots - 1) / slots);
             return base * tiles / (rounds * slots);
         };
-        const double e256 = (a.N >= 1536 && impl != 2) ? eff(256, 256, 256, 1.0) : 0.0;
-        const double e128 = eff(128, 128, 512, 0.87);
-        const double e64 = impl == 2 ? 0.0 : eff(64, 64, 1024, 0.55);
-        if (e256 >= e128 && e256 >= e64)
+        const double e256 = (a.N >= 1536 && impl != 2) ? eff(256, 256, kCUs, 1.0) : 0.0;
+        const double e128 = eff(128, 128, 2 * kCUs, 0.87);
+        const double e64 = impl == 2 ? 0.0 : eff(64, 64, 4 * kCUs, 0.55);
+        // Narrow outputs (N = 768: proj / fc2) have too few 256x256 tiles for whole rounds (576 tiles = 2.25 rounds) and
+        // pay 4.5 -> 5 rounds plus the weaker mainloop with 128x128 tiles.  Hybrid: k FULL rounds of 256x256 tiles over
+        // the first rows, the remaining rows as 128x128 tiles -- two launches over disjoint row ranges, no split-K, no
+        // cross-workgroup fix-up, bit-identical per-row arithmetic order (the K order of a row does not depend on the
+        // tile).  Cost model in units of one 256x256 round; a 128x128 round is 2 tiles per CU at 0.87 efficiency.
+        // Only for deep K (fc2: 324 -> 297 us): at K = 768 (proj) the GEMM is bound by its fp32 residual epilogue, which
+        // two co-resident 128x128 workgroups overlap better than one 256x256 workgroup (117 vs 125 us).
+        int k256 = 0;
+        int64_t rows256 = 0;
+        if (impl != 2 && a.N % 256 == 0 && a.N < 1536 && a.K >= 2048 && a.rpg_in <= 0 && !a.addtab && a.M >= 1024) {
+            const int tn = a.N / 256;
+            const int64_t mtiles = (a.M + 255) / 256;
+            auto cost128 = [&](int64_t rows) {
+                if (rows <= 0) return 0.0;
+                const int64_t t = ((rows + 127) / 128) * (a.N / 128);
+                const int64_t full = t / (2 * kCUs), rem = t % (2 * kCUs);
+                // a partial last round runs with one workgroup on most CUs: faster than a full round
+                return full * 0.575 + (rem == 0 ? 0.0 : (rem <= kCUs ? 0.36 : 0.575));
+            };
+            double best = cost128(a.M);
+            for (int k = 1; k <= 64; ++k) {
+                const int64_t mt = (int64_t)k * kCUs / tn;
+                if (mt > mtiles) break;
+                const int64_t r256 = mt * 256 < a.M ? mt * 256 : a.M;
+                const double c = k + cost128(a.M - r256);
+                if (c < best - 1e-9) { best = c; k256 = k; rows256 = r256; }
+            }
+            if (gemm_split() >= 0) {
+                k256 = gemm_split();
+                const int64_t mt = (int64_t)k256 * kCUs / tn;
+                rows256 = mt * 256 < a.M ? mt * 256 : a.M;
+                if (mt == 0) k256 = 0;
+            }
+        }
+        if (k256 > 0) {
+            const bd_gemm_args big = row_slice<T>(a, 0, (int)rows256);
+            launch_glds<T, NS, BK, 2, 4, 4, 2>(big, s);
+            if (rows256 < a.M) {
+                const bd_gemm_args rest = row_slice<T>(a, rows256, (int)(a.M - rows256));
+                launch_glds<T, NS, BK, 2, 2, 2, 2>(rest, s);
+            }
+        } else if (e256 >= e128 && e256 >= e64)
             launch_glds<T, NS, BK, 2, 4, 4, 2>(a, s);             // 256 x 256, 1 workgroup / CU
         else if (e128 >= e64)
             launch_glds<T, NS, BK, 2, 2, 2, 2>(a, s);             // 128 x 128, 2 workgroups / CU
