@@ -11,8 +11,16 @@ std::vector<Slot> g_slots;
 int g_count = -1;   // -1: tracing off
 }  // namespace
 
+// Event records cannot be timed once captured into a HIP graph (ROCm 7.2: hipEventElapsedTime -> hipErrorInvalidHandle,
+// and hipEventRecordExternal nodes are refused during torch's capture), so launches issued while the stream is
+// capturing are simply not traced; bench.py times graph replays and traces the same step un-graphed right after.
+static bool capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+}
+
 int bd_trace_open(hipStream_t s, int kind, int M, int N, int K) {
-    if (g_count < 0 || g_count >= (int)g_slots.size()) return -1;
+    if (g_count < 0 || g_count >= (int)g_slots.size() || capturing(s)) return -1;
     Slot& sl = g_slots[g_count];
     sl.kind = kind; sl.M = M; sl.N = N; sl.K = K;
     hipEventRecord(sl.e0, s);
