@@ -116,6 +116,57 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_kernel(T* __restrict__ qkv, in
     }
 }
 
+// Coalesced variant: one wave per token row.  The q|k part of a row is 2*heads*HD contiguous elements; lane l owns
+// EPL = 2*heads*HD/64 consecutive ones (three 16-byte chunks for 8 heads x 96), so a wave's loads and stores cover the
+// 3 KiB row back to back (the thread-per-vector kernel above strides 192 B between lanes), and the LPV = HD/EPL lanes of
+// one (q|k, head) vector combine their sums of squares with LPV-1 xor-shuffles.
+template <class T, int NS, int HD, int EPL>
+__global__ __launch_bounds__(256) void qk_rmsnorm_row_kernel(T* __restrict__ qkv, int64_t plane,
+                                                             const float* __restrict__ wq,
+                                                             const float* __restrict__ wk, float eps,
+                                                             int rows, int heads) {
+    typedef typename Op16<T>::vec8 vec8;
+    constexpr int NC = EPL / 8, LPV = HD / EPL;
+    static_assert(EPL % 8 == 0 && HD % EPL == 0 && (LPV & (LPV - 1)) == 0, "row split");
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    T* ptr = qkv + row * (3 * heads * HD) + lane * EPL;
+    const int vec = lane / LPV;                         // 0 .. 2*heads-1: q heads then k heads
+    const float* w = (vec < heads ? wq : wk) + (lane % LPV) * EPL;
+    float f[NC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        vec8 hi = as_vec8<T>(*(const u128*)(ptr + c * 8));
+        vec8 lo;
+        if (NS == 2) lo = as_vec8<T>(*(const u128*)(ptr + plane + c * 8));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = to_f32<T>(hi[j]);
+            if (NS == 2) a += to_f32<T>(lo[j]);
+            f[c][j] = a;
+            ss += a * a;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < LPV; o <<= 1) ss += __shfl_xor(ss, o);
+    const float r = rsqrtf(ss / (float)HD + eps);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const f32x4 w0 = *(const f32x4*)(w + c * 8), w1 = *(const f32x4*)(w + c * 8 + 4);
+        vec8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = (j < 4 ? w0[j] : w1[j - 4]) * (f[c][j] * r);
+            hi[j] = from_f32<T>(y);
+            if (NS == 2) lo[j] = from_f32<T>(y - to_f32<T>(hi[j]));
+        }
+        *(vec8*)(ptr + c * 8) = hi;
+        if (NS == 2) *(vec8*)(ptr + plane + c * 8) = lo;
+    }
+}
+
 template <class T, int NS>
 int launch_ln(const float* x, int64_t ldx, const float* g, const float* b, float eps, void* o16, int64_t o16p,
               float* o32, int64_t ldo, int rows, int cols, int rpg_in, int rpg_out, int row_off, hipStream_t s) {
@@ -130,6 +181,12 @@ int launch_rms(void* qkv, int64_t plane, const float* wq, const float* wk, float
                int hd, hipStream_t s) {
     const int64_t total = (int64_t)rows * 2 * heads;
     const dim3 grid((unsigned)((total + 255) / 256));
+    if (hd == 96 && heads == 8) {                      // BETR: the whole q|k row across one wave
+        hipLaunchKernelGGL((qk_rmsnorm_row_kernel<T, NS, 96, 24>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (T*)qkv,
+                           plane, wq, wk, eps, rows, heads);
+        BD_CHECK_LAUNCH();
+        return BD_OK;
+    }
     if (hd == 96)
         hipLaunchKernelGGL((qk_rmsnorm_kernel<T, NS, 96>), grid, dim3(256), 0, s, (T*)qkv, plane, wq, wk, eps, rows, heads);
     else if (hd == 64)
