@@ -116,6 +116,43 @@ __device__ __forceinline__ float gelu_fast(float x) {
     const float pz = fmaf(x2, fmaf(x2, -1.10189899e-03f, 1.07380689e-01f), 2.30034092f);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-(xc * pz)));
 }
+// Transcendental-free variant for bf16 / e4m3 results, two elements per instruction (v_pk_fma_f32):
+//   gelu(x) ~ x * (0.5 + xc * P(xc^2)),  xc = clamp(x, -4, 4),  P of degree 7 in xc^2, minimax-fitted (tools/fit_gelu.py);
+// |abs err| <= 1.6e-4 in fp32 arithmetic = half a bf16 ulp at |gelu| = 0.08.  v_exp_f32 / v_rcp_f32 issue at quarter
+// rate, so gelu_fast spends most of its time in them; this form is ~2x cheaper.  fp16 results keep gelu_fast (an f16 ulp
+// is 8x finer), fp32 / split-bf16 results keep gelu_erf.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
+    f32x2 xc;
+    xc.x = __builtin_amdgcn_fmed3f(x.x, -4.0f, 4.0f);
+    xc.y = __builtin_amdgcn_fmed3f(x.y, -4.0f, 4.0f);
+    const f32x2 x2 = xc * xc;
+    f32x2 pz = x2 * -1.411566826e-09f + 1.110951978e-07f;
+    pz = pz * x2 + -3.829025890e-06f;
+    pz = pz * x2 + 7.702150218e-05f;
+    pz = pz * x2 + -1.020914998e-03f;
+    pz = pz * x2 + 9.552915274e-03f;
+    pz = pz * x2 + -6.594778014e-02f;
+    pz = pz * x2 + 3.986759341e-01f;
+    return x * (xc * pz + 0.5f);
+}
+// GELU of N (even) values headed for a 16/8-bit store: KIND 0 exact erf, 1 exp-based fit, 2 packed polynomial
+template <int KIND, int N> __device__ __forceinline__ void gelu_n(float (&v)[N]) {
+    if constexpr (KIND == 2) {
+#pragma unroll
+        for (int e = 0; e < N; e += 2) {
+            const f32x2 y = gelu_poly2((f32x2){v[e], v[e + 1]});
+            v[e] = y.x; v[e + 1] = y.y;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = KIND == 1 ? gelu_fast(v[e]) : gelu_erf(v[e]);
+    }
+}
+// which form a narrow (16/8-bit) result of operand class T in an NS-plane mode takes
+template <class T, int NS> struct GeluKind { static constexpr int value = NS == 2 ? 0 : 2; };
+template <> struct GeluKind<_Float16, 1> { static constexpr int value = 1; };
+
 template <bool FAST> __device__ __forceinline__ float gelu_sel(float x) { return FAST ? gelu_fast(x) : gelu_erf(x); }
 
 // trace.hip

@@ -229,10 +229,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = a0[e] * sv[e] + bv[e]; v[4 + e] = a1[e] * sv[4 + e] + bv[4 + e]; }
-                if (act == BD_ACT_GELU) {              // 16/8-bit result: fitted GELU in the single-pass modes (bd_common.h)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_sel<NS == 1>(v[e]);
-                }
+                if (act == BD_ACT_GELU) gelu_n<GeluKind<T, NS>::value, 8>(v);   // 16/8-bit result: fitted forms (bd_common.h)
                 if (cok && gr < M) {
                     const int64_t orow = rpg_in > 0 ? (int64_t)(gr / rpg_in) * rpg_out + gr % rpg_in + row_off : (int64_t)gr;
                     if (addtab) {
