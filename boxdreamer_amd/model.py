@@ -2,7 +2,8 @@
 (/root/reference/src/models/BoxDreamerModel.py:21-384).  Same constructor input (`config["modules"]`),
 same batch-dict keys in and out, same `decoder.*` state_dict, same encoder-plugin API -- the internals call
 the gfx950 HIP library.  Only the released configuration (dino encoder, bb8 / heatmap) is implemented;
-tracker / matcher / dense mode / plucker rays are out of the hot path and raise.
+tracker / matcher / plucker rays are out of the hot path and raise; the dense-reference mode ("next" row
+f4) is wired through boxdreamer_amd/dense.py.
 """
 from __future__ import annotations
 
@@ -13,6 +14,7 @@ from .betr import BETR
 from .box_utils import recover_bb8_corners_chw, solve_poses_host
 from .cache import merge_cached_features
 from .config import setup_camera_params, validate_model_config
+from .dense import process_dense_input, process_multi_round
 from .encoder import DinoV2Wrapper
 
 
@@ -52,8 +54,6 @@ class BoxDreamer(nn.Module):
             raise NotImplementedError("Tracking is not supported yet")            # BoxDreamerModel.py:74-75
         if self.use_matching:
             raise NotImplementedError("LoFTR matching is outside the MI355X hot path")
-        if self.dense_cfg is not None and _get(self.dense_cfg, "enable", False):
-            raise NotImplementedError("dense-reference mode is a 'next' row (SURVEY.md §8 f4)")
         if self.pose_representation != "bb8" or self.roatation_type is not None:
             raise NotImplementedError("only pose_representation='bb8' (rotation_type null) is on the hot path")
         self.tracker = None
@@ -85,7 +85,24 @@ class BoxDreamer(nn.Module):
                                                 data["cached_rgb_mask"])
         else:
             rgb_feature = self.rgb_encoder.predict(images)
-        query_ret = self.decoder(pose_feat, images, camera_mask, rgb_feature, None)
+        if self.dense_cfg is not None and _get(self.dense_cfg, "enable", False):     # BoxDreamerModel.py:291-327
+            data, pose_feat, images, camera_mask, rgb_feature, _ = process_dense_input(
+                data, pose_feat, images, camera_mask, rgb_feature, None, self.dense_cfg)
+            if _get(self.dense_cfg, "multi_round", False):
+                query_ret = process_multi_round(data, pose_feat, images, camera_mask, rgb_feature, None, self.decoder,
+                                                self.dense_cfg, self.bbox_representation)
+                if isinstance(query_ret, dict):                                   # coarse prediction only: dict is final
+                    return query_ret
+            else:
+                query_ret = self.decoder(pose_feat.contiguous(), images.contiguous(), camera_mask,
+                                         rgb_feature.contiguous(), None)
+            # the dense helpers re-pack the batch dict: re-read the views / query position (BoxDreamerModel.py:150-158)
+            images = data["images"]
+            B, T = images.shape[:2]
+            camera_mask = torch.zeros((B, T), dtype=torch.bool, device=images.device)
+            camera_mask[torch.arange(B, device=images.device), data["query_idx"].to(images.device).long()] = True
+        else:
+            query_ret = self.decoder(pose_feat, images, camera_mask, rgb_feature, None)
 
         data["pred_bbox"] = data["bbox_feat"].clone()                            # BoxDreamerModel.py:341-344
         data["pred_bbox"][camera_mask] = query_ret.to(data["pred_bbox"].dtype)

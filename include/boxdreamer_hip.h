@@ -165,6 +165,19 @@ int bd_decode_topk(const float* heat, int n_maps, int height, int width, int k, 
 int bd_render_corner_heatmaps(const float* corners, int n_groups, int group, int height, int width,
                               void* out, int out_dtype, void* stream);
 
+/* Dense-reference mode ("next" row f4): DINO-feature reference selection, src/models/utils/matching.py:64-174
+ * (`dino_matching`, called from process_dense_input, src/models/utils/data_processing.py:179-225).
+ * feats: fp32 [B, T, L, D] patch features of every view (the encoder output); images: [B, T, 3, H, W] RGB crops in [0, 1]
+ * (img_dtype BD_DTYPE_*); query_view[b]: index of the query view.  scores: fp32 [B, T-1], one per reference in view order
+ * = mean over the L x L patch pairs of the masked cosine similarity with the reference's -1e4 fill, evaluated in closed
+ * form.  sums [B*T, D] and counts [B*T] are caller-provided scratch (per-view foreground feature sum / patch count). */
+int bd_dino_match_scores(const float* feats, const void* images, int img_dtype, const int32_t* query_view, int B, int T,
+                         int L, int D, int H, int W, float lum_threshold, float* sums, float* counts, float* scores,
+                         void* stream);
+
+/* Boolean top-k mask per row of scores [B, N] (matching.py:167-173): k largest, ties to the lower index. mask: uint8 [B, N]. */
+int bd_topk_mask(const float* scores, int B, int N, int k, unsigned char* mask, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Whole-path entry points
  * ---------------------------------------------------------------------------------------- */

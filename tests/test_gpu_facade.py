@@ -122,3 +122,78 @@ def test_hip_graph_replay_matches_eager(hip):
         ref = model.decoder(bf, img, mask.cuda(), model.rgb_encoder.predict(img), None)
         rkp, _, ridx = hip_ops.decode_topk(ref)
         assert torch.equal(heat, ref) and torch.equal(kp, rkp) and torch.equal(idx, ridx)
+
+
+def _dense_model_and_batch(dense_cfg, B=2, T=7, seed=13):
+    cfg = _config("bf16x3")
+    cfg["modules"]["dense_cfg"] = dense_cfg
+    model = BoxDreamer(cfg)
+    model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
+    model = model.cuda().eval()
+    data = synth.make_batch(seed=seed, B=B, T=T)
+    # crops in [0, 1] with a black border of a different width per view -> distinct foreground counts
+    img = (data["images"].float() * 0.25 + 0.5).clamp(0, 1)
+    for b in range(B):
+        for t in range(T):
+            w = 14 * ((3 * b + 2 * t) % 5)
+            m = torch.zeros(224, 224); m[w:224 - w, w:224 - w] = 1
+            img[b, t] *= m
+    data["images"] = img
+    data["query_idx"] = torch.tensor([T - 1, 1][:B])
+    return model, data
+
+
+def test_dense_mode_filter_path(hip):
+    """dense_cfg.enable + filter='dino' (BoxDreamerModel.py:291-330, data_processing.py:179-225): references are ranked
+    by the HIP similarity kernel, the batch is re-packed (selected references in order, query last) and decoded once.
+    The re-packed decode must equal the oracle run on the views the facade itself selected."""
+    from boxdreamer_amd import dense
+    from oracle import dense_oracle as do
+    k = 3
+    model, data = _dense_model_and_batch({"enable": True, "filter": "dino", "filter_enable": True, "filter_topk": k,
+                                          "multi_round": False})
+    B, T = data["images"].shape[:2]
+    dev = {kk: (v.cuda() if torch.is_tensor(v) else v) for kk, v in data.items()}
+    out = model(dev)
+    assert out["images"].shape[1] == k + 1 and out["bbox_feat"].shape[1] == k + 1 and out["poses"].shape[1] == k + 1
+    assert out["query_idx"].tolist() == [k] * B and out["camera_mask"][:, -1].all()
+    assert out["pred_bbox"].shape == (B, k + 1, 8, 224, 224)
+    # which references were kept: recover from the re-packed images
+    cm = torch.zeros(B, T, dtype=torch.bool); cm[torch.arange(B), data["query_idx"]] = True
+    feats = model.rgb_encoder.predict(data["images"].cuda()).cpu()
+    rf = feats[~cm].reshape(B, T - 1, *feats.shape[2:]); ri = data["images"][~cm].reshape(B, T - 1, 3, 224, 224)
+    exact = do.dino_matching_scores_closed_form(rf, feats[cm], ri, data["images"][cm])
+    sel = torch.zeros(B, T - 1, dtype=torch.bool)
+    for b in range(B):
+        for j in range(k):
+            hit = [(ri[b, n] == out["images"][b, j].cpu()).all().item() for n in range(T - 1)]
+            assert sum(hit) >= 1
+            sel[b, hit.index(True)] = True
+        assert exact[b][sel[b]].min().item() >= exact[b][~sel[b]].max().item() - 8e-3      # a valid top-k
+    # decode parity on the selected views
+    sub = {"images": do.filter_views(data["images"], cm, sel), "bbox_feat": do.filter_views(data["bbox_feat"].float(), cm, sel),
+           "query_idx": torch.full((B,), k)}
+    o = orc.boxdreamer_forward(sub, synth.betr_state_dict(1234, 2), synth.dino_state_dict(4321, 2))
+    assert (model.decoder.last_logits.cpu() - o["logits"]).abs().max().item() <= 1e-3
+
+
+def test_dense_mode_multi_round(hip):
+    """multi_round: decoder over sub-batches of the references (+ query), one PnP over all rounds' corners, then either
+    the coarse dict (fine_level False) or a fine decode on the pose-nearest references (dense_processing.py:8-158)."""
+    base = {"enable": True, "filter": "dino", "filter_enable": False, "filter_topk": 4, "multi_round": True,
+            "sub_batch_size": 3, "dense_mem_friendly": False, "fine_level": False, "fine_topk": 2}
+    model, data = _dense_model_and_batch(base)
+    B, T = data["images"].shape[:2]
+    dev = {kk: (v.cuda() if torch.is_tensor(v) else v) for kk, v in data.items()}
+    out = model(dev)
+    assert out["pred_poses"].shape == (B, T, 4, 4) and out["pred_bbox"].shape == (B, T, 8, 224, 224)
+    assert torch.isfinite(out["pred_poses"]).all()
+    # both scheduling variants of the rounds give the same heatmaps
+    model2, data2 = _dense_model_and_batch({**base, "dense_mem_friendly": True})
+    out2 = model2({kk: (v.cuda() if torch.is_tensor(v) else v) for kk, v in data2.items()})
+    assert torch.equal(out["pred_bbox"], out2["pred_bbox"])
+    # fine level: a second decode on fine_topk references + query
+    model3, data3 = _dense_model_and_batch({**base, "fine_level": True})
+    out3 = model3({kk: (v.cuda() if torch.is_tensor(v) else v) for kk, v in data3.items()})
+    assert out3["images"].shape[1] == 3 and out3["pred_bbox"].shape == (B, 3, 8, 224, 224)
+    assert out3["camera_mask"][:, -1].all() and torch.isfinite(out3["pred_poses"]).all()
