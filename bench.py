@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel from the host each step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-pnp", action="store_true", help="skip the PnP-inclusive side measurement (host PnP, SURVEY 8d / 8f3)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -297,6 +298,25 @@ def main():
                            "gflop_per_pose": round(fpp / 1e9, 2)},
                 "poses_per_s_per_gpu": round(value / world, 2),
                 "roofline": roofline}
+        if not args.no_pnp:
+            # PnP-inclusive rate (SURVEY 8d asks for it next to `value`, never as `value`): one D2H of the decoded corners
+            # per batch + ONE batched host solve (boxdreamer_amd/pnp.py, row f3).  Serialised = no overlap at all;
+            # overlapped = PnP of batch i on the host while the GPU runs batch i+1.
+            from boxdreamer_amd.box_utils import solve_poses_host
+            b3 = one["bbox_3d"].float().reshape(-1, 8, 3)
+            b3 = b3[-1:].repeat(B, 1, 1).numpy()
+            Kq = one["non_ndc_intrinsics"].float().reshape(-1, 3, 3)[-1:].repeat(B, 1, 1).numpy()
+            tp = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                kp_host = out[:B].float().cpu().numpy()
+                solve_poses_host(kp_host, b3, Kq)
+                tp.append(time.perf_counter() - t1)
+            pnp_ms = sorted(tp)[1] * 1e3
+            step_ms = dt / args.steps * 1e3
+            line["pnp_inclusive"] = {"pnp_ms_per_batch": round(pnp_ms, 2), "host": "numpy batched DLT + LM, 1 thread, parity vs OpenCV un-pinned",
+                                     "serialised_poses_per_s": round(B * world / ((step_ms + pnp_ms) / 1e3), 1),
+                                     "overlapped_poses_per_s": round(min(value, B * world / (pnp_ms / 1e3)), 1)}
         if not args.no_parity:
             line["parity"] = parity_probe(prec, T, device)
         if not args.no_cpu_baseline and world == 1:

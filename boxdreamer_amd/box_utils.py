@@ -6,14 +6,12 @@ the 3-D box and K to the host ONCE per batch and solves PnP there (the reference
 calls per sample inside a Python loop, box_utils.py:139-199)."""
 from __future__ import annotations
 
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
 
 from . import hip_ops, pnp
 
-_POOL = None
 
 
 def recover_bb8_corners(bbox_feat: torch.Tensor, bbox_representation: str = "heatmap"):
@@ -34,29 +32,20 @@ def recover_bb8_corners_chw(heat: torch.Tensor, want_idx: bool = False):
 
 
 def solve_poses_host(kp_px: np.ndarray, bbox_3d: np.ndarray, K: np.ndarray, workers: int = 8) -> np.ndarray:
-    """kp_px [N,8,2], bbox_3d [N,8,3], K [N,3,3] (host) -> poses [N,4,4] ([R|t], zeros on failure)."""
-    global _POOL
+    """kp_px [N,8,2], bbox_3d [N,8,3], K [N,3,3] (host) -> poses [N,4,4] ([R|t], zeros on failure).
+    One batched solve for all N poses ("next" row f3: no per-sample Python loop; pnp.solve_pnp_batched)."""
     n = kp_px.shape[0]
     out = np.zeros((n, 4, 4), np.float32)
-
-    def one(i):
-        try:
-            ok, R, t = pnp.solve_pnp_iterative(bbox_3d[i], kp_px[i], K[i])
-        except Exception as e:  # noqa: BLE001  (reference: print and leave zeros, box_utils.py:192-195)
-            print(f"PnP failed due to exception: {e}")
-            return
-        if ok:
-            out[i, :3, :3] = R
-            out[i, :3, 3] = t
-            out[i, 3, 3] = 1.0
-
-    if n <= 2 or workers <= 1:
-        for i in range(n):
-            one(i)
-    else:
-        if _POOL is None:
-            _POOL = ThreadPoolExecutor(max_workers=workers)
-        list(_POOL.map(one, range(n)))
+    if n == 0:
+        return out
+    try:
+        ok, R, t = pnp.solve_pnp_batched(bbox_3d, kp_px, K)
+    except Exception as e:  # noqa: BLE001  (reference: print and leave zeros, box_utils.py:192-195)
+        print(f"PnP failed due to exception: {e}")
+        return out
+    out[ok, :3, :3] = R[ok]
+    out[ok, :3, 3] = t[ok]
+    out[ok, 3, 3] = 1.0
     return out
 
 

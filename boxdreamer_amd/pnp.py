@@ -116,3 +116,108 @@ def solve_pnp_iterative(p3: np.ndarray, p2: np.ndarray, K: np.ndarray, iters: in
         else:
             lam *= 10
     return True, rodrigues(x[:3]), x[3:]
+
+
+# ------------------------------------------------------------------------------------------------
+# Batched form ("next" row f3 of SURVEY.md §8: removes the per-sample Python loop + double OpenCV call
+# of box_utils.py:139-199).  The same algorithm as solve_pnp_iterative, vectorised over N poses with
+# batched numpy linear algebra: one SVD call for all DLT systems, Levenberg-Marquardt with per-pose
+# damping and accept / reject masks.  PARITY UNPINNED against OpenCV like the scalar form; the two forms
+# agree with each other to ~1e-9 (tests/test_host_logic.py).
+
+def _rodrigues_b(rvec: np.ndarray) -> np.ndarray:
+    th = np.linalg.norm(rvec, axis=1)
+    small = th < 1e-12
+    k = rvec / np.where(small, 1.0, th)[:, None]
+    Kx = np.zeros((rvec.shape[0], 3, 3))
+    Kx[:, 0, 1], Kx[:, 0, 2] = -k[:, 2], k[:, 1]
+    Kx[:, 1, 0], Kx[:, 1, 2] = k[:, 2], -k[:, 0]
+    Kx[:, 2, 0], Kx[:, 2, 1] = -k[:, 1], k[:, 0]
+    R = np.eye(3)[None] + np.sin(th)[:, None, None] * Kx + (1 - np.cos(th))[:, None, None] * (Kx @ Kx)
+    R[small] = np.eye(3)
+    return R
+
+
+def _project_b(x: np.ndarray, p3: np.ndarray) -> np.ndarray:
+    pc = p3 @ np.swapaxes(_rodrigues_b(x[:, :3]), 1, 2) + x[:, None, 3:]
+    return pc[..., :2] / pc[..., 2:3]
+
+
+def solve_pnp_batched(p3: np.ndarray, p2: np.ndarray, K: np.ndarray, iters: int = 30):
+    """p3 (N, n, 3), p2 (N, n, 2) pixels, K (N, 3, 3) -> (ok (N,) bool, R (N, 3, 3), t (N, 3))."""
+    p3 = np.asarray(p3, np.float64)
+    p2 = np.asarray(p2, np.float64)
+    K = np.asarray(K, np.float64)
+    N, n = p3.shape[:2]
+    if _HAVE_CV2:  # pragma: no cover - the reference's own solver when it is importable
+        ok = np.zeros(N, bool); R = np.tile(np.eye(3), (N, 1, 1)); t = np.zeros((N, 3))
+        for i in range(N):
+            ok[i], R[i], t[i] = solve_pnp_iterative(p3[i], p2[i], K[i], iters)
+        return ok, R, t
+    f = np.stack([K[:, 0, 0], K[:, 1, 1]], 1)
+    p2n = (p2 - K[:, None, :2, 2]) / f[:, None, :]
+    # ---- DLT initialisation, all poses in one SVD
+    X = np.concatenate([p3, np.ones((N, n, 1))], 2)
+    A = np.zeros((N, 2 * n, 12))
+    A[:, 0::2, 0:4] = X
+    A[:, 0::2, 8:12] = -p2n[:, :, :1] * X
+    A[:, 1::2, 4:8] = X
+    A[:, 1::2, 8:12] = -p2n[:, :, 1:2] * X
+    ok = np.isfinite(A).all(axis=(1, 2))
+    A[~ok] = 0.0
+    _, _, vt = np.linalg.svd(A)
+    P = vt[:, -1].reshape(N, 3, 4)
+    U, s, Vt = np.linalg.svd(P[:, :, :3])
+    R = U @ Vt
+    scale = s.mean(1)
+    neg = np.linalg.det(R) < 0
+    R[neg], scale[neg] = -R[neg], -scale[neg]
+    t = P[:, :, 3] / np.where(scale == 0, 1.0, scale)[:, None]
+    behind = (np.einsum("nij,nj->ni", R, p3.mean(1)) + t)[:, 2] < 0
+    R[behind], t[behind] = -R[behind], -t[behind]
+    fix = behind & (np.linalg.det(R) < 0)
+    if fix.any():
+        U2 = U[fix].copy(); U2[:, :, -1] *= -1
+        R[fix] = U2 @ Vt[fix]
+    # ---- rotation vector of R (vectorised _rvec_from_R)
+    c = np.clip((np.trace(R, axis1=1, axis2=2) - 1) / 2, -1.0, 1.0)
+    th = np.arccos(c)
+    w = np.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], 1)
+    rvec = w / (2 * np.where(np.sin(th) == 0, 1.0, np.sin(th)))[:, None] * th[:, None]
+    rvec[th < 1e-8] = 0.0
+    for i in np.nonzero(np.pi - th < 1e-4)[0]:          # near pi (rare): scalar branch
+        rvec[i] = _rvec_from_R(R[i])
+    x = np.concatenate([rvec, t], 1)
+    lam = np.full(N, 1e-3)
+    r = (_project_b(x, p3) - p2n).reshape(N, -1)
+    ok &= np.isfinite(r).all(1)
+    r[~ok] = 0.0
+    x[~ok] = 0.0; x[~ok, 5] = 1.0
+    active = ok.copy()
+    eye6 = np.eye(6)
+    for _ in range(iters):
+        if not active.any():
+            break
+        J = np.empty((N, r.shape[1], 6))
+        for j in range(6):
+            J[:, :, j] = ((_project_b(x + 1e-6 * eye6[j], p3) - p2n).reshape(N, -1) - r) / 1e-6
+        J[~np.isfinite(J)] = 0.0
+        H = np.swapaxes(J, 1, 2) @ J
+        g = np.einsum("nij,ni->nj", J, r)
+        D = np.einsum("nii->ni", H) + 1e-12
+        Hd = H + lam[:, None, None] * (D[:, :, None] * eye6[None])
+        sing = np.abs(np.linalg.det(Hd)) < 1e-300
+        Hd[sing] = eye6
+        step = np.linalg.solve(Hd, -g[:, :, None])[:, :, 0]
+        step[sing | ~active] = 0.0
+        active &= ~sing                                   # scalar form: LinAlgError -> stop iterating this pose
+        r_new = (_project_b(x + step, p3) - p2n).reshape(N, -1)
+        better = active & np.isfinite(r_new).all(1) & ((r_new * r_new).sum(1) < (r * r).sum(1))
+        x[better] += step[better]
+        r[better] = r_new[better]
+        lam = np.where(better, np.maximum(lam * 0.3, 1e-9), np.where(active, lam * 10, lam))
+        active &= ~(better & (np.linalg.norm(step, axis=1) < 1e-10))
+    Rout = _rodrigues_b(x[:, :3])
+    tout = x[:, 3:].copy()
+    Rout[~ok] = np.eye(3); tout[~ok] = 0.0
+    return ok, Rout, tout

@@ -140,6 +140,37 @@ def test_pnp_recovers_pose():
         assert ok and np.abs(R2 - R).max() < 1e-5 and np.abs(t2 - t).max() < 1e-5
 
 
+def test_pnp_batched_equals_scalar_form():
+    """one batched solve for the whole batch == the per-sample solver (noisy corners, a degenerate sample
+    with NaNs stays a failure without poisoning the others), and solve_poses_host fills [R|t] / zeros accordingly."""
+    from boxdreamer_amd.box_utils import solve_poses_host
+    rng = np.random.default_rng(1)
+    N = 24
+    box = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], float) * [0.1, 0.07, 0.05]
+    p3 = np.tile(box, (N, 1, 1))
+    K = np.tile(np.array([[600.0, 0, 112], [0, 600, 112], [0, 0, 1]]), (N, 1, 1))
+    p2 = np.zeros((N, 8, 2))
+    Rt, tt = [], []
+    for i in range(N):
+        R = pnp.rodrigues(rng.normal(size=3) * 0.9)
+        t = np.array([rng.normal() * 0.05, rng.normal() * 0.05, 0.6 + rng.random() * 0.4])
+        pc = box @ R.T + t
+        p2[i] = pc[:, :2] / pc[:, 2:3] * 600 + 112 + rng.normal(size=(8, 2)) * 0.7
+        Rt.append(R); tt.append(t)
+    p2[5, 3, 0] = np.nan
+    ok, Rb, tb = pnp.solve_pnp_batched(p3, p2, K)
+    assert not ok[5] and ok.sum() == N - 1
+    for i in range(N):
+        if i == 5:
+            continue
+        o, Rs, ts = pnp.solve_pnp_iterative(p3[i], p2[i], K[i])
+        assert o and np.abs(Rb[i] - Rs).max() < 1e-7 and np.abs(tb[i] - ts).max() < 1e-7
+        assert np.abs(Rb[i] - Rt[i]).max() < 0.05 and np.abs(tb[i] - tt[i]).max() < 0.05     # close to the true pose
+    poses = solve_poses_host(p2.astype(np.float32), p3.astype(np.float32), K.astype(np.float32))
+    assert poses.shape == (N, 4, 4) and (poses[5] == 0).all() and poses[0, 3, 3] == 1.0
+    assert np.abs(poses[0, :3, :3] - Rb[0]).max() < 1e-4
+
+
 def test_c_abi_loads_and_exports_every_declared_symbol():
     """The shared library must export exactly what include/boxdreamer_hip.h declares (no compute calls)."""
     hdr = open(os.path.join(ROOT, "include", "boxdreamer_hip.h")).read()
