@@ -144,17 +144,25 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
     const int act = p.act, rpg_in = p.rpg_in, rpg_out = p.rpg_out, row_off = p.row_off, tab_rows = p.tab_rows;
     const int64_t ldr = p.ldr, ldo = p.ldo, out_plane = p.out_plane;
     float* sc = (float*)scratch;
+    // the wave tile is flushed in column blocks of CW columns (all of it when it is 32 or 64 wide; 3 x 32 for the 96-wide
+    // wave tile of the 256 x 192 workgroup tile) so that the lanes of a pass always cover whole rows of a block
+    constexpr int CW = (NI % 2 == 0) ? 64 : 32, NCB = COLS / CW;
     if (p.out_f32 == OUT_F32) {
-        constexpr int LPR = COLS / 4;                  // lanes per row (4 floats each)
+        constexpr int LPR = CW / 4;                    // lanes per row (4 floats each)
         constexpr int RPI = 64 / LPR;                  // rows per pass
         constexpr int PASSES = 32 / RPI;
         const int c4 = lane % LPR, rsub = lane / LPR;
-        const int gc = wn0 + c4 * 4;
-        const bool cok = gc < N;
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
-        f32x4 bv4 = zero4, sv4 = one4;
-        if (bias && cok) bv4 = *(const f32x4*)(bias + gc);
-        if (wscale && cok) sv4 = *(const f32x4*)(wscale + gc);
+        f32x4 bv4[NCB], sv4[NCB];
+        bool cok[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int gc = wn0 + cb * CW + c4 * 4;
+            cok[cb] = gc < N;
+            bv4[cb] = zero4; sv4[cb] = one4;
+            if (bias && cok[cb]) bv4[cb] = *(const f32x4*)(bias + gc);
+            if (wscale && cok[cb]) sv4[cb] = *(const f32x4*)(wscale + gc);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -166,52 +174,60 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
             // float4 struct in a local array lands in scratch
             constexpr int PB = PASSES > 4 ? 4 : PASSES;
 #pragma unroll
-            for (int t0 = 0; t0 < PASSES; t0 += PB) {
-                f32x4 rv[PB], tv[PB];
-                int64_t orow[PB];
-                bool ok[PB];
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int gc = wn0 + cb * CW + c4 * 4;
 #pragma unroll
-                for (int u = 0; u < PB; ++u) {
-                    const int gr = wm0 + i * 32 + (t0 + u) * RPI + rsub;
-                    ok[u] = cok && gr < M;
-                    const int grc = gr < M ? gr : M - 1;
-                    orow[u] = rpg_in > 0 ? (int64_t)(grc / rpg_in) * rpg_out + grc % rpg_in + row_off : (int64_t)grc;
-                    rv[u] = zero4;
-                    tv[u] = zero4;
-                    if (resid && ok[u]) rv[u] = *(const f32x4*)(resid + orow[u] * ldr + gc);
-                    if (addtab && ok[u]) tv[u] = *(const f32x4*)(addtab + (int64_t)(grc % tab_rows) * N + gc);
-                }
+                for (int t0 = 0; t0 < PASSES; t0 += PB) {
+                    f32x4 rv[PB], tv[PB];
+                    int64_t orow[PB];
+                    bool ok[PB];
 #pragma unroll
-                for (int u = 0; u < PB; ++u) {
-                    f32x4 v = *(const f32x4*)(sc + ((t0 + u) * RPI + rsub) * COLS + c4 * 4) * sv4 + bv4;
-                    if (act == BD_ACT_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    for (int u = 0; u < PB; ++u) {
+                        const int gr = wm0 + i * 32 + (t0 + u) * RPI + rsub;
+                        ok[u] = cok[cb] && gr < M;
+                        const int grc = gr < M ? gr : M - 1;
+                        orow[u] = rpg_in > 0 ? (int64_t)(grc / rpg_in) * rpg_out + grc % rpg_in + row_off : (int64_t)grc;
+                        rv[u] = zero4;
+                        tv[u] = zero4;
+                        if (resid && ok[u]) rv[u] = *(const f32x4*)(resid + orow[u] * ldr + gc);
+                        if (addtab && ok[u]) tv[u] = *(const f32x4*)(addtab + (int64_t)(grc % tab_rows) * N + gc);
                     }
-                    v = v + tv[u] + rv[u];
-                    if (ok[u]) *(f32x4*)((float*)p.out + orow[u] * ldo + gc) = v;
+#pragma unroll
+                    for (int u = 0; u < PB; ++u) {
+                        f32x4 v = *(const f32x4*)(sc + ((t0 + u) * RPI + rsub) * COLS + cb * CW + c4 * 4) * sv4[cb] + bv4[cb];
+                        if (act == BD_ACT_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        }
+                        v = v + tv[u] + rv[u];
+                        if (ok[u]) *(f32x4*)((float*)p.out + orow[u] * ldo + gc) = v;
+                    }
                 }
             }
         }
     } else {
-        constexpr int LPR = COLS / 8;                  // lanes per row (8 output columns each)
+        constexpr int LPR = CW / 8;                    // lanes per row (8 output columns each)
         constexpr int RPI = 64 / LPR;
         constexpr int PASSES = 32 / RPI;
         const int c8 = lane % LPR, rsub = lane / LPR;
-        const int gc = wn0 + c8 * 8;
-        const bool cok = gc < N;
-        float bv[8], sv[8];
+        float bv[NCB][8], sv[NCB][8];
+        bool cok[NCB];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { bv[e] = 0.f; sv[e] = 1.f; }
-        if (bias && cok) {
-            const f32x4 b0 = *(const f32x4*)(bias + gc), b1 = *(const f32x4*)(bias + gc + 4);
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int gc = wn0 + cb * CW + c8 * 8;
+            cok[cb] = gc < N;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
-        }
-        if (wscale && cok) {
-            const f32x4 s0 = *(const f32x4*)(wscale + gc), s1 = *(const f32x4*)(wscale + gc + 4);
+            for (int e = 0; e < 8; ++e) { bv[cb][e] = 0.f; sv[cb][e] = 1.f; }
+            if (bias && cok[cb]) {
+                const f32x4 b0 = *(const f32x4*)(bias + gc), b1 = *(const f32x4*)(bias + gc + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { sv[e] = s0[e]; sv[4 + e] = s1[e]; }
+                for (int e = 0; e < 4; ++e) { bv[cb][e] = b0[e]; bv[cb][4 + e] = b1[e]; }
+            }
+            if (wscale && cok[cb]) {
+                const f32x4 s0 = *(const f32x4*)(wscale + gc), s1 = *(const f32x4*)(wscale + gc + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sv[cb][e] = s0[e]; sv[cb][4 + e] = s1[e]; }
+            }
         }
         const int out_mode = p.out_f32;
 #pragma unroll
@@ -222,40 +238,44 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
                 for (int r = 0; r < 16; ++r)
                     sc[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
 #pragma unroll
-            for (int t = 0; t < PASSES; ++t) {
-                const int gr = wm0 + i * 32 + t * RPI + rsub;
-                const float* src = sc + (t * RPI + rsub) * COLS + c8 * 8;
-                const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
-                float v[8];
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int gc = wn0 + cb * CW + c8 * 8;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = a0[e] * sv[e] + bv[e]; v[4 + e] = a1[e] * sv[4 + e] + bv[4 + e]; }
-                if (act == BD_ACT_GELU) gelu_n<GeluKind<T, NS>::value, 8>(v);   // 16/8-bit result: fitted forms (bd_common.h)
-                if (cok && gr < M) {
-                    const int64_t orow = rpg_in > 0 ? (int64_t)(gr / rpg_in) * rpg_out + gr % rpg_in + row_off : (int64_t)gr;
-                    if (addtab) {
-                        const float* tp = addtab + (int64_t)(gr % tab_rows) * N + gc;
+                for (int t = 0; t < PASSES; ++t) {
+                    const int gr = wm0 + i * 32 + t * RPI + rsub;
+                    const float* src = sc + (t * RPI + rsub) * COLS + cb * CW + c8 * 8;
+                    const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+                    float v[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += tp[e];
-                    }
-                    if (resid) {
-                        const float* rp = resid + orow * ldr + gc;
+                    for (int e = 0; e < 4; ++e) { v[e] = a0[e] * sv[cb][e] + bv[cb][e]; v[4 + e] = a1[e] * sv[cb][4 + e] + bv[cb][4 + e]; }
+                    if (act == BD_ACT_GELU) gelu_n<GeluKind<T, NS>::value, 8>(v);   // 16/8-bit result: fitted forms (bd_common.h)
+                    if (cok[cb] && gr < M) {
+                        const int64_t orow = rpg_in > 0 ? (int64_t)(gr / rpg_in) * rpg_out + gr % rpg_in + row_off : (int64_t)gr;
+                        if (addtab) {
+                            const float* tp = addtab + (int64_t)(gr % tab_rows) * N + gc;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += rp[e];
-                    }
-                    if (out_mode == OUT_F16) {            // f16 single plane (optional f16 attention of the strict mode)
-                        store_cvt<_Float16, 8>((_Float16*)p.out + orow * ldo + gc, v);
-                    } else if (out_mode == OUT_BF16) {    // bf16 single plane (fp8 mode: attention operands stay bf16)
-                        store_cvt<__bf16, 8>((__bf16*)p.out + orow * ldo + gc, v);
-                    } else {
-                        T* o = (T*)p.out + orow * ldo + gc;
-                        if constexpr (NS == 2) {
-                            float hi8[8], lo8[8];
+                            for (int e = 0; e < 8; ++e) v[e] += tp[e];
+                        }
+                        if (resid) {
+                            const float* rp = resid + orow * ldr + gc;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { hi8[e] = to_f32<T>(from_f32<T>(v[e])); lo8[e] = v[e] - hi8[e]; }
-                            store_cvt<T, 8>(o, hi8);
-                            store_cvt<T, 8>(o + out_plane, lo8);
+                            for (int e = 0; e < 8; ++e) v[e] += rp[e];
+                        }
+                        if (out_mode == OUT_F16) {            // f16 single plane (optional f16 attention of the strict mode)
+                            store_cvt<_Float16, 8>((_Float16*)p.out + orow * ldo + gc, v);
+                        } else if (out_mode == OUT_BF16) {    // bf16 single plane (fp8 mode: attention operands stay bf16)
+                            store_cvt<__bf16, 8>((__bf16*)p.out + orow * ldo + gc, v);
                         } else {
-                            store_cvt<T, 8>(o, v);
+                            T* o = (T*)p.out + orow * ldo + gc;
+                            if constexpr (NS == 2) {
+                                float hi8[8], lo8[8];
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { hi8[e] = to_f32<T>(from_f32<T>(v[e])); lo8[e] = v[e] - hi8[e]; }
+                                store_cvt<T, 8>(o, hi8);
+                                store_cvt<T, 8>(o + out_plane, lo8);
+                            } else {
+                                store_cvt<T, 8>(o, v);
+                            }
                         }
                     }
                 }
@@ -441,6 +461,7 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
         // two co-resident 128x128 workgroups overlap better than one 256x256 workgroup (117 vs 125 us).
         int k256 = 0;
         int64_t rows256 = 0;
+        double hybrid_cost = 1e30;
         if (impl != 2 && a.N % 256 == 0 && a.N < 1536 && a.K >= 2048 && a.rpg_in <= 0 && !a.addtab && a.M >= 1024) {
             const int tn = a.N / 256;
             const int64_t mtiles = (a.M + 255) / 256;
@@ -459,11 +480,29 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
                 const double c = k + cost128(a.M - r256);
                 if (c < best - 1e-9) { best = c; k256 = k; rows256 = r256; }
             }
+            hybrid_cost = best;
             if (gemm_split() >= 0) {
                 k256 = gemm_split();
                 const int64_t mt = (int64_t)k256 * kCUs / tn;
                 rows256 = mt * 256 < a.M ? mt * 256 : a.M;
                 if (mt == 0) k256 = 0;
+            }
+        }
+        // 256 x 192 tiles (8 waves of 64 x 96): N = 768 in 4 columns of tiles, 192 row tiles x 4 = exactly 3 rounds at
+        // M = 49152 (BETR fc2) -- whole rounds of a big tile without any row split.
+        static const int t192 = [] { const char* e = getenv("BD_GEMM_T192"); return e ? atoi(e) : 1; }();
+        bool use192 = false;
+        if (t192 && impl != 2 && a.N % 192 == 0 && a.N < 1536 && a.K >= 2048 && a.M >= 1024) {
+            const double e192 = eff(256, 192, kCUs, 0.93);
+            const double ehyb = k256 > 0 ? (double)((a.M + 255) / 256) * (a.N / 256) / kCUs / hybrid_cost : e128;
+            use192 = e192 > ehyb && e192 > e128;
+        }
+        if constexpr (NS == 1) {
+            if (use192) {
+                launch_glds<T, NS, BK, 4, 2, 2, 3>(a, s);         // 256 x 192, 1 workgroup / CU
+                bd_trace_close(s, slot);
+                BD_CHECK_LAUNCH();
+                return BD_OK;
             }
         }
         if (k256 > 0) {
