@@ -269,6 +269,9 @@ def main():
         if os.path.exists(tpath) and prec == "bf16" and B == 32 and T == 6:
             tj = json.load(open(tpath))
             traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
+            if tj.get("steps_profiled") and g:      # per kernel launch -> per bd_gemm call (the unit of `achieved`)
+                calls_per_step = len(g) / (TRACE_STEPS if graphed is not None else args.steps)
+                traffic = round(tj["hbm_bytes_per_launch"] * tj["launches"] / tj["steps_profiled"] / calls_per_step)
         roofline = {"bound": "mfma", "kernel": "gemm_kernel_glds (256x256 / 128x128 tiles, LDS-DMA operands, v_mfma_f32_32x32x16)",
                     "achieved": round(gemm_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tf / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src,
