@@ -317,7 +317,21 @@ def main():
                 tp.append(time.perf_counter() - t1)
             pnp_ms = sorted(tp)[1] * 1e3
             step_ms = dt / args.steps * 1e3
+            # the same solve as a HIP kernel (one pose per thread, fp64): corners stay on the device
+            from boxdreamer_amd.box_utils import solve_poses_device
+            b3d, Kd = torch.from_numpy(b3).to(device), torch.from_numpy(Kq).to(device)
+            for _ in range(2):
+                solve_poses_device(out[:B], b3d, Kd)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                solve_poses_device(out[:B], b3d, Kd)
+            torch.cuda.synchronize()
+            gpu_pnp_ms = (time.perf_counter() - t1) / 5 * 1e3
             line["pnp_inclusive"] = {"pnp_ms_per_batch": round(pnp_ms, 2), "host": "numpy batched DLT + LM, 1 thread, parity vs OpenCV un-pinned",
+                                     "gpu_pnp_ms_per_batch": round(gpu_pnp_ms, 2),
+                                     "gpu_pnp_serialised_poses_per_s": round(B * world / ((step_ms + gpu_pnp_ms) / 1e3), 1),
+                                     "gpu_pnp": "bd_solve_pnp, 1 pose per thread fp64, same stream (random-weight corners: LM runs all 30 iterations)",
                                      "serialised_poses_per_s": round(B * world / ((step_ms + pnp_ms) / 1e3), 1),
                                      "overlapped_poses_per_s": round(min(value, B * world / (pnp_ms / 1e3)), 1)}
         if not args.no_parity:

@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import hip_ops, pnp
+from . import _lib, hip_ops, pnp
 
 
 
@@ -46,6 +46,21 @@ def solve_poses_host(kp_px: np.ndarray, bbox_3d: np.ndarray, K: np.ndarray, work
     out[ok, :3, :3] = R[ok]
     out[ok, :3, 3] = t[ok]
     out[ok, 3, 3] = 1.0
+    return out
+
+
+def solve_poses_device(kp_px: torch.Tensor, bbox_3d: torch.Tensor, K: torch.Tensor, iters: int = 30) -> torch.Tensor:
+    """kp_px [N,n,2], bbox_3d [N,n,3], K [N,3,3] on the GPU -> poses [N,4,4] on the GPU ([R|t], zeros on failure):
+    `bd_solve_pnp`, one pose per thread in fp64 -- the corners never leave the device ("next" row f3)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    kp = kp_px.float().contiguous()
+    p3 = bbox_3d.to(kp.device).float().contiguous()
+    Kd = K.to(kp.device).float().contiguous()
+    n, npts = kp.shape[0], kp.shape[1]
+    out = torch.empty((n, 4, 4), dtype=torch.float32, device=kp.device)
+    _lib.check(lib.bd_solve_pnp(_lib.ptr(kp), _lib.ptr(p3), _lib.ptr(Kd), n, npts, iters, _lib.ptr(out), _lib.stream()),
+               "bd_solve_pnp")
     return out
 
 

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJDIR = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libboxdreamer_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "layout.hip", "decode.hip", "match.hip", "forward.hip", "trace.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "layout.hip", "decode.hip", "match.hip", "pnp.hip", "forward.hip", "trace.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 
 

@@ -11,7 +11,8 @@ import torch
 import torch.nn as nn
 
 from .betr import BETR
-from .box_utils import recover_bb8_corners_chw, solve_poses_host
+from . import pnp
+from .box_utils import recover_bb8_corners_chw, solve_poses_device, solve_poses_host
 from .cache import merge_cached_features
 from .config import setup_camera_params, validate_model_config
 from .dense import process_dense_input, process_multi_round
@@ -120,8 +121,11 @@ class BoxDreamer(nn.Module):
         norm_kp, kp_px, _ = recover_bb8_corners_chw(query_ret)                  # [B,8,2] each
         bbox_3d = data["bbox_3d"][camera_mask].float()
         K = data["non_ndc_intrinsics"][camera_mask].float()
-        poses = solve_poses_host(kp_px.cpu().numpy(), bbox_3d.cpu().numpy(), K.cpu().numpy())
-        pred_poses[camera_mask] = torch.from_numpy(poses).to(pred_poses.device).to(pred_poses.dtype)
+        if pnp._HAVE_CV2:    # the reference's own solver, on the host (one D2H of the corners per batch)
+            poses = torch.from_numpy(solve_poses_host(kp_px.cpu().numpy(), bbox_3d.cpu().numpy(), K.cpu().numpy()))
+        else:                # same published algorithm on the GPU, no host round trip (row f3)
+            poses = solve_poses_device(kp_px, bbox_3d, K)
+        pred_poses[camera_mask] = poses.to(pred_poses.device).to(pred_poses.dtype)
         data["regression_boxes"] = data["bbox_proj_crop"].clone()
         data["regression_boxes"][camera_mask] = norm_kp.to(data["regression_boxes"].dtype)
         data["pred_corners_px"] = kp_px

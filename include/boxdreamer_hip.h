@@ -165,6 +165,14 @@ int bd_decode_topk(const float* heat, int n_maps, int height, int width, int k, 
 int bd_render_corner_heatmaps(const float* corners, int n_groups, int group, int height, int width,
                               void* out, int out_dtype, void* stream);
 
+/* Pose from decoded corners on the GPU ("next" row f3): DLT + Levenberg-Marquardt PnP, one pose per thread in fp64,
+ * the algorithm of cv2.solvePnP(SOLVEPNP_ITERATIVE) for non-planar points as restated in boxdreamer_amd/pnp.py
+ * (replaces the per-sample host loop of src/models/utils/box_utils.py:139-199).  kp_px: fp32 [n_poses, n_points, 2] pixel
+ * coordinates; pts3: fp32 [n_poses, n_points, 3]; K: fp32 [n_poses, 3, 3]; poses: fp32 [n_poses, 4, 4] = [R|t; 0 0 0 1],
+ * all zeros where the solve fails.  6 <= n_points <= 64. */
+int bd_solve_pnp(const float* kp_px, const float* pts3, const float* K, int n_poses, int n_points, int iters,
+                 float* poses, void* stream);
+
 /* Dense-reference mode ("next" row f4): DINO-feature reference selection, src/models/utils/matching.py:64-174
  * (`dino_matching`, called from process_dense_input, src/models/utils/data_processing.py:179-225).
  * feats: fp32 [B, T, L, D] patch features of every view (the encoder output); images: [B, T, 3, H, W] RGB crops in [0, 1]

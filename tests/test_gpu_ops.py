@@ -303,3 +303,35 @@ def test_layernorm_and_layout_fp8(hip):
     hmap = hip_ops.patchify_heatmaps(data["bbox_feat"][0].cuda(), kpad=1664, prec="fp8").float().cpu()
     refp = orc.patchify(data["bbox_feat"][0], 14, 8).reshape(512, 1568)
     assert torch.equal(hmap[:, 1568:], torch.zeros(512, 96)) and ((hmap[:, :1568] - refp).abs() <= refp.abs() * 2.0 ** -4 + 2.0 ** -10).all()
+
+
+# ----------------------------------------------------------------------------- GPU PnP
+
+@pytest.mark.parametrize("npts", [8, 24])
+def test_gpu_pnp_matches_host_form(hip, npts):
+    """bd_solve_pnp (one pose per thread, fp64) follows boxdreamer_amd/pnp.py step by step: same poses as the batched numpy
+    form on noisy corners, the true pose on exact corners, zeros for a sample with a NaN corner."""
+    from boxdreamer_amd import pnp
+    from boxdreamer_amd.box_utils import solve_poses_device
+    rng = np.random.default_rng(3)
+    N = 40
+    box = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], float) * [0.1, 0.07, 0.05]
+    p3 = np.tile(np.tile(box, (npts // 8, 1)), (N, 1, 1))
+    K = np.tile(np.array([[600.0, 0, 112], [0, 600, 112], [0, 0, 1]]), (N, 1, 1))
+    Rt = pnp._rodrigues_b(rng.normal(size=(N, 3)) * 0.9)
+    tt = np.stack([rng.normal(size=N) * 0.05, rng.normal(size=N) * 0.05, 0.6 + rng.random(N) * 0.4], 1)
+    pc = p3 @ np.swapaxes(Rt, 1, 2) + tt[:, None]
+    exact = pc[..., :2] / pc[..., 2:] * 600 + 112
+    noisy = exact + rng.normal(size=exact.shape) * 0.7
+    noisy[7, 3, 0] = np.nan
+    f32 = lambda a: torch.from_numpy(a.astype(np.float32)).cuda()
+    got = solve_poses_device(f32(noisy), f32(p3), f32(K)).cpu().numpy()
+    ok, Rb, tb = pnp.solve_pnp_batched(p3.astype(np.float32), noisy.astype(np.float32), K.astype(np.float32))
+    assert not ok[7] and (got[7] == 0).all()
+    for i in range(N):
+        if i == 7:
+            continue
+        assert np.abs(got[i, :3, :3] - Rb[i]).max() < 1e-4 and np.abs(got[i, :3, 3] - tb[i]).max() < 1e-4, i
+        assert got[i, 3, 3] == 1.0
+    got = solve_poses_device(f32(exact), f32(p3), f32(K)).cpu().numpy()
+    assert np.abs(got[:, :3, :3] - Rt).max() < 1e-4 and np.abs(got[:, :3, 3] - tt).max() < 1e-4
