@@ -11,7 +11,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libboxdreamer_hip.so")
+LIB_PATH = os.environ.get("BOXDREAMER_HIP_LIB") or os.path.join(HERE, "libboxdreamer_hip.so")   # env: deploy / A-B a build
 
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 PREC_BF16, PREC_F16, PREC_BF16X3, PREC_F16_OUT_BF16X3, PREC_FP8, PREC_BF16_OUT_FP8 = 0, 1, 2, 3, 4, 5

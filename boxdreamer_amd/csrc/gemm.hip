@@ -24,6 +24,7 @@
 // behind the choices: profiles/r1_gemm_experiments.md, profiles/r1_gemm_pmc.md.
 #include <stdlib.h>
 
+#define BD_STORE_NT 1   // non-temporal 16/8-bit epilogue stores (bd_common.h: store_cvt)
 #include "bd_common.h"
 
 namespace {

@@ -23,12 +23,12 @@ int bd_trace_open(hipStream_t s, int kind, int M, int N, int K) {
     if (g_count < 0 || g_count >= (int)g_slots.size() || capturing(s)) return -1;
     Slot& sl = g_slots[g_count];
     sl.kind = kind; sl.M = M; sl.N = N; sl.K = K;
-    hipEventRecord(sl.e0, s);
+    (void)hipEventRecord(sl.e0, s);
     return g_count++;
 }
 
 void bd_trace_close(hipStream_t s, int slot) {
-    if (slot >= 0) hipEventRecord(g_slots[slot].e1, s);
+    if (slot >= 0) (void)hipEventRecord(g_slots[slot].e1, s);
 }
 
 extern "C" int bd_trace_begin(int capacity) {
@@ -51,9 +51,9 @@ extern "C" int bd_trace_end(bd_trace_record* out, int capacity) {
     g_count = -1;
     for (int i = 0; i < n; ++i) {
         Slot& sl = g_slots[i];
-        hipEventSynchronize(sl.e1);
+        (void)hipEventSynchronize(sl.e1);
         float ms = 0.f;
-        hipEventElapsedTime(&ms, sl.e0, sl.e1);
+        (void)hipEventElapsedTime(&ms, sl.e0, sl.e1);
         if (out) { out[i].kind = sl.kind; out[i].M = sl.M; out[i].N = sl.N; out[i].K = sl.K; out[i].ms = ms; }
     }
     return n;
