@@ -60,6 +60,7 @@ __device__ __forceinline__ void tile_coords_t(int M, int N, int group_m, int& m0
 __device__ __forceinline__ void glds16(const unsigned char* g, unsigned lds_off) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_off) : "memory");
 }
+
 __device__ __forceinline__ void slab_barrier() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces (and earlier stores) have landed
     __builtin_amdgcn_s_barrier();                         // ... and everyone else's; the other buffer is free
