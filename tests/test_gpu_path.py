@@ -126,7 +126,7 @@ def test_query_view_position(hip):
     assert (dec.last_logits.cpu() - o["logits"]).abs().max().item() <= 1e-3
 
 
-@pytest.mark.parametrize("size,T,B", [(112, 3, 2), (84, 2, 1), (224, 2, 3)])
+@pytest.mark.parametrize("size,T,B", [(112, 3, 2), (84, 2, 1), (224, 2, 3), (98, 5, 3), (56, 1, 2), (224, 1, 1)])
 def test_other_crop_sizes_and_view_counts(hip, size, T, B):
     """img_size is a config value in the reference (configs/model/transformer.yaml:46); any multiple of 14 works:
     grid = size/14, DINO sequence = grid^2 + 5 (ragged tail tiles), BETR sequence = T * grid^2, decode over size^2."""
