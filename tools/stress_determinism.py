@@ -1,0 +1,30 @@
+"""Race screen: the full-size step (B=32, T=6, full depth) repeated N times must give bit-identical logits every time
+(LDS-DMA / barrier schedules: a RAW race shows up as rare differing tiles)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from boxdreamer_amd import synth
+from boxdreamer_amd.betr import BETR
+from boxdreamer_amd.encoder import DinoV2Wrapper
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+enc = DinoV2Wrapper(None, {"model_type": "dinov2_vitb14_reg", "synthetic_seed": 4321, "depth": 12, "hip_precision": prec})
+dec = BETR(d_model=768, nhead=8, num_decoder_layers=12, decoder_only=True, patch_size=14, img_size=224, diff_emb=False,
+           nvs_supervision=False, ray_supervision=True, use_mask=False, use_pretrained=True, patchify_rays=True,
+           pose_representation="bb8", bbox_representation="heatmap", hip_precision=prec)
+dec.load_state_dict(synth.betr_state_dict(1234, 12), strict=True); dec = dec.cuda().eval()
+small = synth.make_batch(seed=41, B=4, T=6)
+img = small["images"].repeat(8, 1, 1, 1, 1).to(torch.bfloat16).cuda()
+bf = small["bbox_feat"].repeat(8, 1, 1, 1, 1).to(torch.bfloat16).cuda()
+mask = torch.zeros(32, 6, dtype=torch.bool, device="cuda"); mask[:, 5] = True
+ref = None
+bad = 0
+for i in range(n):
+    dec(bf, img, mask, enc.predict(img), None)
+    l = dec.last_logits.clone()
+    if ref is None:
+        ref = l
+    elif not torch.equal(ref, l):
+        bad += 1
+        print("run", i, "differs: max", (ref - l).abs().max().item(), "count", int((ref != l).sum()))
+print(f"{prec}: {n} runs, {bad} differing")
