@@ -287,7 +287,7 @@ def main():
                     "attention_time_frac_of_step": round(sum(ms for _, ms in a) / traced_ms, 4),
                     "whole_path_achieved": round(value / world * fpp / 1e12, 2),
                     "whole_path_frac": round(value / world * fpp / 1e12 / peak, 4)}
-        metric = "poses/s (5-ref, 224x224, bf16 operands); heatmap max-abs err vs CPU ref"
+        metric = "poses/s/GPU (5-ref, 224×224, bf16); heatmap max-abs err vs CPU ref"     # BASELINE.json's metric string
         if args.cache_refs:
             metric = "poses/s with reference features cached across queries (SURVEY 8f1; encoder on the query crop only)"
         line = {"metric": metric,
@@ -300,6 +300,7 @@ def main():
                            "global_batch": B * world, "views": T, "parallelism": f"dp{world}", "streams_per_gpu": nstream, "hip_graph": bool(args.graph),
                            "gflop_per_pose": round(fpp / 1e9, 2)},
                 "poses_per_s_per_gpu": round(value / world, 2),
+                "value_is": "whole-job aggregate over n_gpus (bench contract); the per-GPU figure of the metric is poses_per_s_per_gpu",
                 "roofline": roofline}
         if not args.no_pnp:
             # PnP-inclusive rate (SURVEY 8d asks for it next to `value`, never as `value`): one D2H of the decoded corners
