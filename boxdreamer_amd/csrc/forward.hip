@@ -47,17 +47,21 @@ inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const
 // f16 MFMA pass (the x3 QKV GEMM stores q, k, v as a single f16 plane, q/k RMSNorm and attention run in f16, attention
 // writes (hi, lo) bf16 planes for the x3 proj GEMM).  Measured at full depth: 513 vs 425 poses/s, but 1.18e-3 vs 7.2e-5
 // logit error -- the f16 Q.K^T on DINOv2's un-normalised q/k eats the whole 1e-3 budget -- so it is NOT the default.
-inline bool x3_f16_attention() {
-    static const bool on = [] { const char* e = getenv("BD_X3_ATTN"); return e && e[0] == 'f'; }();
-    return on;
+// BD_X3_ATTN=betr: the same, but only where q and k are RMS-normalised (BETR); DINOv2's attention stays split-bf16.
+inline int x3_attention_mode() {
+    // default: "betr" (measured 1.3e-4 on the logits, 542 vs 501 poses/s); "x3" = split-bf16 attention everywhere (8.2e-5);
+    // "f16" = f16 attention everywhere (1.18e-3: misses the bar because of DINOv2's un-normalised q.k)
+    static const int m = [] { const char* e = getenv("BD_X3_ATTN"); return !e ? 2 : (e[0] == 'f' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
+    return m;
 }
+inline bool x3_f16_attention(bool qk_normed) { return x3_attention_mode() == 1 || (x3_attention_mode() == 2 && qk_normed); }
 
 // One pre-LN transformer block: x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x))).
 // BETR: blocks.py:876-886 (+ q/k RMSNorm :257); DINOv2: layers/block.py:89-114 (LayerScale folded).
 int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, int seq, int D, int heads,
               float ln_eps, float rms_eps, int prec, void* stream) {
     const int hd = D / heads;
-    const bool hyb = prec == BD_PREC_BF16X3 && x3_f16_attention();
+    const bool hyb = prec == BD_PREC_BF16X3 && x3_f16_attention(w.q_norm_w != nullptr);
     const bool f8 = prec == BD_PREC_FP8;      // e4m3 Linears, bf16 attention
     const int aprec_in = hyb ? BD_PREC_F16 : (f8 ? BD_PREC_BF16 : prec);
     const int aprec = hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec);
@@ -94,7 +98,7 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
 int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, float* xc, const int32_t* query_idx, int B,
                               int T, int P, int D, int heads, float ln_eps, float rms_eps, int prec, void* stream) {
     const int hd = D / heads, M = B * T * P, Mq = B * P;
-    const bool hyb = prec == BD_PREC_BF16X3 && x3_f16_attention();
+    const bool hyb = prec == BD_PREC_BF16X3 && x3_f16_attention(w.q_norm_w != nullptr);
     const bool f8 = prec == BD_PREC_FP8;      // e4m3 Linears, bf16 attention
     const int aprec_in = hyb ? BD_PREC_F16 : (f8 ? BD_PREC_BF16 : prec);
     const int aprec = hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec);
