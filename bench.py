@@ -1,22 +1,32 @@
 #!/usr/bin/env python
 """bench.py -- poses/s of the corner-heatmap inference path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--prec bf16|fp16|bf16x3] [--batch B] [--views T]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--prec bf16|fp16|bf16x3|fp8] [--batch B] [--views T]
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
 DINOv2 ViT-B/14-reg encoder on all B*T crops -> BETR decoder -> corner decode (top-20 mean), plus for
 N > 1 the RCCL all-gather of predicted corners.  Default workload = BASELINE.json configs[1]:
-1 query + 5 refs, 224x224, batch 32 per GPU.  One process per GPU (torch.distributed.run), batch
-sharded across ranks (independent samples -> weak scaling, no data-path collective besides the
-corner gather).  Prints ONE JSON line on rank 0.
+1 query + 5 refs, 224x224, batch 32 per GPU.  One process per GPU, batch sharded across ranks
+(independent samples -> weak scaling, no data-path collective besides the corner gather).
+
+Launch: `python bench.py --gpus N` with no torch.distributed environment re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, backend "nccl" = RCCL); started
+by torch.distributed.run directly (the driver's form) it reads RANK / LOCAL_RANK / WORLD_SIZE and
+asserts WORLD_SIZE == --gpus.  `--backend gloo --cpu-plumbing` runs ONLY the launcher / barrier /
+gather plumbing on CPU (tests/test_bench_launcher.py) -- the data path itself has no CPU form.
+
+Rank 0 prints ONE JSON line.  `value` is the headline mode (--prec, default bf16 = BASELINE.json's metric); the same
+invocation also times the STRICT mode (the mode that meets north_star's 1e-3 heatmap-logit tolerance) and reports it
+under `strict`, each with its own roofline and parity block.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 
 import torch
@@ -25,9 +35,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense, no sparsity)
-PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0, "fp8": 5000.0}   # fp8 = MX-scaled dense peak
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0, "bf16x3_attn_x3": 2500.0, "fp8": 5000.0}
 PEAK_HBM_GBS = 8000.0
 DINO_FLOP_PER_IMAGE = 47_078_313_984          # BASELINE.md §4 / SURVEY.md §8(d)
+STRICT_PREC = "bf16x3"                          # the mode whose logits meet the 1e-3 bar
+DTYPE_LABEL = {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3", "bf16x3_attn_x3": "bf16x3",
+               "fp8": "fp8-e4m3 (Linears) + bf16 (attention)"}
+MFMA_PASSES = {"bf16x3": 3.0, "bf16x3_attn_x3": 3.0}
 
 
 def betr_flops(T: int) -> int:
@@ -49,6 +63,7 @@ def build_models(prec, device):
                diff_emb=False, nvs_supervision=False, ray_supervision=True, use_mask=False, use_pretrained=True,
                patchify_rays=True, pose_representation="bb8", bbox_representation="heatmap", hip_precision=prec)
     dec.load_state_dict(synth.betr_state_dict(seed=1234, depth=12), strict=True)
+    dec.validate_inputs = False         # the one-hot mask check is a device sync per forward: not inside a timed step
     return enc, dec.to(device).eval()
 
 
@@ -65,45 +80,390 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
-def cpu_baseline(T: int, budget_s: float = 20.0) -> dict:
-    """The oracle (CPU restatement of the reference arithmetic, torch fp32) timed on this box's host cores on a
-    bounded sample of the same workload: single poses (B=1) with T views, full depth."""
+def cpu_baseline(T: int, budget_s: float = 24.0) -> dict:
+    """SURVEY §8d protocol: the oracle (CPU restatement of the reference arithmetic) on this box's host cores, same seeded
+    inputs/weights as the GPU parity probe, 2 warm-up + median of >= 5 timed single-pose forwards, fp32 (primary, `value`)
+    and CPU bf16-autocast (secondary: the reference's own `precision: bf16` on a CPU).  Bounded to ~budget_s."""
     from boxdreamer_amd import synth
     from oracle import boxdreamer_oracle as orc
     cores = usable_cpus()
     torch.set_num_threads(cores)
     bsd, dsd = synth.betr_state_dict(1234, 12), synth.dino_state_dict(4321, 12)
     data = synth.make_batch(seed=11, B=1, T=T)
-    with torch.no_grad():
-        orc.boxdreamer_forward(data, bsd, dsd)          # warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
-            orc.boxdreamer_forward(data, bsd, dsd)
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt > budget_s or n >= 64:
-                break
-    return {"value": n / dt, "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} single-pose forwards (B=1, T={T}, 224x224, fp32, full depth) of oracle/boxdreamer_oracle.py "
-                      f"in {dt:.1f}s, torch {torch.__version__} CPU"}
+
+    def leg(autocast: bool, budget: float):
+        ts = []
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            t_begin = time.perf_counter()
+            for i in range(2 + 64):
+                t0 = time.perf_counter()
+                orc.boxdreamer_forward(data, bsd, dsd)
+                if i >= 2:
+                    ts.append(time.perf_counter() - t0)
+                if len(ts) >= 5 and time.perf_counter() - t_begin > budget:
+                    break
+                if len(ts) >= 9:
+                    break
+        return statistics.median(ts), len(ts)
+
+    m32, n32 = leg(False, budget_s * 0.6)
+    m16, n16 = leg(True, budget_s * 0.4)
+    return {"value": round(1.0 / m32, 3), "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
+            "bf16_autocast_value": round(1.0 / m16, 3),
+            "sample": f"single-pose forwards (B=1, T={T}, 224x224, full depth) of oracle/boxdreamer_oracle.py: 2 warm-up + "
+                      f"median of {n32} (fp32) / {n16} (CPU bf16 autocast) timed runs, torch {torch.__version__} CPU, "
+                      f"{torch.get_num_threads()} threads"}
 
 
-def parity_probe(prec, T: int, device) -> dict:
-    """Max-abs error of the heatmap logits vs the CPU oracle on one full-depth pose (outside the timed region)."""
+def parity_probe(prec, T: int, device, models=None) -> dict:
+    """Max-abs error of the heatmap logits vs the CPU oracle on full-depth poses (outside the timed region): B = 2 samples
+    with different inputs, the same weights as the timed step."""
     from boxdreamer_amd import hip_ops, synth
     from oracle import boxdreamer_oracle as orc
-    enc, dec = build_models(prec, device)
-    data = synth.make_batch(seed=11, B=1, T=T)
-    mask = torch.zeros(1, T, dtype=torch.bool); mask[0, T - 1] = True
+    enc, dec = models if models is not None else build_models(prec, device)
+    B = 2
+    data = synth.make_batch(seed=11, B=B, T=T)
+    mask = torch.zeros(B, T, dtype=torch.bool); mask[:, T - 1] = True
     img, bf = data["images"].to(device), data["bbox_feat"].to(device)
     heat = dec(bf, img, mask.to(device), enc.predict(img), None)
-    _, _, idx = hip_ops.decode_topk(heat)
+    kp, _, idx = hip_ops.decode_topk(heat)
     with torch.no_grad():
         o = orc.boxdreamer_forward(data, synth.betr_state_dict(1234, 12), synth.dino_state_dict(4321, 12))
     same = (idx.cpu().long().sort(-1)[0] == o["topk_idx"].sort(-1)[0]).all(-1).float().mean().item()
     return {"mode": prec, "logits_max_abs_err": float((dec.last_logits.cpu() - o["logits"]).abs().max()),
             "heat_max_abs_err": float((heat.cpu() - o["heat"]).abs().max()),
-            "top20_sets_equal_frac": same, "case": f"B=1,T={T} full depth vs CPU oracle (fp32)"}
+            "top20_sets_equal_frac": same,
+            "corner_px_max_err": float((kp.cpu() - o["corners_px"]).abs().max()),
+            "tolerance": 1e-3, "meets_tolerance": bool((dec.last_logits.cpu() - o["logits"]).abs().max() <= 1e-3),
+            "case": f"B={B},T={T} full depth vs CPU oracle (fp32), random-init weights"}
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+
+def dist_env():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def maybe_respawn(args) -> None:
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: become the launcher."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    port = str(29400 + os.getpid() % 1000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__), *sys.argv[1:]]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver (RCCL needs it)
+    os.execvp(cmd[0], cmd)
+
+
+def init_dist(args):
+    """Returns (world, rank, local_rank, dist-or-None).  World size must equal --gpus."""
+    world, rank, local_rank = dist_env()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; launch with "
+                         f"`python bench.py --gpus {world}` (it spawns the ranks itself) or matching torchrun arguments")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    return world, rank, local_rank, dist
+
+
+def timed_steps(step, steps: int, warmup: int, world: int, dist, sync, device=None):
+    """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize pairs; returns (max-over-ranks seconds,
+    per-rank seconds list on rank 0, last output)."""
+    out = None
+    for _ in range(warmup):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    per_rank = [dt]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(g.item()) for g in gathered]
+        dt = max(per_rank)
+    return dt, per_rank, out
+
+
+def cpu_plumbing(args) -> None:
+    """Launcher / barrier / corner-gather plumbing on CPU (gloo).  NOT the data path: the corners are a fixed pattern."""
+    from boxdreamer_amd.dist import gather_corners
+    world, rank, _, dist = init_dist(args)
+    B = args.batch
+    kp = (torch.arange(B * 16, dtype=torch.float32).reshape(B, 8, 2) + 1000.0 * rank)
+
+    def step():
+        return gather_corners(kp, world) if world > 1 else kp
+    dt, per_rank, out = timed_steps(step, args.steps, args.warmup, world, dist, lambda: None)
+    ok = all(torch.equal(out[r * B:(r + 1) * B], torch.arange(B * 16, dtype=torch.float32).reshape(B, 8, 2) + 1000.0 * r)
+             for r in range(world))
+    if rank == 0:
+        print(json.dumps({"plumbing_only": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "backend": args.backend, "gathered_rows": int(out.shape[0]), "gather_ok": bool(ok),
+                          "per_rank_ms_per_step": [round(t / args.steps * 1e3, 4) for t in per_rank]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ one precision mode
+
+class ModeRun:
+    """Everything needed to time one precision mode on this rank: models, resident inputs, the (graphed) step."""
+
+    def __init__(self, prec, args, device, world, rank, dist, images, bbox, mask):
+        from boxdreamer_amd import hip_ops
+        from boxdreamer_amd.dist import gather_corners
+        self.prec, self.args, self.device, self.world, self.rank, self.dist = prec, args, device, world, rank, dist
+        self.images, self.bbox, self.mask = images, bbox, mask
+        self.hip_ops, self.gather = hip_ops, gather_corners
+        self.enc, self.dec = build_models(prec, device)
+        self.B, self.T = images.shape[:2]
+        self.kp_all = torch.empty((self.B, 8, 2), dtype=torch.float32, device=device)
+        self.graphed = None
+        self.cached = None
+        if args.cache_refs:
+            from boxdreamer_amd.cache import RefFeatureCache
+            cache = RefFeatureCache(self.enc)
+            qidx = torch.full((self.B,), self.T - 1, dtype=torch.long, device=device)
+            self.cached = cache.place(cache.encode(images[:, : self.T - 1]), qidx, self.T)
+        use_graph = args.graph if args.graph is not None else not args.cache_refs
+        if use_graph:
+            if args.cache_refs:
+                raise SystemExit("--graph is wired for the plain step (not --cache-refs)")
+            from boxdreamer_amd.graph import GraphedPath
+            self.graphed = GraphedPath(self.enc, self.dec, self.B, self.T, 224, torch.bfloat16, device)
+            self.graphed.set_inputs(images, bbox)
+
+    def eager(self):
+        if self.cached is not None:
+            from boxdreamer_amd.cache import merge_cached_features
+            feats = merge_cached_features(self.enc, self.images, self.cached[0], self.cached[1])
+        else:
+            feats = self.enc.predict(self.images)
+        heat = self.dec(self.bbox, self.images, self.mask, feats, None)
+        kp, _, _ = self.hip_ops.decode_topk(heat, want_idx=False)
+        self.kp_all.copy_(kp)
+        return self.kp_all
+
+    def step(self):
+        kp = self.graphed.replay()[1] if self.graphed is not None else self.eager()
+        return self.gather(kp, self.world) if self.world > 1 else kp
+
+    def close(self):
+        self.graphed = None          # lifts the modules' freeze (graph.py) and releases the capture pool
+
+
+def trace_launches(lib, _lib, run_once, n_runs: int, cap: int = 8192):
+    """HIP events on the launch stream around every GEMM / attention launch of `n_runs` un-graphed executions."""
+    _lib.check(lib.bd_trace_begin(cap), "bd_trace_begin")
+    t1 = time.perf_counter()
+    for _ in range(n_runs):
+        run_once()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t1) * 1e3
+    buf = (_lib.TraceRecord * cap)()
+    n = lib.bd_trace_end(buf, cap)
+    return [(buf[i].kind, buf[i].M, buf[i].N, buf[i].K, buf[i].ms) for i in range(n)], wall_ms
+
+
+def gather_latency_ms(kp, world, dist, gather, reps: int = 50) -> float:
+    """Mean latency of the corner all-gather alone (the only collective of the sweep), barrier-aligned."""
+    for _ in range(5):
+        gather(kp, world)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gather(kp, world)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, traffic):
+    peak = PEAK_MFMA_TFLOPS[prec]
+    g = [(2.0 * m * n * k, ms) for kind, m, n, k, ms in recs if kind == 0]
+    a = [(4.0 * m * n * n * k, ms) for kind, m, n, k, ms in recs if kind == 1]   # 4*S^2*d per (batch*head)
+    gemm_tf = sum(f for f, _ in g) / max(sum(ms for _, ms in g), 1e-9) / 1e9 if g else 0.0
+    attn_tf = sum(f for f, _ in a) / max(sum(ms for _, ms in a), 1e-9) / 1e9 if a else 0.0
+    r = {"bound": "mfma", "kernel": "gemm_kernel_glds (256x256 / 256x192 / 128x128 tiles, LDS-DMA operands, v_mfma_f32_32x32x16)",
+         "achieved": round(gemm_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tf / peak, 4),
+         "traffic": traffic[0], "traffic_source": traffic[1],
+         "algorithmic_flops_per_launch": round(sum(f for f, _ in g) / max(len(g), 1)), "launches": len(g),
+         "events": f"HIP events (launch stream) around every GEMM / attention launch of {trace_runs} un-graphed executions of "
+                   "the step on the same buffers right after the timed region (events cannot be timed inside a captured graph)",
+         "avg_launch_ms": round(sum(ms for _, ms in g) / max(len(g), 1), 4),
+         "mfma_passes_per_algorithmic_flop": MFMA_PASSES.get(prec, 1.0),
+         "attention_achieved": round(attn_tf, 2),
+         "attention_avg_launch_ms": round(sum(ms for _, ms in a) / max(len(a), 1), 4),
+         # kernel time per step (event-timed, un-graphed) over the TIMED step time (graph replay)
+         "gemm_time_frac_of_step": round(sum(ms for _, ms in g) / trace_runs / ms_per_step, 4),
+         "attention_time_frac_of_step": round(sum(ms for _, ms in a) / trace_runs / ms_per_step, 4),
+         "whole_path_achieved": round(value_per_gpu * fpp / 1e12, 2),
+         "whole_path_frac": round(value_per_gpu * fpp / 1e12 / peak, 4)}
+    return r
+
+
+def measure_mode(prec, args, device, world, rank, dist, images, bbox, mask, with_traffic: bool):
+    from boxdreamer_amd import _lib
+    lib = _lib.load()
+    run = ModeRun(prec, args, device, world, rank, dist, images, bbox, mask)
+    dt, per_rank, out = timed_steps(run.step, args.steps, args.warmup, world, dist, torch.cuda.synchronize, device)
+    B, T = run.B, run.T
+    assert out.shape[0] == B * world and torch.isfinite(out).all()
+    res = {"dt": dt, "per_rank": per_rank, "out": out, "run": run}
+    if rank == 0:
+        TRACE = 3
+        recs, _ = trace_launches(lib, _lib, run.eager, TRACE)
+        value = B * world * args.steps / dt
+        fpp = flops_per_pose(T) if not args.cache_refs else DINO_FLOP_PER_IMAGE + betr_flops(T)
+        traffic = (None, None)
+        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+        if with_traffic and os.path.exists(tpath) and prec == "bf16" and B == 32 and T == 6 and not args.cache_refs:
+            tj = json.load(open(tpath))
+            nb = tj["hbm_bytes_per_launch"]
+            g_calls = sum(1 for r in recs if r[0] == 0) / TRACE
+            if tj.get("steps_profiled") and g_calls:      # per kernel launch -> per bd_gemm call (the unit of `achieved`)
+                nb = round(tj["hbm_bytes_per_launch"] * tj["launches"] / tj["steps_profiled"] / g_calls)
+            traffic = (nb, tj["source"])
+        res.update(value=value, fpp=fpp, ms_per_step=dt / args.steps * 1e3,
+                   roofline=roofline_block(prec, recs, dt / args.steps * 1e3, TRACE, value / world, fpp, traffic))
+    return res
+
+
+def h2d_inclusive(run: "ModeRun", steps: int) -> dict:
+    """MEASURED host-buffer rate: every step's inputs start in PINNED host memory; a copy stream uploads batch i+1 into the
+    second of two device buffer sets while the compute stream runs batch i (events order copy -> compute -> reuse)."""
+    dev = run.device
+    orig = (run.images, run.bbox)
+    host_img = run.images.cpu().pin_memory()
+    host_bb = run.bbox.cpu().pin_memory()
+    dimg = [torch.empty_like(run.images) for _ in range(2)]
+    dbb = [torch.empty_like(run.bbox) for _ in range(2)]
+    copy_s = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    free = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(i):
+        b = i & 1
+        with torch.cuda.stream(copy_s):
+            copy_s.wait_event(free[b])
+            dimg[b].copy_(host_img, non_blocking=True)
+            dbb[b].copy_(host_bb, non_blocking=True)
+            ready[b].record(copy_s)
+
+    def compute(i):
+        b = i & 1
+        main.wait_event(ready[b])
+        if run.graphed is not None:
+            run.graphed.set_inputs(dimg[b], dbb[b])
+            run.graphed.replay()
+        else:
+            run.images, run.bbox = dimg[b], dbb[b]
+            run.eager()
+        free[b].record(main)
+
+    for b in range(2):
+        free[b].record(main)
+    torch.cuda.synchronize()
+    # serialised: copy, then compute, no overlap
+    t0 = time.perf_counter()
+    for i in range(steps):
+        upload(i); compute(i)
+        torch.cuda.synchronize()
+    ser = (time.perf_counter() - t0) / steps
+    # double-buffered: upload of batch i+1 issued before the compute of batch i
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    upload(0)
+    for i in range(steps):
+        if i + 1 < steps:
+            upload(i + 1)
+        compute(i)
+    torch.cuda.synchronize()
+    ovl = (time.perf_counter() - t0) / steps
+    nbytes = host_img.numel() * host_img.element_size() + host_bb.numel() * host_bb.element_size()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        dimg[0].copy_(host_img, non_blocking=True); dbb[0].copy_(host_bb, non_blocking=True)
+    torch.cuda.synchronize()
+    copy_ms = (time.perf_counter() - t0) / 3 * 1e3
+    run.images, run.bbox = orig
+    if run.graphed is not None:
+        run.graphed.set_inputs(*orig)
+    return {"input_mb_per_batch": round(nbytes / 1e6, 1), "h2d_ms_per_batch": round(copy_ms, 3),
+            "h2d_gb_per_s": round(nbytes / copy_ms / 1e6, 1),
+            "serialised_poses_per_s": round(run.B / ser, 1), "double_buffered_poses_per_s": round(run.B / ovl, 1),
+            "how": "measured: pinned host buffers, copy stream + 2 device buffer sets, events between copy and compute"}
+
+
+def pnp_inclusive(run: "ModeRun", one, steps: int, step_ms: float) -> dict:
+    """MEASURED PnP-inclusive rates (never `value`): one D2H of the decoded corners per batch + ONE batched host
+    solve (boxdreamer_amd/pnp.py).  serialised: step, D2H, solve, next step.  overlapped: a host thread solves batch i
+    while the GPU runs batch i+1 (measured wall over `steps` batches, not a min() of two rates)."""
+    from boxdreamer_amd.box_utils import solve_poses_host
+    from boxdreamer_amd import pnp as pnp_mod
+    B = run.B
+    b3 = one["bbox_3d"].float().reshape(-1, 8, 3)[-1:].repeat(B, 1, 1).numpy()
+    Kq = one["non_ndc_intrinsics"].float().reshape(-1, 3, 3)[-1:].repeat(B, 1, 1).numpy()
+
+    def solve(kp_dev):
+        return solve_poses_host(kp_dev.float().cpu().numpy(), b3, Kq)
+
+    kp = run.step()[:B]
+    tp = []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        solve(kp)
+        tp.append(time.perf_counter() - t1)
+    pnp_ms = sorted(tp)[1] * 1e3
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        solve(run.step()[:B])
+    ser = (time.perf_counter() - t0) / steps
+    # overlapped: corners of batch i are copied to a pinned host buffer (async, event), the solver thread waits for the
+    # event and solves while the main thread has already enqueued batch i+1
+    host_kp = [torch.empty((B, 8, 2), dtype=torch.float32).pin_memory() for _ in range(2)]
+    evs = [torch.cuda.Event() for _ in range(2)]
+    worker = [None]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        b = i & 1
+        out = run.step()[:B]
+        host_kp[b].copy_(out, non_blocking=True)
+        evs[b].record()
+        if worker[0] is not None:
+            worker[0].join()
+
+        def job(b=b):
+            evs[b].synchronize()
+            solve_poses_host(host_kp[b].numpy(), b3, Kq)
+        worker[0] = threading.Thread(target=job)
+        worker[0].start()
+    worker[0].join()
+    torch.cuda.synchronize()
+    ovl = (time.perf_counter() - t0) / steps
+    return {"pnp_ms_per_batch": round(pnp_ms, 2),
+            "host": ("cv2.solvePnP" if pnp_mod._HAVE_CV2 else "numpy batched DLT + LM, 1 thread, parity vs OpenCV un-pinned"),
+            "serialised_poses_per_s": round(B / ser, 1), "overlapped_poses_per_s": round(B / ovl, 1),
+            "how": f"measured over {steps} batches: serialised = step -> D2H -> solve -> next step; overlapped = solver thread "
+                   "on batch i while the GPU runs batch i+1 (pinned D2H + event)"}
 
 
 def main():
@@ -111,235 +471,106 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--prec", default=os.environ.get("BOXDREAMER_HIP_PREC", "bf16"), choices=["bf16", "fp16", "bf16x3", "fp8"])
+    ap.add_argument("--prec", default=os.environ.get("BOXDREAMER_HIP_PREC", "bf16"),
+                    choices=["bf16", "fp16", "bf16x3", "bf16x3_attn_x3", "fp8"])
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
     ap.add_argument("--views", type=int, default=6, help="T = refs + 1")
     ap.add_argument("--cache-refs", action="store_true",
                     help="'next' row f1: reference features encoded once outside the timed region; per step the encoder "
                          "sees only the query crops (different algorithmic FLOPs -> reported as its own metric)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="split the per-GPU batch into this many independent sub-batches, each on its own HIP stream "
-                         "(samples are independent units; overlaps memory-bound phases of one with MFMA phases of another)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
-                    help="replay the step from a captured HIP graph (default for the plain single-stream step)")
+                    help="replay the step from a captured HIP graph (default)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel from the host each step")
+    ap.add_argument("--no-strict", action="store_true", help="skip the second (strict-mode) timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-pnp", action="store_true", help="skip the PnP-inclusive side measurement (host PnP, SURVEY 8d / 8f3)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-buffer (PCIe-inclusive) side measurement")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--cpu-plumbing", action="store_true",
+                    help="run ONLY the launcher / barrier / corner-gather plumbing on CPU (tests); needs --backend gloo")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    maybe_respawn(args)
+    if args.cpu_plumbing:
+        if args.backend != "gloo":
+            raise SystemExit("--cpu-plumbing needs --backend gloo")
+        return cpu_plumbing(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback for the product path")
+    if args.backend != "nccl":
+        raise SystemExit("the GPU sweep runs on RCCL (--backend nccl)")
+    _, _, local_rank = dist_env()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    n_gpus = world
+    world, rank, local_rank, dist = init_dist(args)
 
-    from boxdreamer_amd import _lib, hip_ops, synth
-    from boxdreamer_amd.dist import gather_corners
-    lib = _lib.load()
+    from boxdreamer_amd import synth
     B, T, prec = args.batch, args.views, args.prec
-    enc, dec = build_models(prec, device)
-    nstream = max(1, args.streams)
-    lanes = [(enc, dec, torch.cuda.current_stream(device))]
-    for _ in range(nstream - 1):
-        e2, d2 = build_models(prec, device)
-        lanes.append((e2, d2, torch.cuda.Stream(device=device)))
-    # synthetic batch: every rank gets its own shard (different seed), values pre-rounded to bf16 as the
-    # reference dataset does; tensors are bf16 on device (the dataset's `precision`), resident before timing.
-    one = synth.make_batch(seed=100 + rank, B=min(B, 4), T=T)
-    reps = (B + one["images"].shape[0] - 1) // one["images"].shape[0]
-    images = one["images"].repeat(reps, 1, 1, 1, 1)[:B].to(torch.bfloat16).to(device)
-    bbox = one["bbox_feat"].repeat(reps, 1, 1, 1, 1)[:B].to(torch.bfloat16).to(device)
+    # synthetic batch: every rank gets its own shard (different seed), B DISTINCT samples, values pre-rounded to bf16 as
+    # the reference dataset does; tensors are bf16 on device (the dataset's `precision`), resident before timing.
+    one = synth.make_batch(seed=100 + rank, B=B, T=T)
+    images = one["images"].to(torch.bfloat16).to(device)
+    bbox = one["bbox_feat"].to(torch.bfloat16).to(device)
     mask = torch.zeros(B, T, dtype=torch.bool, device=device); mask[:, T - 1] = True
 
-    cached = None
-    if args.cache_refs:
-        from boxdreamer_amd.cache import RefFeatureCache, merge_cached_features
-        cache = RefFeatureCache(enc)
-        qidx = torch.full((B,), T - 1, dtype=torch.long, device=device)
-        cached = cache.place(cache.encode(images[:, : T - 1]), qidx, T)
-        if max(1, args.streams) > 1:
-            raise SystemExit("--cache-refs with --streams > 1 is not wired up")
-
-    from boxdreamer_amd.dist import shard_range
-    spans = [shard_range(B, i, nstream) for i in range(nstream)]
-    kp_all = torch.empty((B, 8, 2), dtype=torch.float32, device=device)
-
-    def run_span(e, d, lo, hi):
-        if cached is not None:          # (single stream only: slicing would drop the attached operand-dtype copy)
-            feats = merge_cached_features(e, images, cached[0], cached[1])
-        else:
-            feats = e.predict(images[lo:hi])
-        heat = d(bbox[lo:hi], images[lo:hi], mask[lo:hi], feats, None)
-        kp, kn, _ = hip_ops.decode_topk(heat, want_idx=False)
-        kp_all[lo:hi] = kp
-
-    # The step is ~300 launches; replaying it from one HIP graph removes the host launch cost and most inter-kernel
-    # gaps (B = 32: 31.5 -> 30.5 ms).  HIP event records cannot be timed inside a captured graph (ROCm 7.2), so in graph
-    # mode the per-launch durations behind `roofline` come from TRACE_STEPS un-graphed executions of the same step on the
-    # same buffers immediately after the timed region; --no-graph measures them inside the timed region itself.
-    cap = 4096
-    graphed = None
-    if args.graph is None:
-        args.graph = nstream == 1 and not args.cache_refs
-    if args.graph:
-        if nstream > 1 or args.cache_refs:
-            raise SystemExit("--graph is wired for the plain single-stream step")
-        from boxdreamer_amd.graph import GraphedPath
-        graphed = GraphedPath(enc, dec, B, T, 224, torch.bfloat16, device)
-        graphed.set_inputs(images, bbox)
-
-    def step():
-        if graphed is not None:
-            kp = graphed.replay()[1]
-            return gather_corners(kp, world) if world > 1 else kp
-        main = torch.cuda.current_stream(device)
-        if nstream == 1:
-            run_span(enc, dec, 0, B)
-        else:
-            for (e, d, st), (lo, hi) in zip(lanes, spans):
-                if st is not main:
-                    st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    run_span(e, d, lo, hi)
-            for _, _, st in lanes:
-                if st is not main:
-                    main.wait_stream(st)
-        if world > 1:
-            return gather_corners(kp_all, world)
-        return kp_all
-
-    for _ in range(args.warmup):
-        step()
-    # ---- timed region: EXACTLY K steps between barrier+sync pairs; launch trace active on rank 0
-    if rank == 0 and graphed is None:
-        _lib.check(lib.bd_trace_begin(cap), "bd_trace_begin")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    recs = []
-    TRACE_STEPS = 3
-    if rank == 0 and graphed is not None:
-        _lib.check(lib.bd_trace_begin(cap), "bd_trace_begin")
-        t1 = time.perf_counter()
-        for _ in range(TRACE_STEPS):
-            run_span(enc, dec, 0, B)
-        torch.cuda.synchronize()
-        traced_wall_ms = (time.perf_counter() - t1) * 1e3
+    main_res = measure_mode(prec, args, device, world, rank, dist, images, bbox, mask, with_traffic=True)
+    line = None
     if rank == 0:
-        buf = (_lib.TraceRecord * cap)()
-        n = lib.bd_trace_end(buf, cap)
-        recs = [(buf[i].kind, buf[i].M, buf[i].N, buf[i].K, buf[i].ms) for i in range(n)]
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    assert out.shape[0] == B * world and torch.isfinite(out).all()
-
-    if rank == 0:
-        poses = B * world * args.steps
-        value = poses / dt
-        fpp = flops_per_pose(T) if not args.cache_refs else DINO_FLOP_PER_IMAGE + betr_flops(T)
-        # dominant kernel = the MFMA GEMM (kind 0).  Algorithmic FLOPs per launch = 2*M*N*K of that launch;
-        # achieved = sum(flops) / sum(duration) = mean flops per launch / mean launch duration.
-        g = [(2.0 * m * n * k, ms) for kind, m, n, k, ms in recs if kind == 0]
-        a = [(4.0 * m * n * n * k, ms) for kind, m, n, k, ms in recs if kind == 1]   # 4*S^2*d per (batch*head)
-        passes = 3.0 if prec == "bf16x3" else 1.0
-        traced_ms = traced_wall_ms if graphed is not None else dt * 1e3
-        peak = PEAK_MFMA_TFLOPS[prec]
-        gemm_tf = sum(f for f, _ in g) / max(sum(ms for _, ms in g), 1e-9) / 1e9 if g else 0.0
-        attn_tf = sum(f for f, _ in a) / max(sum(ms for _, ms in a), 1e-9) / 1e9 if a else 0.0
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-        if os.path.exists(tpath) and prec == "bf16" and B == 32 and T == 6:
-            tj = json.load(open(tpath))
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
-            if tj.get("steps_profiled") and g:      # per kernel launch -> per bd_gemm call (the unit of `achieved`)
-                calls_per_step = len(g) / (TRACE_STEPS if graphed is not None else args.steps)
-                traffic = round(tj["hbm_bytes_per_launch"] * tj["launches"] / tj["steps_profiled"] / calls_per_step)
-        roofline = {"bound": "mfma", "kernel": "gemm_kernel_glds (256x256 / 128x128 tiles, LDS-DMA operands, v_mfma_f32_32x32x16)",
-                    "achieved": round(gemm_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tf / peak, 4),
-                    "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_flops_per_launch": round(sum(f for f, _ in g) / max(len(g), 1)),
-                    "launches": len(g),
-                    "events": ("HIP events around every launch of %d un-graphed executions of the step right after the timed "
-                               "region (events cannot be timed inside a captured graph)" % TRACE_STEPS) if graphed is not None
-                              else "HIP events around every launch inside the timed region", "avg_launch_ms": round(sum(ms for _, ms in g) / max(len(g), 1), 4),
-                    "mfma_passes_per_algorithmic_flop": passes,
-                    "attention_achieved": round(attn_tf, 2),
-                    "attention_avg_launch_ms": round(sum(ms for _, ms in a) / max(len(a), 1), 4),
-                    "gemm_time_frac_of_step": round(sum(ms for _, ms in g) / traced_ms, 4),
-                    "attention_time_frac_of_step": round(sum(ms for _, ms in a) / traced_ms, 4),
-                    "whole_path_achieved": round(value / world * fpp / 1e12, 2),
-                    "whole_path_frac": round(value / world * fpp / 1e12 / peak, 4)}
+        value, fpp = main_res["value"], main_res["fpp"]
         metric = "poses/s/GPU (5-ref, 224×224, bf16); heatmap max-abs err vs CPU ref"     # BASELINE.json's metric string
         if args.cache_refs:
             metric = "poses/s with reference features cached across queries (SURVEY 8f1; encoder on the query crop only)"
         line = {"metric": metric,
-                "value": round(value, 2), "unit": "poses/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3", "fp8": "fp8-e4m3 (Linears) + bf16 (attention)"}[prec],
-                "data": "synthetic",
-                "config": {"workload": f"configs[1]: 1 query + {T - 1} ref, 224x224, batch {B}/GPU, DINOv2 ViT-B/14-reg "
-                                       f"+ BETR-12 + top-20 decode, random-init weights, inputs bf16 in HBM",
-                           "global_batch": B * world, "views": T, "parallelism": f"dp{world}", "streams_per_gpu": nstream, "hip_graph": bool(args.graph),
-                           "gflop_per_pose": round(fpp / 1e9, 2)},
+                "value": round(value, 2), "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(main_res["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": DTYPE_LABEL[prec], "data": "synthetic",
+                "config": {"workload": f"configs[1]: 1 query + {T - 1} ref, 224x224, batch {B}/GPU ({B} distinct seeded samples "
+                                       f"per rank), DINOv2 ViT-B/14-reg + BETR-12 + top-20 decode, random-init weights, "
+                                       f"inputs bf16 in HBM",
+                           "global_batch": B * world, "views": T, "parallelism": f"dp{world}",
+                           "hip_graph": main_res["run"].graphed is not None, "gflop_per_pose": round(fpp / 1e9, 2)},
                 "poses_per_s_per_gpu": round(value / world, 2),
                 "value_is": "whole-job aggregate over n_gpus (bench contract); the per-GPU figure of the metric is poses_per_s_per_gpu",
-                "roofline": roofline}
-        if not args.no_pnp:
-            # PnP-inclusive rate (SURVEY 8d asks for it next to `value`, never as `value`): one D2H of the decoded corners
-            # per batch + ONE batched host solve (boxdreamer_amd/pnp.py, row f3).  Serialised = no overlap at all;
-            # overlapped = PnP of batch i on the host while the GPU runs batch i+1.
-            from boxdreamer_amd.box_utils import solve_poses_host
-            b3 = one["bbox_3d"].float().reshape(-1, 8, 3)
-            b3 = b3[-1:].repeat(B, 1, 1).numpy()
-            Kq = one["non_ndc_intrinsics"].float().reshape(-1, 3, 3)[-1:].repeat(B, 1, 1).numpy()
-            tp = []
-            for _ in range(3):
-                t1 = time.perf_counter()
-                kp_host = out[:B].float().cpu().numpy()
-                solve_poses_host(kp_host, b3, Kq)
-                tp.append(time.perf_counter() - t1)
-            pnp_ms = sorted(tp)[1] * 1e3
-            step_ms = dt / args.steps * 1e3
-            # the same solve as a HIP kernel (one pose per thread, fp64): corners stay on the device
-            from boxdreamer_amd.box_utils import solve_poses_device
-            b3d, Kd = torch.from_numpy(b3).to(device), torch.from_numpy(Kq).to(device)
-            for _ in range(2):
-                solve_poses_device(out[:B], b3d, Kd)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                solve_poses_device(out[:B], b3d, Kd)
-            torch.cuda.synchronize()
-            gpu_pnp_ms = (time.perf_counter() - t1) / 5 * 1e3
-            line["pnp_inclusive"] = {"pnp_ms_per_batch": round(pnp_ms, 2), "host": "numpy batched DLT + LM, 1 thread, parity vs OpenCV un-pinned",
-                                     "gpu_pnp_ms_per_batch": round(gpu_pnp_ms, 2),
-                                     "gpu_pnp_serialised_poses_per_s": round(B * world / ((step_ms + gpu_pnp_ms) / 1e3), 1),
-                                     "gpu_pnp": "bd_solve_pnp, 1 pose per thread fp64, same stream (random-weight corners: LM runs all 30 iterations)",
-                                     "serialised_poses_per_s": round(B * world / ((step_ms + pnp_ms) / 1e3), 1),
-                                     "overlapped_poses_per_s": round(min(value, B * world / (pnp_ms / 1e3)), 1)}
+                "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in main_res["per_rank"]],
+                "roofline": main_res["roofline"]}
+    if world > 1:
+        lat = gather_latency_ms(main_res["run"].kp_all, world, dist, main_res["run"].gather)
+        if rank == 0:
+            line["corner_allgather_ms"] = round(lat, 4)
+            line["collective"] = f"all_gather_into_tensor of ({B}, 8, 2) fp32 per rank over RCCL (xGMI), once per step"
+    if rank == 0:
+        run = main_res["run"]
         if not args.no_parity:
-            line["parity"] = parity_probe(prec, T, device)
+            line["parity"] = parity_probe(prec, T, device, (run.enc, run.dec))
+        if world == 1 and not args.no_h2d and not args.cache_refs:
+            line["h2d_inclusive"] = h2d_inclusive(run, max(4, args.steps))
+        if world == 1 and not args.no_pnp:
+            line["pnp_inclusive"] = pnp_inclusive(run, one, max(4, args.steps), main_res["ms_per_step"])
+    main_res["run"].close()
+    del main_res
+
+    # ---- the strict mode, same invocation, same inputs (every rank takes part: same barrier / gather structure)
+    if not args.no_strict and prec != STRICT_PREC and not args.cache_refs:
+        torch.cuda.empty_cache()
+        sres = measure_mode(STRICT_PREC, args, device, world, rank, dist, images, bbox, mask, with_traffic=False)
+        if rank == 0:
+            srun = sres["run"]
+            line["strict"] = {"mode": STRICT_PREC,
+                              "what": "split-bf16 Linears (hi*hi + hi*lo + lo*hi, fp32 accumulate), f16 attention where q/k are "
+                                      "RMS-normalised, split-bf16 attention in DINOv2: the mode that meets the 1e-3 logits bar",
+                              "value": round(sres["value"], 2), "unit": "poses/s",
+                              "poses_per_s_per_gpu": round(sres["value"] / world, 2),
+                              "ms_per_step": round(sres["ms_per_step"], 3), "dtype": DTYPE_LABEL[STRICT_PREC],
+                              "roofline": sres["roofline"]}
+            if not args.no_parity:
+                line["strict"]["parity"] = parity_probe(STRICT_PREC, T, device, (srun.enc, srun.dec))
+        sres["run"].close()
+        del sres
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(T)
-            line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+            line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

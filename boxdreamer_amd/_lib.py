@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -15,7 +16,10 @@ LIB_PATH = os.environ.get("BOXDREAMER_HIP_LIB") or os.path.join(HERE, "libboxdre
 
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 PREC_BF16, PREC_F16, PREC_BF16X3, PREC_F16_OUT_BF16X3, PREC_FP8, PREC_BF16_OUT_FP8 = 0, 1, 2, 3, 4, 5
-PREC_NAMES = {"bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8}
+PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16 = 6, 7      # whole-path only: attention policy of the strict family
+PREC_NAMES = {"bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8,
+              "bf16x3_attn_x3": PREC_BF16X3_ATTN_X3, "bf16x3_attn_f16": PREC_BF16X3_ATTN_F16}
+_X3_FAMILY = (PREC_BF16X3, PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16)
 ACT_NONE, ACT_GELU = 0, 1
 
 _ERR = {-1: "BD_ERR_SHAPE", -2: "BD_ERR_DTYPE", -3: "BD_ERR_ALIGN", -4: "BD_ERR_WORKSPACE", -5: "BD_ERR_NULL"}
@@ -124,13 +128,25 @@ def load() -> C.CDLL:
     lib.bd_solve_pnp.argtypes = [vp, vp, vp, i, i, i, vp, vp]
     lib.bd_trace_begin.argtypes = [i]
     lib.bd_trace_end.argtypes = [C.POINTER(TraceRecord), i]
-    if lib.bd_abi_version() != 1:
+    if lib.bd_abi_version() != 2:
         raise HipLibraryError("libboxdreamer_hip.so ABI version mismatch")
     _lib = lib
     return lib
 
 
+# Device discipline, kept central so that no call site can forget it: `ptr()` notes the device of every tensor whose address
+# is handed to the library, `stream()` returns torch's current stream ON THAT DEVICE and makes the device current for the
+# launch (a module moved with .to("cuda:1") while cuda:0 is current would otherwise launch on a device-0 stream with
+# device-1 pointers), and `check()` restores the previous current device.  Mixed devices in one call raise.
+_call = threading.local()
+
+
 def check(rc: int, what: str) -> None:
+    prev = getattr(_call, "restore", None)
+    _call.dev = None
+    if prev is not None:
+        _call.restore = None
+        torch.cuda.set_device(prev)
     if rc == 0:
         return
     if rc < 0:
@@ -147,6 +163,12 @@ def prec_id(prec) -> int:
         raise ValueError(f"unknown precision {prec!r}; choose from {sorted(PREC_NAMES)}") from None
 
 
+def operand_prec(prec) -> int:
+    """Operand class of a (possibly whole-path) precision id: the value the unit operators and the weight packer take."""
+    pid = prec_id(prec)
+    return PREC_BF16X3 if pid in _X3_FAMILY else pid
+
+
 def op_dtype(prec) -> torch.dtype:
     pid = prec_id(prec)
     if pid == PREC_FP8:
@@ -160,7 +182,7 @@ def k_multiple(prec) -> int:
 
 
 def planes(prec) -> int:
-    return 2 if prec_id(prec) == PREC_BF16X3 else 1
+    return 2 if prec_id(prec) in _X3_FAMILY else 1
 
 
 def dtype_id(t: torch.Tensor) -> int:
@@ -175,11 +197,42 @@ def ptr(t) -> C.c_void_p:
         return C.c_void_p(0)
     if not t.is_cuda:
         raise HipLibraryError("the HIP path needs device tensors (got a CPU tensor); there is no CPU fallback")
+    dev = getattr(_call, "dev", None)
+    if dev is None:
+        _call.dev = t.device
+    elif dev != t.device:
+        _call.dev = None
+        raise HipLibraryError(f"one call mixes tensors on {dev} and {t.device}")
     return C.c_void_p(t.data_ptr())
 
 
 def stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current HIP stream on the device of the tensors passed through ptr() for this call; that device is made
+    current until check() runs."""
+    dev = getattr(_call, "dev", None)
+    _call.dev = None
+    if dev is None:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cur = torch.cuda.current_device()
+    if dev.index is not None and dev.index != cur:
+        _call.restore = cur
+        torch.cuda.set_device(dev)
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def same_device(*tensors) -> torch.device:
+    """All given (non-None) tensors must live on one HIP device; returns it."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HipLibraryError("the HIP path needs device tensors (got a CPU tensor); there is no CPU fallback")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise HipLibraryError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
 
 
 def require_gpu() -> None:

@@ -8,11 +8,12 @@ bbox_representation='heatmap', use_pretrained=True.  Inference o
 from __future__ import annotations
 
 import os
+import warnings
 
 import torch
 from torch import nn
 
-from . import _lib, hip_ops, pack
+from . import _lib, features, hip_ops, pack
 
 
 class _Norm(nn.Module):
@@ -88,25 +89,46 @@ class BETR(nn.Module):
         self.bbox_learnable_query = nn.Parameter(torch.zeros(1, d_model))
         self.bbox_emb = nn.Linear(self.patch_size ** 2 * 8, d_model)
 
-        self._packed = {}
+        self._packed = {}          # (device, operand class) -> (content signature, pack.Packed)
         self._ws = None
+        self._frozen_by = None     # a live GraphedPath that captured raw pointers into _packed / _ws (graph.py)
         self.last_logits = None
+        self.validate_inputs = True   # one-hot check of `masks` costs a device sync; graph capture and bench turn it off
+        self.recast_count = 0         # forwards that had to re-cast features lacking an operand copy (features.py)
 
-    # -- packed-weight cache invalidation
+    # -- packed-weight cache: invalidated by CONTENT, not by hooks.  The key carries every parameter's storage address
+    # and version counter, so a checkpoint loaded through the PARENT module (`BoxDreamer.load_state_dict`, which recurses
+    # through `_load_from_state_dict` and never calls this module's `load_state_dict`), an in-place edit, `.to()` or
+    # `.half()` all re-pack on the next forward.
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
     def _apply(self, fn, *a, **k):
+        self._check_not_frozen("moving / casting the module")
         self._packed = {}
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
-        self._packed = {}
-        return super().load_state_dict(*a, **k)
+    def _check_not_frozen(self, what: str):
+        g = self._frozen_by() if self._frozen_by is not None else None
+        if g is not None:
+            raise RuntimeError(f"{what} would free memory a live GraphedPath still replays on; delete the graph first")
 
     def _weights(self, device, prec) -> pack.Packed:
-        key = (str(device), _lib.prec_id(prec))
-        if key not in self._packed:
+        key = (str(device), _lib.operand_prec(prec))
+        sig = self._signature()
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != sig:
+            self._check_not_frozen("re-packing the decoder weights")
             sd = {k: v.detach() for k, v in self.state_dict().items()}
-            self._packed[key] = pack.pack_betr(sd, prec, device, self.nhead, self.patch_size, self.img_size)
-        return self._packed[key]
+            hit = (sig, pack.pack_betr(sd, _lib.operand_prec(prec), device, self.nhead, self.patch_size, self.img_size))
+            self._packed[key] = hit
+        return hit[1]
+
+    def _workspace(self, need: int, dev) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._check_not_frozen("growing the decoder workspace (a larger B or T than the captured one)")
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws
 
     # -- reference helpers kept for API compatibility (host-side, tiny)
     def patchify(self, imgs, c):
@@ -132,28 +154,41 @@ class BETR(nn.Module):
             raise NotImplementedError("the MI355X path requires pretrained RGB features (use_pretrained=True)")
         _lib.require_gpu()
         lib = _lib.load()
-        dev = pose_feat.device
+        dev = _lib.same_device(pose_feat, rgbs, masks, pretrain_rgb_feat)
         prec = self.hip_precision
         pid = _lib.prec_id(prec)
         w = self._weights(dev, prec).struct
         P, D = w.grid * w.grid, w.dim
         if masks.dtype != torch.bool or masks.shape != (B, T):
             raise ValueError("masks must be a (B, T) bool tensor")
+        if tuple(pose_feat.shape) != (B, T, self.box_dim, H, W):
+            raise ValueError(f"pose_feat must be (B, T, {self.box_dim}, H, W) = {(B, T, self.box_dim, H, W)}, got "
+                             f"{tuple(pose_feat.shape)}")
+        if pretrain_rgb_feat.numel() != B * T * P * D or pretrain_rgb_feat.shape[-1] != D:
+            raise ValueError(f"pretrain_rgb_feat must be (B, T, {P}, {D}), got {tuple(pretrain_rgb_feat.shape)}")
+        if self.validate_inputs and not torch.cuda.is_current_stream_capturing():
+            # the reference writes the query token through `pose_feat[masks] = ...` (betr.py:286-290), which fails unless
+            # every sample marks exactly one view; argmax below would silently pick view 0 for an empty row
+            if not bool((masks.sum(dim=1) == 1).all()):
+                raise ValueError("masks must mark exactly one query view per sample")
         query_idx = masks.to(torch.int32).argmax(dim=1).to(torch.int32).contiguous()
-        tagged = getattr(pretrain_rgb_feat, "_bd_feats16", None)
-        if tagged is not None and tagged[1] == pid:
-            feats16 = tagged[0]
-        else:   # features from somewhere else: cast/split here (glue, off the default path)
-            feats16 = hip_ops.to_operand(pretrain_rgb_feat.reshape(B * T * P, D).float(), prec)
+        np_ = _lib.planes(prec)
+        feats16 = features.operand_of(pretrain_rgb_feat, _lib.operand_prec(prec))
+        if feats16 is not None and (feats16.numel() != np_ * B * T * P * D or feats16.device != dev):
+            feats16 = None
+        if feats16 is None:   # features without an operand copy (computed elsewhere, copied, sliced): explicit re-cast
+            self.recast_count += 1
+            if self.recast_count == 1:
+                warnings.warn("BETR: pretrain_rgb_feat carries no operand-dtype copy from the HIP encoder; re-casting it "
+                              "(slow path, see boxdreamer_amd/features.py)", stacklevel=2)
+            feats16 = hip_ops.to_operand(pretrain_rgb_feat.reshape(B * T * P, D).float(), _lib.operand_prec(prec))
         pose_feat = pose_feat.contiguous()
-        need = lib.bd_decoder_workspace_bytes(w, B, T, pid)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = self._workspace(lib.bd_decoder_workspace_bytes(w, B, T, pid), dev)
         logits = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)
         heat = torch.empty_like(logits)
         _lib.check(lib.bd_decoder_forward(w, _lib.ptr(pose_feat), _lib.dtype_id(pose_feat), _lib.ptr(feats16),
-                                          B * T * P * D if _lib.planes(prec) == 2 else 0, _lib.ptr(query_idx), B, T, H,
-                                          _lib.ptr(logits), _lib.ptr(heat), _lib.ptr(self._ws), self._ws.numel(), pid,
+                                          B * T * P * D if np_ == 2 else 0, _lib.ptr(query_idx), B, T, H,
+                                          _lib.ptr(logits), _lib.ptr(heat), _lib.ptr(ws), ws.numel(), pid,
                                           _lib.stream()), "bd_decoder_forward")
         self.last_logits = logits
         return heat

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib
+from . import _lib, features
 
 
 class RefFeatureCache:
@@ -29,7 +29,7 @@ class RefFeatureCache:
 
     @staticmethod
     def _feats16_view(feats: torch.Tensor):
-        tag = getattr(feats, "_bd_feats16", None)
+        tag = features.tag_of(feats)
         if tag is None:
             raise ValueError("features were not produced by the HIP encoder (no operand-dtype copy attached)")
         return tag
@@ -54,8 +54,7 @@ class RefFeatureCache:
             full16 = torch.zeros((B, T, P, C), dtype=f16.dtype, device=dev)
             full16[valid] = f16.reshape(B * R, P, C)
             full16 = full16.reshape(B * T * P, C)
-        full32._bd_feats16 = (full16, pid)
-        return full32, valid
+        return features.attach(full32, full16, pid), valid
 
 
 def merge_cached_features(encoder, images: torch.Tensor, cached: torch.Tensor, valid: torch.Tensor) -> torch.Tensor:
@@ -78,5 +77,4 @@ def merge_cached_features(encoder, images: torch.Tensor, cached: torch.Tensor, v
         out16 = f16.clone().reshape(B, T, P, C)
         out16[miss] = n16.reshape(-1, P, C)
         out16 = out16.reshape(B * T * P, C)
-    out32._bd_feats16 = (out16, pid)
-    return out32
+    return features.attach(out32, out16, pid)

@@ -2,8 +2,6 @@
 // (BETR.forward) as straight-line sequences of kernel launches on the caller's stream.
 // No allocation, no synchronisation, no state: the caller provides one workspace blob that is
 // carved here (256-byte aligned slices).
-#include <stdlib.h>
-
 #include "bd_common.h"
 
 namespace {
@@ -19,7 +17,9 @@ struct Carver {
     }
 };
 
-inline int planes_of(int prec) { return prec == BD_PREC_BF16X3 ? 2 : 1; }
+inline int planes_of(int prec) {
+    return (prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_BF16X3_ATTN_F16) ? 2 : 1;
+}
 
 struct BlockBufs {
     float* x;        // fp32 residual stream [M, D]
@@ -43,25 +43,29 @@ inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const
 
 #define BD_TRY(expr) do { int rc__ = (expr); if (rc__ != BD_OK) return rc__; } while (0)
 
-// Optional variant of the strict (split-bf16 x3) mode, selected with BD_X3_ATTN=f16 in the environment: ATTENTION as one
-// f16 MFMA pass (the x3 QKV GEMM stores q, k, v as a single f16 plane, q/k RMSNorm and attention run in f16, attention
-// writes (hi, lo) bf16 planes for the x3 proj GEMM).  Measured at full depth: 513 vs 425 poses/s, but 1.18e-3 vs 7.2e-5
-// logit error -- the f16 Q.K^T on DINOv2's un-normalised q/k eats the whole 1e-3 budget -- so it is NOT the default.
-// BD_X3_ATTN=betr: the same, but only where q and k are RMS-normalised (BETR); DINOv2's attention stays split-bf16.
-inline int x3_attention_mode() {
-    // default: "betr" (measured 1.3e-4 on the logits, 542 vs 501 poses/s); "x3" = split-bf16 attention everywhere (8.2e-5);
-    // "f16" = f16 attention everywhere (1.18e-3: misses the bar because of DINOv2's un-normalised q.k)
-    static const int m = [] { const char* e = getenv("BD_X3_ATTN"); return !e ? 2 : (e[0] == 'f' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
-    return m;
+// Attention policy of the strict (split-bf16 x3) family.  The three variants are separate `prec` values of the whole-path
+// entry points (no environment switches, no library state):
+//   BD_PREC_BF16X3           GEMMs split-bf16; attention as ONE f16 pass where q and k are RMS-normalised (BETR: the x3 QKV
+//                            GEMM stores q, k, v as a single f16 plane, q/k RMSNorm and attention run in f16, attention writes
+//                            (hi, lo) bf16 planes for the x3 proj GEMM); DINOv2's attention (un-normalised q.k) stays
+//                            split-bf16.  Measured 1.3e-4 on the logits at full depth, T = 6.
+//   BD_PREC_BF16X3_ATTN_X3   split-bf16 attention everywhere (8.2e-5, ~8 % slower)
+//   BD_PREC_BF16X3_ATTN_F16  f16 attention everywhere (1.18e-3: the f16 Q.K^T on DINOv2's un-normalised q/k eats the whole
+//                            1e-3 budget -- kept for measurement, misses the bar)
+inline int gemm_prec(int prec) {
+    return (prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_BF16X3_ATTN_F16) ? BD_PREC_BF16X3 : prec;
 }
-inline bool x3_f16_attention(bool qk_normed) { return x3_attention_mode() == 1 || (x3_attention_mode() == 2 && qk_normed); }
+inline bool x3_f16_attention(int prec, bool qk_normed) {
+    return prec == BD_PREC_BF16X3_ATTN_F16 || (prec == BD_PREC_BF16X3 && qk_normed);
+}
 
 // One pre-LN transformer block: x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x))).
 // BETR: blocks.py:876-886 (+ q/k RMSNorm :257); DINOv2: layers/block.py:89-114 (LayerScale folded).
 int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, int seq, int D, int heads,
-              float ln_eps, float rms_eps, int prec, void* stream) {
+              float ln_eps, float rms_eps, int wprec, void* stream) {
     const int hd = D / heads;
-    const bool hyb = prec == BD_PREC_BF16X3 && x3_f16_attention(w.q_norm_w != nullptr);
+    const int prec = gemm_prec(wprec);
+    const bool hyb = prec == BD_PREC_BF16X3 && x3_f16_attention(wprec, w.q_norm_w != nullptr);
     const bool f8 = prec == BD_PREC_FP8;      // e4m3 Linears, bf16 attention
     const int aprec_in = hyb ? BD_PREC_F16 : (f8 ? BD_PREC_BF16 : prec);
     const int aprec = hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec);
@@ -96,9 +100,10 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
 // compact [B*P, D] result; proj, LN2 and the MLP then run on B*P rows (1/T of the work).  Row-wise arithmetic is
 // unchanged, so the result is bit-identical to the full-width block.  xc: fp32 [B*P, D] compact residual stream.
 int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, float* xc, const int32_t* query_idx, int B,
-                              int T, int P, int D, int heads, float ln_eps, float rms_eps, int prec, void* stream) {
+                              int T, int P, int D, int heads, float ln_eps, float rms_eps, int wprec, void* stream) {
     const int hd = D / heads, M = B * T * P, Mq = B * P;
-    const bool hyb = prec == BD_PREC_BF16X3 && x3_f16_attention(w.q_norm_w != nullptr);
+    const int prec = gemm_prec(wprec);
+    const bool hyb = prec == BD_PREC_BF16X3 && x3_f16_attention(wprec, w.q_norm_w != nullptr);
     const bool f8 = prec == BD_PREC_FP8;      // e4m3 Linears, bf16 attention
     const int aprec_in = hyb ? BD_PREC_F16 : (f8 ? BD_PREC_BF16 : prec);
     const int aprec = hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec);
@@ -170,7 +175,8 @@ DecBufs carve_decoder(const bd_betr_weights* w, int B, int T, int prec, void* ws
 }
 
 inline bool bad_prec(int prec) {
-    return prec != BD_PREC_BF16 && prec != BD_PREC_F16 && prec != BD_PREC_BF16X3 && prec != BD_PREC_FP8;
+    return prec != BD_PREC_BF16 && prec != BD_PREC_F16 && prec != BD_PREC_BF16X3 && prec != BD_PREC_FP8 &&
+           prec != BD_PREC_BF16X3_ATTN_X3 && prec != BD_PREC_BF16X3_ATTN_F16;
 }
 
 }  // namespace
@@ -185,9 +191,10 @@ extern "C" size_t bd_encoder_workspace_bytes(const bd_dino_weights* w, int n_ima
 
 extern "C" int bd_encoder_forward(const bd_dino_weights* w, const void* images, int img_dtype, int n_images,
                                   int size, float* feats32, void* feats16, int64_t feats16_plane, void* workspace,
-                                  size_t workspace_bytes, int prec, void* stream) {
+                                  size_t workspace_bytes, int wprec, void* stream) {
     if (!w || !images || !workspace || !w->blocks || (!feats32 && !feats16)) return BD_ERR_NULL;
-    if (bad_prec(prec)) return BD_ERR_DTYPE;
+    if (bad_prec(wprec)) return BD_ERR_DTYPE;
+    const int prec = gemm_prec(wprec);      // operand class of the unit operators; wprec also carries the attention policy
     if (n_images <= 0 || size != w->grid * w->patch || w->dim % w->heads || w->kpad % 64 ||
         w->kpad < 3 * w->patch * w->patch)
         return BD_ERR_SHAPE;
@@ -210,7 +217,7 @@ extern "C" int bd_encoder_forward(const bd_dino_weights* w, const void* images, 
     }
     BD_TRY(bd_write_prefix_tokens(e.blk.x, w->prefix_tokens, n_images, tpi, w->n_prefix, D, stream));
     for (int i = 0; i < w->depth; ++i)
-        BD_TRY(run_block(w->blocks[i], e.blk, Md, n_images, tpi, D, w->heads, w->ln_eps, 0.f, prec, stream));
+        BD_TRY(run_block(w->blocks[i], e.blk, Md, n_images, tpi, D, w->heads, w->ln_eps, 0.f, wprec, stream));
     // final LayerNorm on the patch tokens only (vision_transformer.py:263-267)
     BD_TRY(bd_layernorm(e.blk.x, D, w->norm_w, w->norm_b, w->ln_eps, feats16, feats16_plane, feats32, D, Mp, D, P, tpi,
                         w->n_prefix, prec, stream));
@@ -224,10 +231,11 @@ extern "C" size_t bd_decoder_workspace_bytes(const bd_betr_weights* w, int B, in
 
 extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_feat, int in_dtype, const void* feats16,
                                   int64_t feats16_plane, const int32_t* query_idx, int B, int T, int size,
-                                  float* logits, float* heat, void* workspace, size_t workspace_bytes, int prec,
+                                  float* logits, float* heat, void* workspace, size_t workspace_bytes, int wprec,
                                   void* stream) {
     if (!w || !bbox_feat || !feats16 || !query_idx || !workspace || !w->blocks || (!logits && !heat)) return BD_ERR_NULL;
-    if (bad_prec(prec)) return BD_ERR_DTYPE;
+    if (bad_prec(wprec)) return BD_ERR_DTYPE;
+    const int prec = gemm_prec(wprec);
     if (B <= 0 || T <= 0 || size != w->grid * w->patch || w->dim % w->heads || w->kpad % 64 || w->box_dim != 8 ||
         w->kpad < w->patch * w->patch * w->box_dim)
         return BD_ERR_SHAPE;
@@ -260,18 +268,13 @@ extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_fea
     }
     BD_TRY(bd_query_substitute(d.blk.x, d.rgb, w->pos_table, w->query_token, query_idx, B, T, P, D, stream));
     // K9: joint self-attention over all T*P tokens of a sample
-    static const bool full_last = getenv("BD_FULL_LAST_BLOCK") != nullptr;   // A/B measurements only
-    for (int i = 0; i + (full_last ? 0 : 1) < w->depth; ++i)
-        BD_TRY(run_block(w->blocks[i], d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, prec, stream));
-    if (full_last) {
-        BD_TRY(bd_gather_query_tokens(d.blk.x, query_idx, d.qtok, (int64_t)Mq * D, B, T, P, D, prec, stream));
-    } else {
-        // last block: query-view rows only past the K/V projection; d.t2 (dead since the adapter) holds the compact stream
-        BD_TRY(run_last_block_query_only(w->blocks[w->depth - 1], d.blk, d.t2, query_idx, B, T, P, D, w->heads,
-                                         w->ln_eps, w->rms_eps, prec, stream));
-        // K10: head on the query view's tokens (no final norm, betr.py:298-306)
-        BD_TRY(bd_gather_query_tokens(d.t2, nullptr, d.qtok, (int64_t)Mq * D, B, 1, P, D, prec, stream));
-    }
+    for (int i = 0; i + 1 < w->depth; ++i)
+        BD_TRY(run_block(w->blocks[i], d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, wprec, stream));
+    // last block: query-view rows only past the K/V projection; d.t2 (dead since the adapter) holds the compact stream
+    BD_TRY(run_last_block_query_only(w->blocks[w->depth - 1], d.blk, d.t2, query_idx, B, T, P, D, w->heads,
+                                     w->ln_eps, w->rms_eps, wprec, stream));
+    // K10: head on the query view's tokens (no final norm, betr.py:298-306)
+    BD_TRY(bd_gather_query_tokens(d.t2, nullptr, d.qtok, (int64_t)Mq * D, B, 1, P, D, prec, stream));
     {
         bd_gemm_args g = gemm_args(d.qtok, D, (int64_t)Mq * D, w->bbox_proj, D, F, d.proj, F, 0, 1, Mq, D, BD_ACT_NONE);
         BD_TRY(bd_gemm(&g, prec, stream));

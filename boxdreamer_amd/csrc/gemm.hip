@@ -22,10 +22,20 @@
 // Experiments that did NOT pay (deeper LDS-DMA rings, mid-slab barriers, ping-pong wave groups, 256x128 tiles at one or
 // two workgroups per CU, a persistent tile loop with the epilogue overlapped, pinned fragment prefetch) and the counters
 // behind the choices: profiles/r1_gemm_experiments.md, profiles/r1_gemm_pmc.md.
-#include <stdlib.h>
-
 #define BD_STORE_NT 1   // non-temporal 16/8-bit epilogue stores (bd_common.h: store_cvt)
 #include "bd_common.h"
+
+#ifdef BD_GEMM_PROBE
+// Measurement build only (tools/gemm_phase_probe.py; never part of libboxdreamer_hip.so): per-wave shader-clock stamps of
+// the mainloop phases, kept in the lanes of one VGPR (lane i = stamp i) and written out once at kernel end.
+__device__ unsigned* bd_probe_buf = nullptr;
+extern "C" int bd_gemm_probe_set(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(bd_probe_buf), &buf, sizeof(buf));
+}
+#define BD_PROBE(idx) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((idx) < 64) probe_ts = (lane == (idx)) ? (unsigned)t__ : probe_ts; }
+#else
+#define BD_PROBE(idx)
+#endif
 
 namespace {
 
@@ -346,10 +356,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gem
 
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int nk = p.K / BK;
+#ifdef BD_GEMM_PROBE
+    unsigned probe_ts = 0;
+#endif
+    BD_PROBE(60)
     DMA_SLAB(0, 0)
     for (int kt = 0; kt < nk; ++kt) {
+        BD_PROBE(kt * 3)
         slab_barrier();                                    // slab kt landed; buffer (kt+1)&1 is free
+        BD_PROBE(kt * 3 + 1)
         if (kt + 1 < nk) { DMA_SLAB((kt + 1) & 1, (kt + 1) * ROWB) }
+        BD_PROBE(kt * 3 + 2)
         const unsigned char* base = lds + (kt & 1) * STAGE_BYTES;
         // fragments are double-buffered in registers (one plane only: two sets next to 128 accumulators would
         // spill in the split mode): the LDS reads of k-step ks+1 are in flight while the MFMAs of ks issue
@@ -401,17 +418,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gem
                       (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.addtab || ((uintptr_t)p.addtab & 15) == 0) &&
                       (!p.wscale || ((uintptr_t)p.wscale & 15) == 0) &&
                       (p.out_f32 || NS == 1 || (p.out_plane % 8 == 0));
+    BD_PROBE(61)
     if (wide) {
         __syncthreads();                                   // every wave is done with the operand slabs
+        BD_PROBE(62)
         gemm_epilogue_lds<T, NS, MI, NI>(p, acc, lds + wid * (32 * NI * 32 * 4), m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
     } else {
         gemm_epilogue<T, NS, MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
     }
-}
-
-int gemm_impl() {   // BD_GEMM_IMPL=2: 128x128 tiles only (measurement)
-    static const int impl = [] { const char* e = getenv("BD_GEMM_IMPL"); return e ? atoi(e) : 1; }();
-    return impl;
+#ifdef BD_GEMM_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the epilogue's stores have left
+    BD_PROBE(63)
+    if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * NWAVE + wid) * 64 + lane] = probe_ts;
+#endif
 }
 
 template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_glds(const bd_gemm_args& a, hipStream_t s) {
@@ -420,12 +439,20 @@ template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_g
     hipLaunchKernelGGL((gemm_kernel_glds<T, NS, BK, WM, WN, MI, NI>), dim3(tiles), dim3(WM * WN * 64), 0, s, a);
 }
 
-int gemm_split() {   // BD_GEMM_SPLIT=k forces k rounds of 256x256 tiles ahead of the 128x128 remainder (measurement); default: model
-    static const int v = [] { const char* e = getenv("BD_GEMM_SPLIT"); return e ? atoi(e) : -1; }();
-    return v;
+// Compute units of the current device (MI355X: 256; partitioned / harvested parts differ): the tile-choice model counts
+// resident workgroup slots per round (one 256x256 workgroup per CU, two 128x128, four 64x64).  Immutable device property,
+// looked up once per device.
+int cu_count() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
 }
-
-constexpr int kCUs = 256;   // gfx950: one 256x256 workgroup per CU, two 128x128, four 64x64
 
 // rows [row0, row0 + rows) of the problem as its own launch (no row remap / table: checked by the caller)
 template <class T> bd_gemm_args row_slice(const bd_gemm_args& a, int64_t row0, int rows) {
@@ -441,7 +468,7 @@ template <class T> bd_gemm_args row_slice(const bd_gemm_args& a, int64_t row0, i
 
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
-    const int impl = gemm_impl();
+    const int kCUs = cu_count();
     {
         // Tile choice = best estimated efficiency: wave quantisation over the resident slots (256x256: one workgroup
         // per CU; 128x128: two; 64x64: four) times the measured relative mainloop efficiency of the tile
@@ -451,9 +478,9 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
             const double rounds = (double)(((int64_t)tiles + slots - 1) / slots);
             return base * tiles / (rounds * slots);
         };
-        const double e256 = (a.N >= 1536 && impl != 2) ? eff(256, 256, kCUs, 1.0) : 0.0;
+        const double e256 = a.N >= 1536 ? eff(256, 256, kCUs, 1.0) : 0.0;
         const double e128 = eff(128, 128, 2 * kCUs, 0.87);
-        const double e64 = impl == 2 ? 0.0 : eff(64, 64, 4 * kCUs, 0.55);
+        const double e64 = eff(64, 64, 4 * kCUs, 0.55);
         // Narrow outputs (N = 768: proj / fc2) have too few 256x256 tiles for whole rounds (576 tiles = 2.25 rounds) and
         // pay 4.5 -> 5 rounds plus the weaker mainloop with 128x128 tiles.  Hybrid: k FULL rounds of 256x256 tiles over
         // the first rows, the remaining rows as 128x128 tiles -- two launches over disjoint row ranges, no split-K, no
@@ -464,7 +491,7 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
         int k256 = 0;
         int64_t rows256 = 0;
         double hybrid_cost = 1e30;
-        if (impl != 2 && a.N % 256 == 0 && a.N < 1536 && a.K >= 2048 && a.rpg_in <= 0 && !a.addtab && a.M >= 1024) {
+        if (a.N % 256 == 0 && a.N < 1536 && a.K >= 2048 && a.rpg_in <= 0 && !a.addtab && a.M >= 1024) {
             const int tn = a.N / 256;
             const int64_t mtiles = (a.M + 255) / 256;
             auto cost128 = [&](int64_t rows) {
@@ -483,18 +510,11 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
                 if (c < best - 1e-9) { best = c; k256 = k; rows256 = r256; }
             }
             hybrid_cost = best;
-            if (gemm_split() >= 0) {
-                k256 = gemm_split();
-                const int64_t mt = (int64_t)k256 * kCUs / tn;
-                rows256 = mt * 256 < a.M ? mt * 256 : a.M;
-                if (mt == 0) k256 = 0;
-            }
         }
         // 256 x 192 tiles (8 waves of 64 x 96): N = 768 in 4 columns of tiles, 192 row tiles x 4 = exactly 3 rounds at
         // M = 49152 (BETR fc2) -- whole rounds of a big tile without any row split.
-        static const int t192 = [] { const char* e = getenv("BD_GEMM_T192"); return e ? atoi(e) : 1; }();
         bool use192 = false;
-        if (t192 && impl != 2 && a.N % 192 == 0 && a.N < 1536 && a.K >= 2048 && a.M >= 1024) {
+        if (a.N % 192 == 0 && a.N < 1536 && a.K >= 2048 && a.M >= 1024) {
             const double e192 = eff(256, 192, kCUs, 0.93);
             const double ehyb = k256 > 0 ? (double)((a.M + 255) / 256) * (a.N / 256) / kCUs / hybrid_cost : e128;
             use192 = e192 > ehyb && e192 > e128;

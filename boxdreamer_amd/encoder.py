@@ -6,7 +6,7 @@ Differences that are deliberate:
   * weights are never fetched with `torch.hub` (no network; and the hub model's xformers path is the
     CUDA dependency being replaced).  `ckpt_path` is a local state_dict file (.pth/.pt/.safetensors)
     with the hub key names, or cfg['state_dict'] / cfg['synthetic_seed'] supply tensors directly;
-  * `predict` returns fp32 features and tags the tensor with the operand-dtype copy the decoder consumes.
+  * `predict` returns fp32 features with the operand-dtype copy the decoder consumes attached (features.py).
 """
 from __future__ import annotations
 
@@ -14,7 +14,7 @@ import os
 
 import torch
 
-from . import _lib, pack, synth
+from . import _lib, features, pack, synth
 
 _ARCH = {  # model_type -> (dim, depth, heads)
     "dinov2_vits14_reg": (384, 12, 6),
@@ -45,13 +45,28 @@ class DinoV2Encoder:
         self.sd = {k: v.detach().float() for k, v in state_dict.items()}
         self.heads, self.patch, self.prec = heads, patch, prec
         self.device = torch.device("cpu")
-        self._packed = {}       # (device, prec, img_size) -> pack.Packed
+        self._packed = {}       # (device, operand class, img_size) -> pack.Packed
         self._ws = None
+        self._frozen_by = None  # weakref to a live GraphedPath that captured raw pointers into _packed / _ws (graph.py)
+
+    def _check_not_frozen(self, what: str):
+        g = self._frozen_by() if self._frozen_by is not None else None
+        if g is not None:
+            raise RuntimeError(f"{what} would free memory a live GraphedPath still replays on; delete the graph first")
 
     def to(self, device):
-        self.device = torch.device(device)
-        self._packed.clear()
+        device = torch.device(device)
+        if device != self.device:
+            self._check_not_frozen("moving the encoder")
+            self._packed.clear()
+        self.device = device
         return self
+
+    def _workspace(self, need: int, dev) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._check_not_frozen("growing the encoder workspace (more images than the captured batch)")
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws
 
     def eval(self):
         return self
@@ -60,9 +75,9 @@ class DinoV2Encoder:
         return iter(())          # frozen: nothing to hand to an optimiser
 
     def _weights(self, size: int, prec) -> pack.Packed:
-        key = (str(self.device), _lib.prec_id(prec), size)
+        key = (str(self.device), _lib.operand_prec(prec), size)
         if key not in self._packed:
-            self._packed[key] = pack.pack_dino(self.sd, prec, self.device, self.heads, self.patch, size)
+            self._packed[key] = pack.pack_dino(self.sd, _lib.operand_prec(prec), self.device, self.heads, self.patch, size)
         return self._packed[key]
 
     @torch.no_grad()
@@ -80,16 +95,14 @@ class DinoV2Encoder:
         pk = self._weights(size, prec)
         w = pk.struct
         P, D = w.grid * w.grid, w.dim
-        need = lib.bd_encoder_workspace_bytes(w, n, _lib.prec_id(prec))
-        if self._ws is None or self._ws.numel() < need or self._ws.device != images.device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=images.device)
+        ws = self._workspace(lib.bd_encoder_workspace_bytes(w, n, _lib.prec_id(prec)), images.device)
         feats32 = torch.empty((n, P, D), dtype=torch.float32, device=images.device)
         np_ = _lib.planes(prec)
         feats16 = torch.empty((np_, n * P, D) if np_ == 2 else (n * P, D), dtype=_lib.op_dtype(prec),
                               device=images.device)
         _lib.check(lib.bd_encoder_forward(w, _lib.ptr(images), _lib.dtype_id(images), n, size, _lib.ptr(feats32),
-                                          _lib.ptr(feats16), n * P * D if np_ == 2 else 0, _lib.ptr(self._ws),
-                                          self._ws.numel(), _lib.prec_id(prec), _lib.stream()), "bd_encoder_forward")
+                                          _lib.ptr(feats16), n * P * D if np_ == 2 else 0, _lib.ptr(ws),
+                                          ws.numel(), _lib.prec_id(prec), _lib.stream()), "bd_encoder_forward")
         return feats32, feats16
 
 
@@ -158,5 +171,4 @@ class DinoV2Wrapper(PretrainedModelWrapper):
         with torch.no_grad():
             feats32, feats16 = self.model.patch_tokens(input_tensor, self.prec)
             ret = feats32.view(B, T, *feats32.shape[1:]) if flag else feats32
-            ret._bd_feats16 = (feats16, _lib.prec_id(self.prec))     # hand-off to BETR without a re-cast
-            return ret
+            return features.attach(ret, feats16, _lib.operand_prec(self.prec))   # explicit hand-off to BETR (features.py)

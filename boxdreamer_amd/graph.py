@@ -7,6 +7,8 @@ buffers, the graph is replayed, outputs are read from static buffers.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import hip_ops
@@ -33,8 +35,19 @@ class GraphedPath:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._run()
+        # The captured launches hold RAW device pointers into memory the modules own (workspaces allocated during the
+        # warm-up above, packed weights).  (1) Keep those tensors alive on this object, so nothing the modules do later can
+        # turn a replay into a use-after-free; (2) mark the modules frozen (weak reference), so an operation that would
+        # re-allocate or re-pack them -- a larger eager batch, .to(), a checkpoint load -- raises instead of leaving the
+        # graph replaying on stale weights.  Deleting the GraphedPath lifts the freeze.
+        enc_model = getattr(encoder, "model", encoder)
+        self._pinned = [enc_model._ws, decoder._ws, list(enc_model._packed.values()), list(decoder._packed.values())]
+        ref = weakref.ref(self)
+        enc_model._frozen_by = ref
+        decoder._frozen_by = ref
 
     def _run(self):
+        self.decoder.validate_inputs = False      # the one-hot mask check is a device sync (illegal while capturing)
         feats = self.encoder.predict(self.images)
         heat = self.decoder(self.bbox_feat, self.images, self.mask, feats, None)
         kp, kn, idx = hip_ops.decode_topk(heat, want_idx=self.want_idx)

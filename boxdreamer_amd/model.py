@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .betr import BETR
-from . import pnp
+from . import features, pnp
 from .box_utils import recover_bb8_corners_chw, solve_poses_device, solve_poses_host
 from .cache import merge_cached_features
 from .config import setup_camera_params, validate_model_config
@@ -48,6 +48,7 @@ class BoxDreamer(nn.Module):
         module_configs = validate_model_config(module_configs)
         self.bbox_representation = module_configs["bbox_representation"]
         self.dense_cfg = module_configs.get("dense_cfg", None)
+        self.pnp_on_device = bool(module_configs.get("pnp_on_device", False))
         module_configs, self.camera_dim, self.rotation_length = setup_camera_params(module_configs)
         self.module_configs = module_configs
 
@@ -95,8 +96,10 @@ class BoxDreamer(nn.Module):
                 if isinstance(query_ret, dict):                                   # coarse prediction only: dict is final
                     return query_ret
             else:
+                # .contiguous() returns a NEW tensor object when it has to copy; the operand-dtype copy of the features
+                # follows only an alias of the same storage (features.carry), otherwise BETR re-casts explicitly
                 query_ret = self.decoder(pose_feat.contiguous(), images.contiguous(), camera_mask,
-                                         rgb_feature.contiguous(), None)
+                                         features.carry(rgb_feature, rgb_feature.contiguous()), None)
             # the dense helpers re-pack the batch dict: re-read the views / query position (BoxDreamerModel.py:150-158)
             images = data["images"]
             B, T = images.shape[:2]
@@ -121,10 +124,17 @@ class BoxDreamer(nn.Module):
         norm_kp, kp_px, _ = recover_bb8_corners_chw(query_ret)                  # [B,8,2] each
         bbox_3d = data["bbox_3d"][camera_mask].float()
         K = data["non_ndc_intrinsics"][camera_mask].float()
-        if pnp._HAVE_CV2:    # the reference's own solver, on the host (one D2H of the corners per batch)
-            poses = torch.from_numpy(solve_poses_host(kp_px.cpu().numpy(), bbox_3d.cpu().numpy(), K.cpu().numpy()))
-        else:                # same published algorithm on the GPU, no host round trip (row f3)
+        # PnP stays on the host CPU (north_star; box_utils.py:139-199): ONE D2H of the corners per batch, then OpenCV's
+        # solvePnP when cv2 is importable, else this repo's restatement of its ITERATIVE algorithm -- whose parity against
+        # OpenCV is UN-PINNED in this image; `pose_solver` says which one produced `pred_poses`.
+        # The HIP solver (bd_solve_pnp, row f3) is opt-in: config["modules"]["pnp_on_device"] = True.
+        if self.pnp_on_device:
             poses = solve_poses_device(kp_px, bbox_3d, K)
+            data["pose_solver"] = "hip:bd_solve_pnp (DLT + LM, parity vs OpenCV un-pinned)"
+        else:
+            poses = torch.from_numpy(solve_poses_host(kp_px.cpu().numpy(), bbox_3d.cpu().numpy(), K.cpu().numpy()))
+            data["pose_solver"] = ("host:cv2.solvePnP" if pnp._HAVE_CV2
+                                   else "host:numpy DLT + LM restatement (parity vs OpenCV un-pinned)")
         pred_poses[camera_mask] = poses.to(pred_poses.device).to(pred_poses.dtype)
         data["regression_boxes"] = data["bbox_proj_crop"].clone()
         data["regression_boxes"][camera_mask] = norm_kp.to(data["regression_boxes"].dtype)

@@ -9,7 +9,9 @@
  * Conventions (all entry points):
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host];
  *   - the caller (PyTorch) owns every input / output / workspace buffer; the library never
- *     allocates, frees, synchronises or keeps state between calls;
+ *     allocates, frees, synchronises or keeps state between calls, and reads no environment
+ *     variables: everything that affects numerics or scheduling is an argument (the optional
+ *     launch trace at the end of this file is the only state, off by default);
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *   - return 0 on success, a negative BD_ERR_* for bad arguments, a positive hipError_t if a
  *     launch failed; no exceptions, no exit();
@@ -34,7 +36,7 @@
 extern "C" {
 #endif
 
-#define BD_ABI_VERSION 1
+#define BD_ABI_VERSION 2
 
 #define BD_DTYPE_BF16 0
 #define BD_DTYPE_F16 1
@@ -47,6 +49,13 @@ extern "C" {
 #define BD_PREC_FP8 4            /* OCP e4m3 operands for every Linear (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales,
                                     per-output-channel weight scale in the epilogue); attention stays bf16 (configs[4]) */
 #define BD_PREC_BF16_OUT_FP8 5   /* bd_attention[_q] only: bf16 attention whose output is stored as e4m3 */
+/* Whole-path entry points only (bd_encoder_forward / bd_decoder_forward / *_workspace_bytes): attention policy of the
+ * strict family.  Operand layout and GEMMs are BD_PREC_BF16X3's; the unit operators do not accept these values.
+ *   BD_PREC_BF16X3           f16 single-pass attention where q, k are RMS-normalised (BETR), split-bf16 attention in DINOv2
+ *   BD_PREC_BF16X3_ATTN_X3   split-bf16 attention everywhere
+ *   BD_PREC_BF16X3_ATTN_F16  f16 single-pass attention everywhere (measurement: misses the 1e-3 bar) */
+#define BD_PREC_BF16X3_ATTN_X3 6
+#define BD_PREC_BF16X3_ATTN_F16 7
 
 #define BD_OK 0
 #define BD_ERR_SHAPE (-1)

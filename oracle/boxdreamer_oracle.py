@@ -182,7 +182,7 @@ def betr_forward(sd: dict, pose_feat: torch.Tensor, masks: torch.Tensor, rgb_fea
     pf = F.linear(pf, sd["bbox_emb.weight"], sd["bbox_emb.bias"])
     # betr.py:286-290 query substitution (pose stream only)
     pf = pf.clone()
-    pf[masks] = sd["bbox_learnable_query"].expand(B, P, C)
+    pf[masks] = sd["bbox_learnable_query"].expand(B, P, C).to(pf.dtype)     # the reference casts too (betr.py:287-289)
     # betr.py:351-401 fuse + positional table
     g = int(P ** 0.5)
     x = pf + r + sincos_pos_embed(C, g).reshape(1, 1, P, C)
@@ -266,6 +266,6 @@ def boxdreamer_forward(data: dict, betr_sd: dict, dino_sd: dict, nhead: int = 8,
     logits, heat = betr_forward(betr_sd, data["bbox_feat"], mask, feats, nhead, patch)
     norm, kp, idx = recover_bb8_corners(heat)
     pred_bbox = data["bbox_feat"].float().clone()
-    pred_bbox[mask] = heat
+    pred_bbox[mask] = heat.to(pred_bbox.dtype)
     return {"camera_mask": mask, "rgb_feat": feats, "logits": logits, "heat": heat,
             "pred_bbox": pred_bbox, "corners_px": kp, "corners_norm": norm, "topk_idx": idx}

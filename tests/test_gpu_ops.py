@@ -159,6 +159,43 @@ def test_attention(hip, prec, batch, seq, heads, hd):
     assert err < 6 * EPS[prec] * max(1.0, ref.abs().max().item()) + 2e-5, (prec, err)
 
 
+@pytest.mark.parametrize("variant", ["f16_out_bf16x3", "bf16_out_fp8"])
+@pytest.mark.parametrize("batch,seq,heads,hd", [(2, 261, 12, 64), (1, 1536, 8, 96), (1, 4352, 8, 96), (3, 70, 2, 64)])
+def test_attention_mixed_output_variants(hip, variant, batch, seq, heads, hd):
+    """The two attention variants the default modes really run, against fp64 torch on the operands as stored:
+      BD_PREC_F16_OUT_BF16X3  (strict mode, BETR): f16 qkv in, one f16 MFMA pass, split-bf16 (hi, lo) planes out;
+      BD_PREC_BF16_OUT_FP8    (fp8 mode): bf16 qkv in, e4m3 out.
+    seq 4352 = BASELINE configs[3] (T = 17)."""
+    from boxdreamer_amd import _lib
+    qkv = _rand("attq", (batch, seq, 3, heads, hd), 1.0)
+    qkv[:, :, 0] *= 1.7
+    if seq >= 200:
+        qkv[:, 150, 1] = qkv[:, 7, 0] * 3.0
+    in_prec = "fp16" if variant == "f16_out_bf16x3" else "bf16"
+    t = hip_ops.to_operand(qkv.reshape(batch * seq, -1).cuda(), in_prec)
+    src = _q(qkv.reshape(batch * seq, -1), in_prec).reshape(batch, seq, 3, heads, hd).double()
+    q, k, v = (src[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = (((q @ k.transpose(-1, -2)) * hd ** -0.5).softmax(-1) @ v).permute(0, 2, 1, 3).float()
+    lib = _lib.load()
+    if variant == "f16_out_bf16x3":
+        out = torch.empty((2, batch * seq, heads * hd), dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.bd_attention(_lib.ptr(t), 0, _lib.ptr(out), out[0].numel(), batch, seq, heads, hd, hd ** -0.5,
+                                    _lib.PREC_F16_OUT_BF16X3, _lib.stream()), "bd_attention")
+        got = (out[0].float() + out[1].float()).cpu().reshape(batch, seq, heads, hd)
+        tol = 6 * 2.0 ** -11 * max(1.0, ref.abs().max().item()) + 2e-5      # f16 P and V rounding; the (hi, lo) store is ~2^-16
+    else:
+        out = torch.empty((batch * seq, heads * hd), dtype=torch.float8_e4m3fn, device="cuda")
+        _lib.check(lib.bd_attention(_lib.ptr(t), 0, _lib.ptr(out), 0, batch, seq, heads, hd, hd ** -0.5,
+                                    _lib.PREC_BF16_OUT_FP8, _lib.stream()), "bd_attention")
+        got = out.float().cpu().reshape(batch, seq, heads, hd)
+        # e4m3 output rounding: 2^-4 relative (normal range >= 2^-6), 2^-10 absolute below it; plus the bf16 pass
+        err = (got - ref).abs()
+        assert (err <= ref.abs() * 2.0 ** -4 + 2.0 ** -10 + 6 * 2.0 ** -8).all(), err.max().item()
+        return
+    err = (got - ref).abs().max().item()
+    assert err < tol, (variant, err)
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_im2col_and_patchify(hip, prec):
     data = synth.make_batch(seed=21, B=1, T=2)

@@ -1,0 +1,68 @@
+"""Where does a GEMM tile's time go?  Measurement tool (not part of the product library).
+
+    python tools/gemm_phase_probe.py build            # here (no GPU): tools/_probe/libbd_probe.so = gemm.hip + trace.hip with -DBD_GEMM_PROBE
+    python tools/gemm_phase_probe.py run M N K [prec] # on the GPU box
+
+Every wave stamps the shader clock (s_memtime) at three points of every K-slab -- before the slab barrier, after it, after
+issuing the next slab's LDS-DMA -- plus kernel start, mainloop end, epilogue start and end.  Printed: mean cycles per phase
+over the workgroups of the first round, for the older (wave 0) and younger (wave 4) wave of SIMD 0."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "_probe", "libbd_probe.so")
+
+
+def build():
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    src = os.path.join(ROOT, "boxdreamer_amd", "csrc")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-DBD_GEMM_PROBE",
+           "-I", os.path.join(ROOT, "include"), "-shared", "-o", LIB, os.path.join(src, "gemm.hip"), os.path.join(src, "trace.hip")]
+    subprocess.check_call(cmd)
+    print("built", LIB)
+
+
+def run(M, N, K, prec="bf16"):
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    os.environ["BOXDREAMER_HIP_LIB"] = LIB
+    from boxdreamer_amd import _lib, hip_ops
+    lib = _lib.load()
+    a = hip_ops.to_operand(torch.randn(M, K, device="cuda"), prec)
+    w = hip_ops.to_operand(torch.randn(N, K, device="cuda") * 0.05, prec)
+    b = torch.randn(N, device="cuda")
+    nwave = 8
+    buf = torch.zeros(1024 * nwave * 64, dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        hip_ops.gemm(a, w, b, prec=prec)
+    lib.bd_gemm_probe_set.argtypes = [C.c_void_p]
+    assert lib.bd_gemm_probe_set(C.c_void_p(buf.data_ptr())) == 0
+    torch.cuda.synchronize()
+    hip_ops.gemm(a, w, b, prec=prec)
+    torch.cuda.synchronize()
+    ts = buf.cpu().numpy().astype(np.uint32).reshape(1024, nwave, 64)
+    nk = min(K // (32 if prec == "bf16x3" else (128 if prec == "fp8" else 64)), 20)
+    first = ts[:256]                                   # first round: one workgroup per CU
+    for wv in (0, 4):
+        t = first[:, wv, :].astype(np.int64)
+        d = lambda i, j: ((t[:, i] - t[:, j]) & 0xFFFFFFFF).astype(np.float64)
+        bar = np.stack([d(3 * k + 1, 3 * k) for k in range(nk)], 1)
+        dma = np.stack([d(3 * k + 2, 3 * k + 1) for k in range(nk)], 1)
+        mma = np.stack([d(3 * (k + 1), 3 * k + 2) for k in range(nk - 1)] + [d(61, 3 * (nk - 1) + 2)], 1)
+        print(f"wave {wv}: per-slab cycles (mean over 256 workgroups)")
+        print("  barrier wait :", np.round(bar.mean(0)).astype(int).tolist())
+        print("  DMA issue    :", np.round(dma.mean(0)).astype(int).tolist())
+        print("  frags + MFMA :", np.round(mma.mean(0)).astype(int).tolist())
+        print(f"  prologue {d(0, 60).mean():.0f}  mainloop {d(61, 0).mean():.0f}  sync {d(62, 61).mean():.0f}  epilogue {d(63, 62).mean():.0f}"
+              f"  total {d(63, 60).mean():.0f} cycles;  slab mean: barrier {bar[:, 1:].mean():.0f} dma {dma[:, :-1].mean():.0f} mfma {mma.mean():.0f}")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    else:
+        run(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else "bf16")
