@@ -22,7 +22,26 @@
 // Experiments that did NOT pay (deeper LDS-DMA rings, mid-slab barriers, ping-pong wave groups, 256x128 tiles at one or
 // two workgroups per CU, a persistent tile loop with the epilogue overlapped, pinned fragment prefetch) and the counters
 // behind the choices: profiles/r1_gemm_experiments.md, profiles/r1_gemm_pmc.md.
+#ifndef BD_STORE_NT
 #define BD_STORE_NT 1   // non-temporal 16/8-bit epilogue stores (bd_common.h: store_cvt)
+#endif
+#ifndef BD_EXP_NOSTORE
+#define BD_EXP_NOSTORE 0 // measurement builds only: 1 drops the 16-bit epilogue stores (invalid results) to time the rest
+#endif
+// Compile-time kernel-selection policy, for A/B builds loaded through BOXDREAMER_HIP_LIB (never an environment switch):
+// 0 = one-tile-per-workgroup kernels only (round 1), 1 = persistent producer/consumer kernel with 256x192 tiles where they
+// fit and fill the CUs' rounds (default).
+#ifndef BD_GEMM_POLICY
+#define BD_GEMM_POLICY 1
+#endif
+// Epilogue of the persistent kernel: 0 = LDS-staged, full-line 16-byte stores (default); 1 = transposed accumulators with
+// row-per-lane 16-byte accesses straight from registers -- measured 2.1x SLOWER (27-29k vs 12.8k cycles per 256x192 tile: a
+// wave store touching 32 rows x 32 bytes is issue-bound in the texture path), kept for the record.
+#ifndef BD_PC_EPI
+#define BD_PC_EPI 0
+#endif
+
+
 #include "bd_common.h"
 
 #ifdef BD_GEMM_PROBE
@@ -33,8 +52,10 @@ extern "C" int bd_gemm_probe_set(void* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(bd_probe_buf), &buf, sizeof(buf));
 }
 #define BD_PROBE(idx) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((idx) < 64) probe_ts = (lane == (idx)) ? (unsigned)t__ : probe_ts; }
+#define BD_PROBE_IF(c, idx) { if (c) BD_PROBE(idx) }
 #else
 #define BD_PROBE(idx)
+#define BD_PROBE_IF(c, idx)
 #endif
 
 namespace {
@@ -76,6 +97,18 @@ __device__ __forceinline__ void slab_barrier() {
     __builtin_amdgcn_s_barrier();                         // ... and everyone else's; the other buffer is free
     asm volatile("" ::: "memory");
 }
+// LDS-DMA with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: the producer wave of
+// gemm_kernel_pc keeps one offset VGPR per piece and advances K on the scalar side.
+__device__ __forceinline__ void glds16_s(unsigned voff, const unsigned char* sbase, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
+// workgroup barrier without any counter wait of its own (consumers have nothing outstanding that matters; the producer waits
+// for its DMA explicitly): a raw s_barrier fenced against compiler motion of LDS accesses
+__device__ __forceinline__ void pc_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p);
 }
@@ -83,13 +116,34 @@ __device__ __forceinline__ unsigned lds_offset_of(const void* p) {
 // out_f32 codes
 enum { OUT_OPERAND = 0, OUT_F32 = 1, OUT_F16 = 2, OUT_BF16 = 3 };
 
+// Accumulators start at the bias of their column (C fragment: col = lane & 31 of tile j) instead of zero, so no epilogue
+// carries a bias add or keeps bias vectors live; with a per-channel weight scale (e4m3) the start value is bias / scale and
+// the epilogue's  scale * acc  restores it.  Every kernel uses the same convention (results stay bit-identical across tile
+// shapes: the property tests compare a sample run alone with the same sample inside a batch).
+template <int MI, int NI>
+__device__ __forceinline__ void acc_init_bias(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wn0, int lane) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = wn0 + j * 32 + (lane & 31);
+        float b = 0.f;
+        if (p.bias && col < p.N) {
+            b = p.bias[col];
+            if (p.wscale) b = b / p.wscale[col];
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+    }
+}
+
 // ---- scalar fallback epilogue (N not a multiple of 8 / unaligned pointers): C fragment = (col = lane & 31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5)); operand-dtype (16-bit) or fp32 outputs only
 template <class T, int NS, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wm0, int wn0, int lane) {
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int M = p.M, N = p.N;
-    const float* bias = p.bias;
+    const float* bias = nullptr;       // the bias is folded into the accumulator initialisation (acc_init_bias)
     const float* resid = p.resid;
     const float* addtab = p.addtab;
     const float* wscale = p.wscale;
@@ -143,13 +197,18 @@ __device__ __forceinline__ void gemm_epilogue(const bd_gemm_args& p, f32x16 (&ac
 // half-wave), read back with ds_read_b128 as 4 (fp32 out) or 8 (narrow out) consecutive columns per lane, the residual
 // / table rows are fetched as 16-byte vectors in batches, and the result leaves as full-line stores.  Same-wave LDS
 // traffic is ordered, so no workgroup barrier is needed between chunks.
-template <class T, int NS, int MI, int NI>
+// SR: rows of the wave tile staged per pass through the scratch (32 = one MFMA row chunk; 16 = half of it, for kernels whose
+// scratch must fit a smaller LDS region: registers r with (r >> 2) in {2 hc, 2 hc + 1} are exactly rows 16 hc .. 16 hc + 15).
+// LEAN: register-frugal form for kernels capped at 168 VGPRs (gemm_kernel_pc: three waves on one SIMD): per-column bias /
+// scale vectors are re-loaded per column block instead of kept live across the whole tile, and the fp32 path batches its
+// global reads two passes at a time instead of four.
+template <class T, int NS, int MI, int NI, int SR = 32, bool LEAN = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], unsigned char* scratch,
                                                   int wm0, int wn0, int lane) {
     constexpr int COLS = NI * 32;                      // wave-tile width (fp32 words per scratch row)
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int M = p.M, N = p.N;
-    const float* bias = p.bias;
+    const float* bias = nullptr;       // the bias is folded into the accumulator initialisation (acc_init_bias)
     const float* resid = p.resid;
     const float* addtab = p.addtab;
     const float* wscale = p.wscale;
@@ -162,7 +221,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
     if (p.out_f32 == OUT_F32) {
         constexpr int LPR = CW / 4;                    // lanes per row (4 floats each)
         constexpr int RPI = 64 / LPR;                  // rows per pass
-        constexpr int PASSES = 32 / RPI;
+        constexpr int PASSES = SR / RPI;
         const int c4 = lane % LPR, rsub = lane / LPR;
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
         f32x4 bv4[NCB], sv4[NCB];
@@ -176,15 +235,16 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
             if (wscale && cok[cb]) sv4[cb] = *(const f32x4*)(wscale + gc);
         }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int ih = 0; ih < MI * (32 / SR); ++ih) {
+            const int i = ih / (32 / SR), hc = ih % (32 / SR);
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    sc[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
+                for (int r = hc * (SR / 2); r < (hc + 1) * (SR / 2); ++r)
+                    sc[((r & 3) + 8 * ((r >> 2) - hc * (SR / 8)) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
             // global reads are issued in batches of PB passes (register budget); native vector types only -- HIP's
             // float4 struct in a local array lands in scratch
-            constexpr int PB = PASSES > 4 ? 4 : PASSES;
+            constexpr int PB = LEAN ? (PASSES > 2 ? 2 : PASSES) : (PASSES > 4 ? 4 : PASSES);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const int gc = wn0 + cb * CW + c4 * 4;
@@ -195,7 +255,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
                     bool ok[PB];
 #pragma unroll
                     for (int u = 0; u < PB; ++u) {
-                        const int gr = wm0 + i * 32 + (t0 + u) * RPI + rsub;
+                        const int gr = wm0 + i * 32 + hc * SR + (t0 + u) * RPI + rsub;
                         ok[u] = cok[cb] && gr < M;
                         const int grc = gr < M ? gr : M - 1;
                         orow[u] = rpg_in > 0 ? (int64_t)(grc / rpg_in) * rpg_out + grc % rpg_in + row_off : (int64_t)grc;
@@ -220,48 +280,57 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
     } else {
         constexpr int LPR = CW / 8;                    // lanes per row (8 output columns each)
         constexpr int RPI = 64 / LPR;
-        constexpr int PASSES = 32 / RPI;
+        constexpr int PASSES = SR / RPI;
         const int c8 = lane % LPR, rsub = lane / LPR;
-        float bv[NCB][8], sv[NCB][8];
+        constexpr int NBV = LEAN ? 1 : NCB;            // LEAN: one live bias / scale vector, re-loaded per column block
+        float bv[NBV][8], sv[NBV][8];
         bool cok[NCB];
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
+        auto load_bias_scale = [&](int cb, int slot) {
             const int gc = wn0 + cb * CW + c8 * 8;
             cok[cb] = gc < N;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { bv[cb][e] = 0.f; sv[cb][e] = 1.f; }
+            for (int e = 0; e < 8; ++e) { bv[slot][e] = 0.f; sv[slot][e] = 1.f; }
             if (bias && cok[cb]) {
                 const f32x4 b0 = *(const f32x4*)(bias + gc), b1 = *(const f32x4*)(bias + gc + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { bv[cb][e] = b0[e]; bv[cb][4 + e] = b1[e]; }
+                for (int e = 0; e < 4; ++e) { bv[slot][e] = b0[e]; bv[slot][4 + e] = b1[e]; }
             }
             if (wscale && cok[cb]) {
                 const f32x4 s0 = *(const f32x4*)(wscale + gc), s1 = *(const f32x4*)(wscale + gc + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { sv[cb][e] = s0[e]; sv[cb][4 + e] = s1[e]; }
+                for (int e = 0; e < 4; ++e) { sv[slot][e] = s0[e]; sv[slot][4 + e] = s1[e]; }
             }
+        };
+        if constexpr (!LEAN) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) load_bias_scale(cb, cb);
         }
         const int out_mode = p.out_f32;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int ih = 0; ih < MI * (32 / SR); ++ih) {
+            const int i = ih / (32 / SR), hc = ih % (32 / SR);
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    sc[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
+                for (int r = hc * (SR / 2); r < (hc + 1) * (SR / 2); ++r)
+                    sc[((r & 3) + 8 * ((r >> 2) - hc * (SR / 8)) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const int gc = wn0 + cb * CW + c8 * 8;
+                constexpr int dummy_ = 0;
+                const int bs = LEAN ? 0 : cb;
+                if constexpr (LEAN) load_bias_scale(cb, 0);
+                (void)dummy_;
 #pragma unroll
                 for (int t = 0; t < PASSES; ++t) {
-                    const int gr = wm0 + i * 32 + t * RPI + rsub;
+                    const int gr = wm0 + i * 32 + hc * SR + t * RPI + rsub;
                     const float* src = sc + (t * RPI + rsub) * COLS + cb * CW + c8 * 8;
                     const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = a0[e] * sv[cb][e] + bv[cb][e]; v[4 + e] = a1[e] * sv[cb][4 + e] + bv[cb][4 + e]; }
+                    for (int e = 0; e < 4; ++e) { v[e] = a0[e] * sv[bs][e] + bv[bs][e]; v[4 + e] = a1[e] * sv[bs][4 + e] + bv[bs][4 + e]; }
                     if (act == BD_ACT_GELU) gelu_n<GeluKind<T, NS>::value, 8>(v);   // 16/8-bit result: fitted forms (bd_common.h)
-                    if (cok[cb] && gr < M) {
+                    if (cok[cb] && gr < M && !BD_EXP_NOSTORE) {
                         const int64_t orow = rpg_in > 0 ? (int64_t)(gr / rpg_in) * rpg_out + gr % rpg_in + row_off : (int64_t)gr;
                         if (addtab) {
                             const float* tp = addtab + (int64_t)(gr % tab_rows) * N + gc;
@@ -347,12 +416,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gem
     }
 
     f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    acc_init_bias<MI, NI>(p, acc, n0 + wn * (NI * 32), lane);
 
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int nk = p.K / BK;
@@ -433,6 +497,441 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gem
 #endif
 }
 
+// ---- row-per-lane epilogue for TRANSPOSED accumulators (gemm_kernel_pc).  The persistent kernel issues its MFMAs with the
+// operand roles swapped (D^T = W . A^T): a lane then owns output row (lane & 31) of tile i and, per 32-column tile j, the
+// sixteen columns  8 q + 4 h + c  (q = r >> 2, c = r & 3, h = lane >> 5) -- four CONSECUTIVE columns per register quad.  Every
+// epilogue operand is therefore a 16-byte global access straight from / to registers: fp32 outputs (residual stream) load
+// the residual quad, add and store it; 16-bit outputs pack a quad to 8 bytes and one v_permlane32_swap per dword pairs the
+// two half-waves' quads into 16-byte stores (lower lanes: columns 16 k .. 16 k + 7 of the tile, upper lanes: the next eight).
+// No LDS round trip (the LDS-staged epilogue spends ~3000 cycles per tile in ds_write_b32 alone and needs a stage of the
+// operand ring as scratch), a fraction of the registers, and nothing to synchronise with the producers.
+template <int MI, int NI>
+__device__ __forceinline__ void acc_init_bias_t(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wn0, int lane) {
+    const int lhalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = wn0 + j * 32 + q * 8 + lhalf * 4;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && col < p.N) {
+                b = *(const f32x4*)(p.bias + col);
+                if (p.wscale) b = b / *(const f32x4*)(p.wscale + col);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[i][j][q * 4 + c] = b[c];
+        }
+}
+
+template <class T> __device__ __forceinline__ unsigned pack2_16(float x, float y) {
+    typedef __attribute__((__vector_size__(2 * sizeof(T)))) T vec2;
+    vec2 v; v[0] = (T)x; v[1] = (T)y;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// 16-bit image of one row of a 32-column tile: g[k] = this lane's quad k (columns 8 k + 4 h + c) in final fp32 form.  One
+// v_permlane32_swap per dword (lanes 32-63 of the first operand <-> lanes 0-31 of the second) leaves the lower lanes with
+// [own quad k | upper lanes' quad k] = columns 8 k .. 8 k + 7 and the upper lanes with [lower lanes' quad k+1 | own quad k+1] =
+// the next eight: one 16-byte store per lane and pair of quads.  rb = &out[row][first column of the tile]; n_left = N - that column.
+template <class T>
+__device__ __forceinline__ void store_row_pairs16(T* rb, const float (&g)[4][4], int lhalf, bool row_ok, int n_left) {
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {
+        const unsigned ax = pack2_16<T>(g[k][0], g[k][1]), ay = pack2_16<T>(g[k][2], g[k][3]);
+        const unsigned bx = pack2_16<T>(g[k + 1][0], g[k + 1][1]), by = pack2_16<T>(g[k + 1][2], g[k + 1][3]);
+        const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+        const u128 v = {rx[0], ry[0], rx[1], ry[1]};
+        const int col = k * 8 + lhalf * 8;
+        if (row_ok && col < n_left) __builtin_nontemporal_store(v, (u128*)(rb + col));   // written once, read by a later kernel
+    }
+}
+
+template <class T, int NS, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue_rowlane(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wm0, int wn0, int lane) {
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int M = p.M, N = p.N;
+    const float* resid = p.resid;
+    const float* addtab = p.addtab;
+    const float* wscale = p.wscale;
+    const int act = p.act, out_mode = p.out_f32;
+    const int64_t ldr = p.ldr, ldo = p.ldo, out_plane = p.out_plane;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int gr = wm0 + i * 32 + lrow;
+        const bool rok = gr < M;
+        const int grc = rok ? gr : M - 1;
+        const int64_t orow = p.rpg_in > 0 ? (int64_t)(grc / p.rpg_in) * p.rpg_out + grc % p.rpg_in + p.row_off : (int64_t)grc;
+        const float* rrow = resid ? resid + orow * ldr : nullptr;
+        const float* trow = addtab ? addtab + (int64_t)(grc % p.tab_rows) * N : nullptr;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int c0 = wn0 + j * 32;                   // first column of this 32-wide tile
+            // the column-validity test is per quad and, because N % 8 == 0, the same for both quads of a 16-byte store pair
+            float g[4][4];
+            f32x4 rv[4], tv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gc = c0 + q * 8 + lhalf * 4;
+                const bool ok = rok && gc < N;
+                rv[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                tv[q] = rv[q];
+                if (rrow && ok) rv[q] = *(const f32x4*)(rrow + gc);
+                if (trow && ok) tv[q] = *(const f32x4*)(trow + gc);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gc = c0 + q * 8 + lhalf * 4;
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = acc[i][j][q * 4 + c];
+                if (wscale) {
+                    const f32x4 sv = gc < N ? *(const f32x4*)(wscale + gc) : (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] *= sv[c];
+                }
+                if (act == BD_ACT_GELU) {
+                    if (out_mode == OUT_F32) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
+                    } else {
+                        gelu_n<GeluKind<T, NS>::value, 4>(v);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) g[q][c] = v[c] + tv[q][c] + rv[q][c];
+            }
+            if (out_mode == OUT_F32) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gc = c0 + q * 8 + lhalf * 4;
+                    if (rok && gc < N) *(f32x4*)((float*)p.out + orow * ldo + gc) = (f32x4){g[q][0], g[q][1], g[q][2], g[q][3]};
+                }
+            } else {
+                if (out_mode == OUT_F16) {
+                    store_row_pairs16<_Float16>((_Float16*)p.out + orow * ldo + c0, g, lhalf, rok, N - c0);
+                } else if (out_mode == OUT_BF16) {
+                    store_row_pairs16<__bf16>((__bf16*)p.out + orow * ldo + c0, g, lhalf, rok, N - c0);
+                } else if constexpr (sizeof(T) == 2) {
+                    T* rb = (T*)p.out + orow * ldo + c0;
+                    store_row_pairs16<T>(rb, g, lhalf, rok, N - c0);                 // plane 0: hi = T(g)
+                    if constexpr (NS == 2) {
+                        float lo[4][4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) lo[q][c] = g[q][c] - to_f32<T>(from_f32<T>(g[q][c]));
+                        store_row_pairs16<T>(rb + out_plane, lo, lhalf, rok, N - c0);
+                    }
+                } else {
+                    // e4m3 operand output: a quad is one dword; one swap pairs the half-waves' quads into 8-byte stores
+                    fp8e4* rb = (fp8e4*)p.out + orow * ldo + c0;
+#pragma unroll
+                    for (int k = 0; k < 4; k += 2) {
+                        int a0 = 0, b0 = 0;
+                        a0 = __builtin_amdgcn_cvt_pk_fp8_f32(g[k][0], g[k][1], a0, false);
+                        a0 = __builtin_amdgcn_cvt_pk_fp8_f32(g[k][2], g[k][3], a0, true);
+                        b0 = __builtin_amdgcn_cvt_pk_fp8_f32(g[k + 1][0], g[k + 1][1], b0, false);
+                        b0 = __builtin_amdgcn_cvt_pk_fp8_f32(g[k + 1][2], g[k + 1][3], b0, true);
+                        const auto rx = __builtin_amdgcn_permlane32_swap((unsigned)a0, (unsigned)b0, false, false);
+                        if (rok && c0 + k * 8 + lhalf * 8 < N) *(uint2*)(rb + k * 8 + lhalf * 8) = make_uint2(rx[0], rx[1]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Producer / consumer, persistent form of the same GEMM  (round 2).
+//
+// Why (tools/gemm_phase_probe.py, profiles/r2_gemm_phase_probe.md): in gemm_kernel_glds every wave issues its share of the
+// next slab's LDS-DMA right after the slab barrier.  The CU's texture-address path accepts one 1-KiB global_load_lds per ~23
+// cycles, so the 64 pieces of a 256x256x64 slab keep the ISSUING waves blocked for 580 (older wave of a SIMD) to 1470 cycles
+// (younger wave) per slab, during which they issue no MFMA: a slab takes ~3300 cycles for 2048 cycles of matrix work per
+// SIMD, and the two waves of a SIMD end up running their MFMA phases one after the other.
+//
+// Here the workgroup has WM*WN consumer waves (MFMA + epilogue, never a VMEM instruction inside the K loop) and ONE producer
+// wave that issues every LDS-DMA piece (SGPR base + 32-bit VGPR offset form) and is the only wave that waits on vmcnt.  One
+// s_barrier per slab:  B(kt) = "slab kt has landed (the producer waited for it) and every consumer is done with slab kt-1";
+// after B(kt) the producer refills the buffer slab kt-1 lived in.  The kernel is persistent (grid = CUs, static XCD-aware
+// tile lists), which buys two more overlaps: the first slab of the NEXT tile is fetched under the last slab of this one, and
+// the epilogue's global stores are not waited for by anyone -- they drain under the next tile's MFMAs (in the one-tile kernel
+// all CUs write their tiles at the same moment: QKV's 128 KiB per CU sit at the HBM write floor of ~10k cycles while the
+// matrix pipes idle).  The MFMAs run with swapped operand roles (D^T = W . A^T) so that a lane owns output ROWS: the epilogue
+// is 16-byte global accesses straight from registers (gemm_epilogue_rowlane), needs no LDS, and both stages of the ring refill
+// under it.  Barriers per tile: nk (B) + 1 (X: every consumer is done reading the last slab).
+// What still bounds it (profiles/r2_gemm_phase_probe.md): per slab the producers need ~1000 cycles to issue + ~840 to land
+// the next slab (a 2-stage ring cannot hide that latency: 2045 cycles per slab for 1536 of matrix work per SIMD), and the
+// epilogue's global stores: dropping them takes QKV from 909 to 1211 TF/s and fc1 from 741 to 1074.  Non-temporal vs plain
+// stores: equal.  Start-up staggers that spread the CUs' epilogues over the tile period -- 4 phase groups inside every XCD, or
+// one phase per XCD -- were measured at +1 % / -9 % (QKV) and -7 % / -2 % (fc1): dropped.
+
+template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NPW>
+__global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const bd_gemm_args p) {
+    typedef typename Op16<T>::vec8 frag_t;
+    constexpr int ESZ = OpGeom<T>::ESZ, KSTEP = OpGeom<T>::KSTEP, CPF = OpGeom<T>::CPF;
+    constexpr int NCW = WM * WN;                      // consumer waves; waves NCW .. NCW + NPW - 1 are producers
+    constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32;
+    constexpr int ROWB = BK * ESZ;
+    constexpr int CH = ROWB / 16;
+    constexpr int RPP = 64 / CH;
+    constexpr int A_BYTES = TBM * ROWB, W_BYTES = TBN * ROWB;
+    constexpr int PA = A_BYTES / 1024, PW = W_BYTES / 1024;       // 1-KiB DMA pieces per plane per slab
+    constexpr int STAGE_BYTES = (A_BYTES + W_BYTES) * NS;
+    constexpr int KS = BK / KSTEP;
+    static_assert(KS >= 1 && CH * 16 == ROWB && (CH == 4 || CH == 8) && A_BYTES % 1024 == 0 && W_BYTES % 1024 == 0, "slab geometry");
+    static_assert(PA % NPW == 0 && PW % NPW == 0, "pieces split evenly over the producer waves");
+    constexpr int SR = (NCW * 32 * NI * 32 * 4 <= STAGE_BYTES) ? 32 : 16;      // LDS-staged epilogue: scratch rows per pass
+    static_assert(BD_PC_EPI == 1 || NCW * SR * NI * 32 * 4 <= STAGE_BYTES, "the epilogue scratch must fit one stage");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = p.M, N = p.N;
+    const int nk = p.K / BK;
+
+    // static tile list: XCD x (= blockIdx % 8) owns a contiguous run of logical tile ids (grouped raster, as in
+    // tile_coords_t); its workgroups walk that run with stride = workgroups on the XCD, so the CUs of an XCD always work on
+    // consecutive tiles (a compact patch of the output: shared A panels / W tiles stay in that XCD's L2).
+    const int tilesM = (M + TBM - 1) / TBM, tilesN = (N + TBN - 1) / TBN, nt = tilesM * tilesN;
+    const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7;
+    const int tq = nt >> 3, tr = nt & 7;
+    const int t_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int t_end = t_begin + tq + (xcd < tr ? 1 : 0);
+    const int stride = (nwg - xcd + 7) >> 3;          // workgroups living on this XCD
+    constexpr int GROUP_M = TBM >= 256 ? 4 : 8;
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int per_group = GROUP_M * tilesN;
+        const int g = t / per_group, in_g = t % per_group;
+        const int gm0 = g * GROUP_M;
+        const int gh = (tilesM - gm0) < GROUP_M ? (tilesM - gm0) : GROUP_M;
+        m0 = (gm0 + in_g % gh) * TBM;
+        n0 = (in_g / gh) * TBN;
+    };
+    const unsigned lds_off = lds_offset_of(lds);
+
+    if (wid >= NCW) {
+        // ------------------------------------------------------------------ producers (wave pw takes pieces pw, pw + NPW, ...)
+        const int pw = wid - NCW;
+        // Per-lane byte offsets of the 1-KiB pieces inside a tile are the same for every tile (piece j = tile rows
+        // j*RPP .. j*RPP+RPP-1, source-side swizzled chunk); the tile origin, the K position and the plane go into the
+        // scalar base.  Rows past the edge of the tensor are clamped with one v_min against the tile's last valid byte
+        // (they load in-bounds garbage whose results the epilogue discards).
+        const unsigned lda_b = (unsigned)(p.lda * ESZ), ldw_b = (unsigned)(p.ldw * ESZ);
+        unsigned offA[PA / NPW], offW[PW / NPW];
+#pragma unroll
+        for (int j = 0; j < PA / NPW; ++j) {
+            const int row = (j * NPW + pw) * RPP + lane / CH;
+            offA[j] = (unsigned)row * lda_b + swz_chunk<CH>(row, lane % CH) * 16;
+        }
+#pragma unroll
+        for (int j = 0; j < PW / NPW; ++j) {
+            const int row = (j * NPW + pw) * RPP + lane / CH;
+            offW[j] = (unsigned)row * ldw_b + swz_chunk<CH>(row, lane % CH) * 16;
+        }
+        const int64_t a_plane = p.a_plane * ESZ, w_plane = p.w_plane * ESZ;
+        auto issue = [&](int stage, int m0, int n0, int kt) {
+            const int rows_a = (M - m0) < TBM ? (M - m0) : TBM, rows_w = (N - n0) < TBN ? (N - n0) : TBN;
+            const unsigned lim_a = (unsigned)(rows_a - 1) * lda_b + (CH - 1) * 16, lim_w = (unsigned)(rows_w - 1) * ldw_b + (CH - 1) * 16;
+            const unsigned st = lds_off + stage * STAGE_BYTES + pw * 1024;
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const unsigned char* ba = (const unsigned char*)p.A + (int64_t)m0 * lda_b + (int64_t)kt * ROWB + s2 * a_plane;
+                const unsigned char* bw = (const unsigned char*)p.W + (int64_t)n0 * ldw_b + (int64_t)kt * ROWB + s2 * w_plane;
+#pragma unroll
+                for (int j = 0; j < PA / NPW; ++j)
+                    glds16_s(offA[j] < lim_a ? offA[j] : lim_a, ba, st + s2 * A_BYTES + j * NPW * 1024);
+#pragma unroll
+                for (int j = 0; j < PW / NPW; ++j)
+                    glds16_s(offW[j] < lim_w ? offW[j] : lim_w, bw, st + NS * A_BYTES + s2 * W_BYTES + j * NPW * 1024);
+            }
+        };
+#ifdef BD_GEMM_PROBE
+        unsigned probe_ts = 0;
+#endif
+        // Issue cursor: slab number `ig` of this workgroup's slab sequence (all its tiles, K-slab by K-slab) is the next one
+        // to fetch, into stage ig & 1.  Consumers are released into slab g by barrier B(g); after B(g) the stage of slab g-1
+        // is free, so slab g+1 may be fetched.  At a tile boundary the consumers signal "done with the tile's last slab" with
+        // one extra barrier X before they start their (LDS-free) epilogue: the producers then already fetch the SECOND slab
+        // of the next tile, so both of its first slabs land while the epilogue runs.
+        int ig = 0, it = t_begin + (bid >> 3), ikt = 0, im0 = 0, in0 = 0;
+        if (it < t_end) tile_origin(it, im0, in0);
+        auto issue_next = [&]() {
+            if (it >= t_end) return;
+            issue(ig & 1, im0, in0, ikt);
+            ++ig;
+            if (++ikt == nk) {
+                ikt = 0;
+                it += stride;
+                if (it < t_end) tile_origin(it, im0, in0);
+            }
+        };
+        issue_next();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int g = 0;
+        for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
+            for (int kt = 0; kt < nk; ++kt) {
+                BD_PROBE_IF(g < 20, g * 3)
+                pc_barrier();                          // B(g): slab g landed; slab g-1 is dead
+                BD_PROBE_IF(g < 20, g * 3 + 1)
+                if (ig == g + 1) issue_next();         // slab g+1 (unless it was fetched at the tile boundary already)
+                BD_PROBE_IF(g < 20, g * 3 + 2)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ++g;
+            }
+            pc_barrier();                              // X: every consumer is done with the tile's last slab
+#if BD_PC_EPI == 1
+            if (ig == g + 1) issue_next();             // second slab of the next tile, under the (LDS-free) epilogue
+#endif
+        }
+#ifdef BD_GEMM_PROBE
+        if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * 16 + wid) * 64 + lane] = probe_ts;
+#endif
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wm = wid / WN, wn = wid % WN;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+#ifdef BD_GEMM_PROBE
+    unsigned probe_ts = 0;
+#endif
+    int g = 0;       // (the host launches this kernel only when the wide, 16-byte epilogue applies: wide_epilogue_ok)
+    for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
+        f32x16 acc[MI][NI];
+#if BD_PC_EPI == 1
+        acc_init_bias_t<MI, NI>(p, acc, n0 + wn * (NI * 32), lane);     // transposed accumulators (row-per-lane)
+#else
+        acc_init_bias<MI, NI>(p, acc, n0 + wn * (NI * 32), lane);
+#endif
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            BD_PROBE_IF(g < 20, g * 3)
+            pc_barrier();                              // B(kt)
+            BD_PROBE_IF(g < 20, g * 3 + 1)
+            const unsigned char* base = lds + (g & 1) * STAGE_BYTES;
+            constexpr int FB = NS == 1 ? 2 : 1;
+            frag_t a[FB][NS][MI], b[FB][NS][NI];
+#define LOAD_ONE(dst, ptr, row, ks)                                                                           \
+            {                                                                                                 \
+                const int c0_ = ((ks) * 2 + lhalf) * CPF;                                                     \
+                if constexpr (CPF == 1) {                                                                     \
+                    dst = __builtin_bit_cast(frag_t, *(const u128*)((ptr) + (row) * ROWB + (swz_chunk<CH>((row), c0_) << 4))); \
+                } else {                                                                                      \
+                    const u128 lo_ = *(const u128*)((ptr) + (row) * ROWB + (swz_chunk<CH>((row), c0_) << 4)); \
+                    const u128 hi_ = *(const u128*)((ptr) + (row) * ROWB + (swz_chunk<CH>((row), c0_ + 1) << 4)); \
+                    dst = (frag_t){(int)lo_[0], (int)lo_[1], (int)lo_[2], (int)lo_[3], (int)hi_[0], (int)hi_[1], (int)hi_[2], (int)hi_[3]}; \
+                }                                                                                             \
+            }
+#define LOAD_FRAGS(ks, slot)                                                                                  \
+            _Pragma("unroll") for (int s2 = 0; s2 < NS; ++s2) {                                               \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                \
+                    LOAD_ONE(a[slot][s2][i], base + s2 * A_BYTES, wm * (MI * 32) + i * 32 + lrow, ks)         \
+                _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                \
+                    LOAD_ONE(b[slot][s2][j], base + NS * A_BYTES + s2 * W_BYTES, wn * (NI * 32) + j * 32 + lrow, ks) \
+            }
+            if constexpr (NS == 1) {
+                // Software pipeline inside the slab, order PINNED (sched_barrier(0) after every MFMA / ds_read pair): the
+                // fragment reads of k-step ks+1 are interleaved one-for-one with the MFMAs of k-step ks, so a consumer wave
+                // keeps its matrix pipe fed on its own.  (With producers doing the DMA, both consumer waves of a SIMD leave the
+                // slab barrier at the same instant; left to itself hipcc re-associates the unrolled k-steps into chains of
+                // dependent MFMAs on one accumulator, each behind an lgkmcnt(0) -- 3100-3600 cycles per slab for 2048 cycles of
+                // matrix work per SIMD, profiles/r2_gemm_phase_probe.md.)  MFMA q of a k-step works on tile (q % MI, q / MI);
+                // reads go a0, b0, a1, b1, ... so that the operands the next k-step needs first arrive first; hipcc keeps the
+                // lgkmcnt waits counted (its own ds_reads, in order).
+                constexpr int NRD = MI + NI, NMM = MI * NI;
+                auto load_q = [&](int slot, int ks, int q) {
+                    const int which = (q < 2 * (MI < NI ? MI : NI)) ? (q & 1) : (MI > NI ? 0 : 1);   // 0: an A fragment, 1: a W fragment
+                    const int idx = (q < 2 * (MI < NI ? MI : NI)) ? (q >> 1) : (q - (MI < NI ? MI : NI));
+                    if (which == 0) LOAD_ONE(a[slot][0][idx], base, wm * (MI * 32) + idx * 32 + lrow, ks)
+                    else LOAD_ONE(b[slot][0][idx], base + NS * A_BYTES, wn * (NI * 32) + idx * 32 + lrow, ks)
+                };
+#pragma unroll
+                for (int q = 0; q < NRD; ++q) load_q(0, 0, q);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int cur = ks & 1;
+#pragma unroll
+                    for (int q = 0; q < NMM; ++q) {
+                        const int i = q % MI, j = q / MI;
+#if BD_PC_EPI == 1
+                        acc[i][j] = Op16<T>::mfma(b[cur][0][j], a[cur][0][i], acc[i][j]);      // D^T = W . A^T
+#else
+                        acc[i][j] = Op16<T>::mfma(a[cur][0][i], b[cur][0][j], acc[i][j]);
+#endif
+                        if (ks + 1 < KS && q < NRD) load_q(cur ^ 1, ks + 1, q);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
+            if (FB == 2) { LOAD_FRAGS(0, 0) }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cur = FB == 2 ? (ks & 1) : 0;
+                if (FB == 2) { if (ks + 1 < KS) { LOAD_FRAGS(ks + 1, (cur ^ 1) & (FB - 1)) } }
+                else { LOAD_FRAGS(ks, 0) }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+#if BD_PC_EPI == 1
+                        if (NS == 2) {
+                            acc[i][j] = Op16<T>::mfma(b[cur][0][j], a[cur][NS - 1][i], acc[i][j]);   // hi(W) * lo(A)
+                            acc[i][j] = Op16<T>::mfma(b[cur][NS - 1][j], a[cur][0][i], acc[i][j]);   // lo(W) * hi(A)
+                        }
+                        acc[i][j] = Op16<T>::mfma(b[cur][0][j], a[cur][0][i], acc[i][j]);            // hi * hi  (D^T = W . A^T)
+#else
+                        if (NS == 2) {
+                            acc[i][j] = Op16<T>::mfma(a[cur][NS - 1][i], b[cur][0][j], acc[i][j]);   // lo * hi
+                            acc[i][j] = Op16<T>::mfma(a[cur][0][i], b[cur][NS - 1][j], acc[i][j]);   // hi * lo
+                        }
+                        acc[i][j] = Op16<T>::mfma(a[cur][0][i], b[cur][0][j], acc[i][j]);            // hi * hi
+#endif
+                    }
+            }
+            }
+#undef LOAD_FRAGS
+#undef LOAD_ONE
+        }
+        BD_PROBE_IF(g == nk, 60)
+        pc_barrier();                                  // X: this wave is done reading the tile's last slab
+        BD_PROBE_IF(g == nk, 61)
+#if BD_PC_EPI == 1
+        gemm_epilogue_rowlane<T, NS, MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+#else
+        {   // LDS-staged epilogue; its scratch is the stage the tile's last slab lived in (free after X)
+            unsigned char* scratch = lds + ((g - 1) & 1) * STAGE_BYTES + wid * (SR * NI * 32 * 4);
+            gemm_epilogue_lds<T, NS, MI, NI, SR, true>(p, acc, scratch, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+        }
+#endif
+        BD_PROBE_IF(g == nk, 62)
+    }
+#ifdef BD_GEMM_PROBE
+    if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * 16 + wid) * 64 + lane] = probe_ts;
+#endif
+}
+
+// the wide (LDS-staged, 16-byte) epilogue needs 16-byte aligned rows: N % 8 == 0 and aligned leading dimensions / pointers
+inline bool wide_epilogue_ok(const bd_gemm_args& p, int ns) {
+    return (p.N % 8 == 0) && (p.ldo % 8 == 0) && (((uintptr_t)p.out & 15) == 0) &&
+           (!p.resid || ((p.ldr % 4 == 0) && ((uintptr_t)p.resid & 15) == 0)) &&
+           (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.addtab || ((uintptr_t)p.addtab & 15) == 0) &&
+           (!p.wscale || ((uintptr_t)p.wscale & 15) == 0) && (p.out_f32 || ns == 1 || (p.out_plane % 8 == 0));
+}
+
+template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_pc(const bd_gemm_args& a, hipStream_t s, int cus) {
+    constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32;
+    constexpr int NPW = 4;        // one producer wave per SIMD: a single wave issues one LDS-DMA piece per ~70 cycles, the CU ~23
+    const int tiles = ((a.M + TBM - 1) / TBM) * ((a.N + TBN - 1) / TBN);
+    const int grid = tiles < cus ? tiles : cus;
+    hipLaunchKernelGGL((gemm_kernel_pc<T, NS, BK, WM, WN, MI, NI, NPW>), dim3(grid), dim3((WM * WN + NPW) * 64), 0, s, a);
+}
+
 template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_glds(const bd_gemm_args& a, hipStream_t s) {
     constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32;
     const int tiles = ((a.M + TBM - 1) / TBM) * ((a.N + TBN - 1) / TBN);
@@ -469,6 +968,23 @@ template <class T> bd_gemm_args row_slice(const bd_gemm_args& a, int64_t row0, i
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     const int kCUs = cu_count();
+    // the producer wave of gemm_kernel_pc addresses a tile's operand rows with 32-bit byte offsets from the tile origin
+    constexpr int ESZ_ = OpGeom<T>::ESZ;
+    const bool pc_ok = BD_GEMM_POLICY != 0 && wide_epilogue_ok(a, NS) && 256 * a.lda * ESZ_ < ((int64_t)1 << 31) &&
+                       256 * a.ldw * ESZ_ < ((int64_t)1 << 31);
+    if constexpr (NS == 1) {
+        // 256 x 192 tiles (8 consumer waves of 64 x 96: 96 accumulator + 2 x 20 fragment registers fit the 168-VGPR budget
+        // of three waves per SIMD with the fragment double-buffering intact) whenever they tile N exactly -- every Linear of
+        // both stacks except the head (N = 2304, 3072, 768 are multiples of 192).
+        const int64_t t192 = (int64_t)((a.M + 255) / 256) * (a.N / 192);
+        const double fill = (double)t192 / (double)(((t192 + kCUs - 1) / kCUs) * kCUs);     // last-round occupancy of the CUs
+        if (BD_GEMM_POLICY == 1 && pc_ok && a.N % 192 == 0 && a.M >= 1024 && fill >= 0.88) {
+            launch_pc<T, NS, BK, 4, 2, 2, 3>(a, s, kCUs);
+            bd_trace_close(s, slot);
+            BD_CHECK_LAUNCH();
+            return BD_OK;
+        }
+    }
     {
         // Tile choice = best estimated efficiency: wave quantisation over the resident slots (256x256: one workgroup
         // per CU; 128x128: two; 64x64: four) times the measured relative mainloop efficiency of the tile
@@ -521,7 +1037,7 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
         }
         if constexpr (NS == 1) {
             if (use192) {
-                launch_glds<T, NS, BK, 4, 2, 2, 3>(a, s);         // 256 x 192, 1 workgroup / CU
+                launch_glds<T, NS, BK, 4, 2, 2, 3>(a, s);
                 bd_trace_close(s, slot);
                 BD_CHECK_LAUNCH();
                 return BD_OK;
@@ -535,7 +1051,7 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
                 launch_glds<T, NS, BK, 2, 2, 2, 2>(rest, s);
             }
         } else if (e256 >= e128 && e256 >= e64)
-            launch_glds<T, NS, BK, 2, 4, 4, 2>(a, s);             // 256 x 256, 1 workgroup / CU
+            launch_glds<T, NS, BK, 2, 4, 4, 2>(a, s);             // 256 x 256, one tile per workgroup
         else if (e128 >= e64)
             launch_glds<T, NS, BK, 2, 2, 2, 2>(a, s);             // 128 x 128, 2 workgroups / CU
         else

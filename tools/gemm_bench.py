@@ -1,5 +1,5 @@
 """Micro-benchmark of bd_gemm on the path's real shapes (config-2: M = 49152 / 50112 rows).
-    BD_GEMM_IMPL=0|1 python tools/gemm_bench.py [prec]
+    python tools/gemm_bench.py [prec]          (BOXDREAMER_HIP_LIB=<other build> for A/B runs)
 Random (not zero) operands; HIP events on torch's current stream (the launch stream)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,8 @@ from boxdreamer_amd import hip_ops, _lib
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 dev = torch.device("cuda")
 shapes = [("qkv", 49152, 2304, 768, 0), ("proj", 49152, 768, 768, 0), ("fc1+gelu", 49152, 3072, 768, 1),
-          ("fc2", 49152, 768, 3072, 0), ("dino qkv", 50112, 2304, 768, 0), ("head", 8192, 1568, 768, 0)]
+          ("fc2", 49152, 768, 3072, 0), ("dino qkv", 50112, 2304, 768, 0), ("dino fc1", 50112, 3072, 768, 1), ("dino fc2", 50112, 768, 3072, 0),
+          ("dino proj", 50112, 768, 768, 0), ("head", 8192, 1568, 768, 0)]
 tot_f = tot_t = 0.0
 for name, M, N, K, act in shapes:
     a = hip_ops.to_operand(torch.randn(M, K, device=dev), prec)
@@ -29,4 +30,4 @@ for name, M, N, K, act in shapes:
     tf = 2.0 * M * N * K / ms / 1e9
     tot_f += 2.0 * M * N * K; tot_t += ms
     print(f"{name:10s} M={M} N={N} K={K} act={act}: {ms:.3f} ms  {tf:.0f} TF/s (algorithmic)")
-print(f"impl={os.environ.get('BD_GEMM_IMPL','1')} prec={prec} weighted: {tot_f / tot_t / 1e9:.0f} TF/s")
+print(f"prec={prec} weighted: {tot_f / tot_t / 1e9:.0f} TF/s")

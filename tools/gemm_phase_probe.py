@@ -1,6 +1,6 @@
 """Where does a GEMM tile's time go?  Measurement tool (not part of the product library).
 
-    python tools/gemm_phase_probe.py build            # here (no GPU): tools/_probe/libbd_probe.so = gemm.hip + trace.hip with -DBD_GEMM_PROBE
+    python tools/gemm_phase_probe.py build            # here (no GPU): tools/_probe/libbd_probe.so = the library built with -DBD_GEMM_PROBE
     python tools/gemm_phase_probe.py run M N K [prec] # on the GPU box
 
 Every wave stamps the shader clock (s_memtime) at three points of every K-slab -- before the slab barrier, after it, after
@@ -20,7 +20,8 @@ def build():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     src = os.path.join(ROOT, "boxdreamer_amd", "csrc")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-DBD_GEMM_PROBE",
-           "-I", os.path.join(ROOT, "include"), "-shared", "-o", LIB, os.path.join(src, "gemm.hip"), os.path.join(src, "trace.hip")]
+           "-I", os.path.join(ROOT, "include"), "-shared", "-o", LIB] + sorted(
+        os.path.join(src, f) for f in os.listdir(src) if f.endswith(".hip"))
     subprocess.check_call(cmd)
     print("built", LIB)
 
@@ -44,6 +45,8 @@ def run(M, N, K, prec="bf16"):
     torch.cuda.synchronize()
     hip_ops.gemm(a, w, b, prec=prec)
     torch.cuda.synchronize()
+    if os.environ.get("BD_PROBE_PC", "1") == "1":
+        return report_pc(buf.cpu().numpy().astype(np.uint32).reshape(512, 16, 64), M, N, K, prec)
     ts = buf.cpu().numpy().astype(np.uint32).reshape(1024, nwave, 64)
     nk = min(K // (32 if prec == "bf16x3" else (128 if prec == "fp8" else 64)), 20)
     first = ts[:256]                                   # first round: one workgroup per CU
@@ -59,6 +62,29 @@ def run(M, N, K, prec="bf16"):
         print("  frags + MFMA :", np.round(mma.mean(0)).astype(int).tolist())
         print(f"  prologue {d(0, 60).mean():.0f}  mainloop {d(61, 0).mean():.0f}  sync {d(62, 61).mean():.0f}  epilogue {d(63, 62).mean():.0f}"
               f"  total {d(63, 60).mean():.0f} cycles;  slab mean: barrier {bar[:, 1:].mean():.0f} dma {dma[:, :-1].mean():.0f} mfma {mma.mean():.0f}")
+
+
+def report_pc(ts, M, N, K, prec):
+    """gemm_kernel_pc (8 consumer + 4 producer waves, persistent): first tile of each of the 256 workgroups."""
+    import numpy as np
+    nk = min(K // (32 if prec == "bf16x3" else (128 if prec == "fp8" else 64)), 20)
+    first = ts[:256].astype(np.int64)
+    d = lambda w, i, j: ((first[:, w, i] - first[:, w, j]) & 0xFFFFFFFF).astype(np.float64)
+    for w in (0, 4):
+        wait = np.stack([d(w, 3 * k + 1, 3 * k) for k in range(nk)], 1)
+        comp = np.stack([d(w, 3 * (k + 1), 3 * k + 1) for k in range(nk - 1)], 1)
+        print(f"consumer wave {w}: barrier wait {np.round(wait.mean(0)).astype(int).tolist()}")
+        print(f"                 frags + MFMA {np.round(comp.mean(0)).astype(int).tolist()}")
+        if nk * 3 <= 60:
+            print(f"                 last slab {d(w, 60, 3 * (nk - 1) + 1).mean():.0f}  X wait {d(w, 61, 60).mean():.0f}  epilogue {d(w, 62, 61).mean():.0f}"
+                  f"  tile total {d(w, 62, 0).mean():.0f}  slab mean {(wait[:, 1:].mean() + comp.mean()):.0f}")
+    for w in (8, 9, 10, 11):
+        wait = np.stack([d(w, 3 * k + 1, 3 * k) for k in range(nk)], 1)
+        iss = np.stack([d(w, 3 * k + 2, 3 * k + 1) for k in range(nk)], 1)
+        land = np.stack([d(w, 3 * (k + 1), 3 * k + 2) for k in range(nk - 1)], 1)
+        print(f"producer wave {w}: barrier wait {np.round(wait.mean(0)).astype(int).tolist()}")
+        print(f"                  issue        {np.round(iss.mean(0)).astype(int).tolist()}")
+        print(f"                  vmcnt wait   {np.round(land.mean(0)).astype(int).tolist()}")
 
 
 if __name__ == "__main__":
