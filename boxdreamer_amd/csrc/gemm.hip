@@ -53,9 +53,11 @@ extern "C" int bd_gemm_probe_set(void* buf) {
 }
 #define BD_PROBE(idx) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((idx) < 64) probe_ts = (lane == (idx)) ? (unsigned)t__ : probe_ts; }
 #define BD_PROBE_IF(c, idx) { if (c) BD_PROBE(idx) }
+#define BD_PROBE_RT(idx) { const unsigned long long t__ = __builtin_amdgcn_s_memrealtime(); probe_ts = (lane == (idx)) ? (unsigned)t__ : probe_ts; }
 #else
 #define BD_PROBE(idx)
 #define BD_PROBE_IF(c, idx)
+#define BD_PROBE_RT(idx)
 #endif
 
 namespace {
@@ -799,6 +801,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
 #ifdef BD_GEMM_PROBE
     unsigned probe_ts = 0;
 #endif
+    BD_PROBE(58) BD_PROBE_RT(56)
     int g = 0;       // (the host launches this kernel only when the wide, 16-byte epilogue applies: wide_epilogue_ok)
     for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
         int m0, n0;
@@ -869,31 +872,65 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                     }
                 }
             } else {
-            if (FB == 2) { LOAD_FRAGS(0, 0) }
+                // Split-bf16 (NS == 2): per k-step and output tile three MFMAs -- lo(A) hi(W), hi(A) lo(W), hi(A) hi(W) -- on ten
+                // fragments (A hi/lo x MI, W hi/lo x NI = 40 VGPRs).  Order pinned so that registers rotate without a second
+                // full fragment set (96 accumulator + 60 fragment registers fit the 168-VGPR budget):
+                //   phase 1  lo(A) * hi(W)   -- afterwards the lo(A) registers are dead: the NEXT k-step's lo(A) loads go there
+                //   phase 2  hi(A) * lo(W)   -- lo(A) loads in flight; afterwards lo(W) is dead: next lo(W) loads go there
+                //   phase 3  hi(A) * hi(W)   -- next lo(W), then next hi(W), hi(A) loads (into the spare hi set) in flight
+                // so one ds_read rides under almost every MFMA and no wave depends on its SIMD partner to cover its reads.
+                constexpr int NMM = MI * NI;
+                frag_t ah[2][MI], wh[2][NI], al[MI], wl[NI];
+                const unsigned char* wbase = base + NS * A_BYTES;
+#define LD_A(dst, plane, idx, ks) LOAD_ONE(dst, base + (plane) * A_BYTES, wm * (MI * 32) + (idx) * 32 + lrow, ks)
+#define LD_W(dst, plane, idx, ks) LOAD_ONE(dst, wbase + (plane) * W_BYTES, wn * (NI * 32) + (idx) * 32 + lrow, ks)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int cur = FB == 2 ? (ks & 1) : 0;
-                if (FB == 2) { if (ks + 1 < KS) { LOAD_FRAGS(ks + 1, (cur ^ 1) & (FB - 1)) } }
-                else { LOAD_FRAGS(ks, 0) }
+                for (int j = 0; j < NI; ++j) LD_W(wh[0][j], 0, j, 0)
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i) LD_A(al[i], 1, i, 0)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-#if BD_PC_EPI == 1
-                        if (NS == 2) {
-                            acc[i][j] = Op16<T>::mfma(b[cur][0][j], a[cur][NS - 1][i], acc[i][j]);   // hi(W) * lo(A)
-                            acc[i][j] = Op16<T>::mfma(b[cur][NS - 1][j], a[cur][0][i], acc[i][j]);   // lo(W) * hi(A)
-                        }
-                        acc[i][j] = Op16<T>::mfma(b[cur][0][j], a[cur][0][i], acc[i][j]);            // hi * hi  (D^T = W . A^T)
-#else
-                        if (NS == 2) {
-                            acc[i][j] = Op16<T>::mfma(a[cur][NS - 1][i], b[cur][0][j], acc[i][j]);   // lo * hi
-                            acc[i][j] = Op16<T>::mfma(a[cur][0][i], b[cur][NS - 1][j], acc[i][j]);   // hi * lo
-                        }
-                        acc[i][j] = Op16<T>::mfma(a[cur][0][i], b[cur][0][j], acc[i][j]);            // hi * hi
-#endif
+                for (int i = 0; i < MI; ++i) LD_A(ah[0][i], 0, i, 0)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) LD_W(wl[j], 1, j, 0)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int cur = ks & 1, nxt = cur ^ 1;
+                    const bool more = ks + 1 < KS;
+                    // phase 1: lo(A) * hi(W)
+#pragma unroll
+                    for (int q = 0; q < NMM; ++q) {
+                        const int i = q % MI, j = q / MI;
+                        acc[i][j] = Op16<T>::mfma(al[i], wh[cur][j], acc[i][j]);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-            }
+                    // phase 2: hi(A) * lo(W), next lo(A) loads riding under the first MFMAs
+#pragma unroll
+                    for (int q = 0; q < NMM; ++q) {
+                        const int i = q % MI, j = q / MI;
+                        acc[i][j] = Op16<T>::mfma(ah[cur][i], wl[j], acc[i][j]);
+                        if (more && q < MI) LD_A(al[q], 1, q, ks + 1)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // phase 3: hi(A) * hi(W), next lo(W), hi(W), hi(A) loads under it
+#pragma unroll
+                    for (int q = 0; q < NMM; ++q) {
+                        const int i = q % MI, j = q / MI;
+                        acc[i][j] = Op16<T>::mfma(ah[cur][i], wh[cur][j], acc[i][j]);
+                        if (more) {
+                            if (q < NI) LD_W(wl[q], 1, q, ks + 1)
+                            else if (q < 2 * NI) LD_W(wh[nxt][q - NI], 0, q - NI, ks + 1)
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (more) {
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) LD_A(ah[nxt][i], 0, i, ks + 1)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#undef LD_A
+#undef LD_W
             }
 #undef LOAD_FRAGS
 #undef LOAD_ONE
@@ -911,6 +948,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
 #endif
         BD_PROBE_IF(g == nk, 62)
     }
+    BD_PROBE(59) BD_PROBE_RT(57)
 #ifdef BD_GEMM_PROBE
     if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * 16 + wid) * 64 + lane] = probe_ts;
 #endif
@@ -972,7 +1010,7 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
     constexpr int ESZ_ = OpGeom<T>::ESZ;
     const bool pc_ok = BD_GEMM_POLICY != 0 && wide_epilogue_ok(a, NS) && 256 * a.lda * ESZ_ < ((int64_t)1 << 31) &&
                        256 * a.ldw * ESZ_ < ((int64_t)1 << 31);
-    if constexpr (NS == 1) {
+    {
         // 256 x 192 tiles (8 consumer waves of 64 x 96: 96 accumulator + 2 x 20 fragment registers fit the 168-VGPR budget
         // of three waves per SIMD with the fragment double-buffering intact) whenever they tile N exactly -- every Linear of
         // both stacks except the head (N = 2304, 3072, 768 are multiples of 192).

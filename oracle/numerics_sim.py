@@ -13,6 +13,7 @@ Schemes (a = activation row block, w = weight row block, both K-contiguous):
   f16c8    f16(a)*f16(w)  +  mx8(a - f16 a) * mx8(w)  +  mx8(a) * mx8(w - f16 w)     corrections on MX e4m3 (0.5 pass each)
   f16c6    same with MX e2m3 (fp6) correction operands                                (0.25 pass each)
   f16c4    same with MX e2m1 (fp4)
+  f16c8fix f16c8 with the FIXED power-of-two scales the kernel uses (no per-block scales; BD_PREC_F16C8)
 """
 from __future__ import annotations
 
@@ -89,7 +90,19 @@ def make_linear(scheme: str):
             return F.linear(xh, wh) + F.linear(mx_quant(x - xh, fmt), mx_quant(w, fmt)) + (0 if b is None else b)
         return f
 
-    table = {"bf16x3": lin_bf16x3, "f16": lin_16(torch.float16), "bf16": lin_16(torch.bfloat16),
+    def e4m3(t):
+        return t.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+
+    def lin_f16c8_fixed(x, w, b, D=11):
+        """The kernel's form (BD_PREC_F16C8): FIXED power-of-two scales instead of per-block ones -- activations' q plane
+        un-scaled, weights' q plane scaled per tensor to the top of e4m3's range, lo planes 2^D above their q plane."""
+        xh = x.half().float(); wh = w.half().float()
+        sw = torch.floor(torch.log2(448.0 / w.abs().max().clamp_min(1e-30)))
+        xq, xl = e4m3(x), e4m3((x - xh) * 2.0 ** D) * 2.0 ** -D
+        wq, wl = e4m3(w * 2.0 ** sw) * 2.0 ** -sw, e4m3((w - wh) * 2.0 ** (sw + D)) * 2.0 ** -(sw + D)
+        return F.linear(xh, wh) + F.linear(xl, wq) + F.linear(xq, wl) + (0 if b is None else b)
+
+    table = {"f16c8fix": lin_f16c8_fixed, "bf16x3": lin_bf16x3, "f16": lin_16(torch.float16), "bf16": lin_16(torch.bfloat16),
              "f16c8": lin_f16c("e4m3"), "f16c6": lin_f16c("e2m3"), "f16c4": lin_f16c("e2m1"),
              "f16a8": lin_f16c_one("e4m3"), "fp32": lambda x, w, b: F.linear(x, w, b)}
     return table[scheme]
@@ -132,7 +145,7 @@ def main():
     ap.add_argument("--views", type=int, default=6)
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--seed", type=int, default=11)
-    ap.add_argument("--schemes", default="bf16x3,f16,f16c8,f16c6,f16c4,f16a8")
+    ap.add_argument("--schemes", default="bf16x3,f16,f16c8,f16c8fix,f16c6,f16c4,f16a8")
     a = ap.parse_args()
     torch.set_num_threads(8)
     bsd, dsd = synth.betr_state_dict(1234, a.depth), synth.dino_state_dict(4321, a.depth)

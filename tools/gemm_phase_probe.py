@@ -43,7 +43,8 @@ def run(M, N, K, prec="bf16"):
     lib.bd_gemm_probe_set.argtypes = [C.c_void_p]
     assert lib.bd_gemm_probe_set(C.c_void_p(buf.data_ptr())) == 0
     torch.cuda.synchronize()
-    hip_ops.gemm(a, w, b, prec=prec)
+    for _ in range(int(os.environ.get("BD_PROBE_LAUNCHES", "60"))):      # back to back: the stamps of the LAST launch survive,
+        hip_ops.gemm(a, w, b, prec=prec)                                   # taken at sustained (DVFS-settled) clocks
     torch.cuda.synchronize()
     if os.environ.get("BD_PROBE_PC", "1") == "1":
         return report_pc(buf.cpu().numpy().astype(np.uint32).reshape(512, 16, 64), M, N, K, prec)
@@ -78,7 +79,10 @@ def report_pc(ts, M, N, K, prec):
         if nk * 3 <= 60:
             print(f"                 last slab {d(w, 60, 3 * (nk - 1) + 1).mean():.0f}  X wait {d(w, 61, 60).mean():.0f}  epilogue {d(w, 62, 61).mean():.0f}"
                   f"  tile total {d(w, 62, 0).mean():.0f}  slab mean {(wait[:, 1:].mean() + comp.mean()):.0f}")
-    for w in (8, 9, 10, 11):
+    cyc, rt = d(0, 59, 58), d(0, 57, 56)
+    print(f"whole kernel (wave 0): {cyc.mean():.0f} shader cycles in {rt.mean() / 100:.1f} us (s_memrealtime, 100 MHz) -> effective shader clock "
+          f"{(cyc / rt).mean() * 0.1:.2f} GHz")
+    for w in (8, 9):
         wait = np.stack([d(w, 3 * k + 1, 3 * k) for k in range(nk)], 1)
         iss = np.stack([d(w, 3 * k + 2, 3 * k + 1) for k in range(nk)], 1)
         land = np.stack([d(w, 3 * (k + 1), 3 * k + 2) for k in range(nk - 1)], 1)
