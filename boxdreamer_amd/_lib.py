@@ -17,8 +17,10 @@ LIB_PATH = os.environ.get("BOXDREAMER_HIP_LIB") or os.path.join(HERE, "libboxdre
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 PREC_BF16, PREC_F16, PREC_BF16X3, PREC_F16_OUT_BF16X3, PREC_FP8, PREC_BF16_OUT_FP8 = 0, 1, 2, 3, 4, 5
 PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16 = 6, 7      # whole-path only: attention policy of the strict family
+PREC_F16C8 = 8                                         # f16 + e4m3 corrections (include/boxdreamer_hip.h)
+F16C8_D = 11                                           # lo planes are scaled 2^D above their q plane
 PREC_NAMES = {"bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8,
-              "bf16x3_attn_x3": PREC_BF16X3_ATTN_X3, "bf16x3_attn_f16": PREC_BF16X3_ATTN_F16}
+              "bf16x3_attn_x3": PREC_BF16X3_ATTN_X3, "bf16x3_attn_f16": PREC_BF16X3_ATTN_F16, "f16c8": PREC_F16C8}
 _X3_FAMILY = (PREC_BF16X3, PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16)
 ACT_NONE, ACT_GELU = 0, 1
 
@@ -39,11 +41,11 @@ class GemmArgs(C.Structure):
                 ("out_f32", C.c_int),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("act", C.c_int),
-                ("rpg_in", C.c_int), ("rpg_out", C.c_int), ("row_off", C.c_int)]
+                ("rpg_in", C.c_int), ("rpg_out", C.c_int), ("row_off", C.c_int), ("w_qexp", C.c_int)]
 
 
 class Linear(C.Structure):
-    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("wscale", C.c_void_p)]
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("wscale", C.c_void_p), ("w_qexp", C.c_int)]
 
 
 class BlockWeights(C.Structure):
@@ -128,7 +130,7 @@ def load() -> C.CDLL:
     lib.bd_solve_pnp.argtypes = [vp, vp, vp, i, i, i, vp, vp]
     lib.bd_trace_begin.argtypes = [i]
     lib.bd_trace_end.argtypes = [C.POINTER(TraceRecord), i]
-    if lib.bd_abi_version() != 2:
+    if lib.bd_abi_version() != 3:
         raise HipLibraryError("libboxdreamer_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -173,7 +175,7 @@ def op_dtype(prec) -> torch.dtype:
     pid = prec_id(prec)
     if pid == PREC_FP8:
         return torch.float8_e4m3fn          # OCP e4m3 (gfx950), not MI300's fnuz
-    return torch.float16 if pid == PREC_F16 else torch.bfloat16
+    return torch.float16 if pid in (PREC_F16, PREC_F16C8) else torch.bfloat16     # F16C8: plane 1 holds raw e4m3 bytes
 
 
 def k_multiple(prec) -> int:
@@ -182,7 +184,7 @@ def k_multiple(prec) -> int:
 
 
 def planes(prec) -> int:
-    return 2 if prec_id(prec) in _X3_FAMILY else 1
+    return 2 if prec_id(prec) in _X3_FAMILY or prec_id(prec) == PREC_F16C8 else 1
 
 
 def dtype_id(t: torch.Tensor) -> int:

@@ -285,6 +285,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
                     for (int j = 0; j < 4; ++j) v4[j] = oacc[dm][rq * 4 + j] * inv;
                     store_cvt<fp8e4, 4>(orow + dm * 32 + 8 * rq + 4 * lh, v4);
                 }
+        } else if (OUTMODE == 3) {
+            // F16C8 operand (the proj GEMM's A in the round-2 strict mode): f16 hi plane + k-permuted lo8 plane
+            const int64_t e0 = ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
+#pragma unroll
+            for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    float v4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = oacc[dm][rq * 4 + j] * inv;
+                    f16c8_store4((f16c8*)p.out, p.out_plane, e0 + dm * 32 + 8 * rq + 4 * lh, v4);
+                }
         } else if (OUTMODE == 1) {
             __bf16* orow = (__bf16*)p.out + ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
 #pragma unroll
@@ -360,6 +372,8 @@ extern "C" int bd_attention_q(const void* qkv, int64_t qkv_plane, void* out, int
         case BD_PREC_BF16X3: return dispatch<__bf16, 2>(a, head_dim, s);
         case BD_PREC_F16_OUT_BF16X3: return dispatch<_Float16, 1, 1>(a, head_dim, s);
         case BD_PREC_BF16_OUT_FP8: return dispatch<__bf16, 1, 2>(a, head_dim, s);
+        case BD_PREC_F16_OUT_F16C8: return dispatch<_Float16, 1, 3>(a, head_dim, s);
+        case BD_PREC_BF16X3_OUT_F16C8: return dispatch<__bf16, 2, 3>(a, head_dim, s);
         default: return BD_ERR_DTYPE;
     }
 }

@@ -42,9 +42,18 @@ template <> struct Op16<fp8e4> {
         return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
     }
 };
+// F16C8 (defined below): the hi plane is an f16 operand; the e4m3 correction pass is issued explicitly by the GEMM
+struct f16c8;
+template <> struct Op16<f16c8> {
+    typedef f16x8 vec8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
 // element size, K per MFMA, 16-byte chunks per fragment per lane
 template <class T> struct OpGeom { static constexpr int ESZ = 2, KSTEP = 16, CPF = 1; };
 template <> struct OpGeom<fp8e4> { static constexpr int ESZ = 1, KSTEP = 64, CPF = 2; };
+template <> struct OpGeom<f16c8> { static constexpr int ESZ = 2, KSTEP = 16, CPF = 1; };
 
 template <class T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 template <class T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
@@ -80,9 +89,29 @@ template <> __device__ __forceinline__ void store_cvt<fp8e4, 4>(fp8e4* dst, cons
     *(int*)dst = lo;
 }
 
+// ---- BD_PREC_F16C8 operand class: "f16 + e4m3 corrections" (the round-2 strict mode).
+//   x  ~=  hi + lo,   hi = f16(x),   lo = x - hi  (|lo| <= 2^-12 |x|)
+//   A . W  ~=  hi_A . hi_W  (one f16 MFMA pass)  +  lo_A . q_W  +  q_A . lo_W   (ONE e4m3 pass over a doubled K on the
+//   block-scaled MFMA at twice the f16 rate: positions [lo_A | q_A] against [q_W | lo_W]),  q = e4m3 image of hi.
+// Two MFMA pass-equivalents instead of split-bf16's three AND 3 bytes per element instead of 4 through LDS-DMA; heatmap-logit
+// error 1.7e-4 at full depth (oracle/numerics_sim.py "f16c8fix"; split-bf16: 0.7e-4; bar: 1e-3).  Storage:
+//   plane 0: f16 hi [rows][K]  (2 bytes / element);
+//   plane 1: lo8 = e4m3(lo * 2^(E + D)) [rows][K] (1 byte / element), starting `plane` 2-byte units after plane 0, the 32 k of
+//            every block stored in the order the MFMA lanes want them: byte 16 h + 8 a + j holds k = 16 a + 8 h + j
+//            (a = f16 k-step of the block, h = lane half, j < 8), so that lane (row, h) reads ITS sixteen lo8 bytes with one
+//            ds_read_b128 and in the same order as the sixteen q8 bytes it derives from its own two f16 fragments
+//            (v_cvt_scalef32_pk_fp8_f16: q8 = e4m3(hi * 2^E), nothing stored).
+// Scales are fixed powers of two: E = 0 for activations, one exponent per weight tensor (bd_linear.w_qexp: max|w| 2^E <= 448),
+// D = 11; both cross terms carry 2^(E_w + D), undone by the MFMA's E8M0 block scales.  The scaled f16 -> e4m3 conversion does
+// NOT saturate (|hi| > 448 -> NaN), so producers clamp A-operand values to +-448 before splitting (far outside anything
+// LayerNorm, GELU or softmax-weighted sums produce here; split-bf16 remains for wider ranges).
+struct f16c8 { unsigned short v; };              // storage element of either plane (never used arithmetically)
+#define BD_F16C8_D 11
+
 template <class T> __device__ __forceinline__ typename Op16<T>::vec8 as_vec8(u128 u);
 template <> __device__ __forceinline__ bf16x8 as_vec8<__bf16>(u128 u) { return __builtin_bit_cast(bf16x8, u); }
 template <> __device__ __forceinline__ f16x8 as_vec8<_Float16>(u128 u) { return __builtin_bit_cast(f16x8, u); }
+template <> __device__ __forceinline__ f16x8 as_vec8<f16c8>(u128 u) { return __builtin_bit_cast(f16x8, u); }
 
 // load one element of a runtime-typed input tensor (bf16 / f16 / f32) as fp32
 __device__ __forceinline__ float load_any(const void* p, size_t i, int dtype) {
@@ -160,8 +189,69 @@ template <int KIND, int N> __device__ __forceinline__ void gelu_n(float (&v)[N])
 // which form a narrow (16/8-bit) result of operand class T in an NS-plane mode takes
 template <class T, int NS> struct GeluKind { static constexpr int value = NS == 2 ? 0 : 2; };
 template <> struct GeluKind<_Float16, 1> { static constexpr int value = 1; };
+template <> struct GeluKind<f16c8, 2> { static constexpr int value = 0; };     // strict: exact erf
 
 template <bool FAST> __device__ __forceinline__ float gelu_sel(float x) { return FAST ? gelu_fast(x) : gelu_erf(x); }
+
+// ---- 8 consecutive elements of a GEMM A-operand from fp32 (every producer: LayerNorm, GEMM epilogue, attention output,
+// im2col / patchify / gather): base = plane 0, e = element index (multiple of 8), plane = 2-byte units between the planes
+template <class T, int NS>
+__device__ __forceinline__ void store_operand8(T* base, int64_t plane, int64_t e, const float (&v)[8]) {
+    T* dst = base + e;
+    if constexpr (NS == 2) {
+        float hi8[8], lo8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi8[j] = to_f32<T>(from_f32<T>(v[j])); lo8[j] = v[j] - hi8[j]; }
+        store_cvt<T, 8>(dst, hi8);
+        store_cvt<T, 8>(dst + plane, lo8);
+    } else {
+        store_cvt<T, 8>(dst, v);
+    }
+}
+// F16C8: 8 consecutive elements starting at element index e (e % 8 == 0, rows are multiples of 32 long)
+__device__ __forceinline__ int64_t f16c8_lo_index(int64_t e) {            // byte index in the lo8 plane of element e's 8-group
+    const int g = (int)(e >> 3) & 3;                                         // 8-group inside the 32-block: k = 8 g ..
+    return (e & ~(int64_t)31) + (((g & 1) << 4) | ((g >> 1) << 3));          // a = g >> 1, h = g & 1  ->  16 h + 8 a
+}
+template <int N>
+__device__ __forceinline__ void f16c8_split(const float (&v)[N], _Float16 (&hi)[N], float (&lo_scaled)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float c = __builtin_amdgcn_fmed3f(v[j], -448.0f, 448.0f);
+        hi[j] = (_Float16)c;
+        lo_scaled[j] = (c - (float)hi[j]) * (float)(1 << BD_F16C8_D);
+    }
+}
+template <> __device__ __forceinline__ void store_operand8<f16c8, 2>(f16c8* base, int64_t plane, int64_t e, const float (&v)[8]) {
+    _Float16 h[8];
+    float lo[8];
+    f16c8_split<8>(v, h, lo);
+    f16x8 hv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hv[j] = h[j];
+    int l0 = 0, l1 = 0;
+    l0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], l0, false); l0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], l0, true);
+    l1 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[4], lo[5], l1, false); l1 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[6], lo[7], l1, true);
+    unsigned char* lo_plane = (unsigned char*)(base + plane);
+#if defined(BD_STORE_NT) && BD_STORE_NT
+    __builtin_nontemporal_store(__builtin_bit_cast(u128, hv), (u128*)(base + e));
+#else
+    *(u128*)(base + e) = __builtin_bit_cast(u128, hv);
+#endif
+    *(uint2*)(lo_plane + f16c8_lo_index(e)) = make_uint2((unsigned)l0, (unsigned)l1);
+}
+// 4 consecutive elements (LayerNorm, attention outputs): e % 4 == 0
+__device__ __forceinline__ void f16c8_store4(f16c8* base, int64_t plane, int64_t e, const float (&v)[4]) {
+    _Float16 h[4];
+    float lo[4];
+    f16c8_split<4>(v, h, lo);
+    typedef __attribute__((__vector_size__(4 * sizeof(_Float16)))) _Float16 f16x4;
+    f16x4 hv = {h[0], h[1], h[2], h[3]};
+    int l0 = 0;
+    l0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], l0, false); l0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], l0, true);
+    *(f16x4*)(base + e) = hv;
+    *(int*)((unsigned char*)(base + plane) + f16c8_lo_index(e & ~(int64_t)7) + (e & 4)) = l0;
+}
 
 // trace.hip
 int bd_trace_open(hipStream_t s, int kind, int M, int N, int K);

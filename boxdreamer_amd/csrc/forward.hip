@@ -17,8 +17,9 @@ struct Carver {
     }
 };
 
-inline int planes_of(int prec) {
-    return (prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_BF16X3_ATTN_F16) ? 2 : 1;
+inline int planes_of(int prec) {      // 2-byte units per element of a 16-bit operand buffer (F16C8: f16 plane + e4m3 plane)
+    return (prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_BF16X3_ATTN_F16 ||
+            prec == BD_PREC_F16C8) ? 2 : 1;
 }
 
 struct BlockBufs {
@@ -38,6 +39,7 @@ inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const
     g.wscale = lin.wscale;
     g.out = out; g.ldo = ldo; g.out_plane = out_plane; g.out_f32 = out_f32;
     g.M = M; g.N = N; g.K = K; g.act = act;
+    g.w_qexp = lin.w_qexp;
     return g;
 }
 
@@ -65,14 +67,18 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
               float ln_eps, float rms_eps, int wprec, void* stream) {
     const int hd = D / heads;
     const int prec = gemm_prec(wprec);
-    const bool hyb = prec == BD_PREC_BF16X3 && x3_f16_attention(wprec, w.q_norm_w != nullptr);
+    const bool c8 = prec == BD_PREC_F16C8;    // f16 + e4m3-correction Linears; attention as in BD_PREC_BF16X3
+    const bool hyb = (prec == BD_PREC_BF16X3 && x3_f16_attention(wprec, w.q_norm_w != nullptr)) || (c8 && w.q_norm_w != nullptr);
     const bool f8 = prec == BD_PREC_FP8;      // e4m3 Linears, bf16 attention
-    const int aprec_in = hyb ? BD_PREC_F16 : (f8 ? BD_PREC_BF16 : prec);
-    const int aprec = hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec);
+    // attention input: f16 single plane where q, k are RMS-normalised (hyb), split-bf16 planes otherwise in the strict classes
+    const int aprec_in = hyb ? BD_PREC_F16 : (f8 ? BD_PREC_BF16 : (c8 ? BD_PREC_BF16X3 : prec));
+    const int aprec = c8 ? (hyb ? BD_PREC_F16_OUT_F16C8 : BD_PREC_BF16X3_OUT_F16C8)
+                         : (hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec));
+    const int qkv_out = hyb ? 2 : (f8 ? 3 : (c8 ? 4 : 0));          // f16 plane / bf16 plane / split-bf16 planes / operand class
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D, p4D = (int64_t)M * 4 * D;
     BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
     {
-        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, hyb ? 2 : (f8 ? 3 : 0), M, D, BD_ACT_NONE);
+        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, qkv_out, M, D, BD_ACT_NONE);
         BD_TRY(bd_gemm(&g, prec, stream));
     }
     if (w.q_norm_w) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, aprec_in, stream));
@@ -103,15 +109,19 @@ int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, flo
                               int T, int P, int D, int heads, float ln_eps, float rms_eps, int wprec, void* stream) {
     const int hd = D / heads, M = B * T * P, Mq = B * P;
     const int prec = gemm_prec(wprec);
-    const bool hyb = prec == BD_PREC_BF16X3 && x3_f16_attention(wprec, w.q_norm_w != nullptr);
+    const bool c8 = prec == BD_PREC_F16C8;    // f16 + e4m3-correction Linears; attention as in BD_PREC_BF16X3
+    const bool hyb = (prec == BD_PREC_BF16X3 && x3_f16_attention(wprec, w.q_norm_w != nullptr)) || (c8 && w.q_norm_w != nullptr);
     const bool f8 = prec == BD_PREC_FP8;      // e4m3 Linears, bf16 attention
-    const int aprec_in = hyb ? BD_PREC_F16 : (f8 ? BD_PREC_BF16 : prec);
-    const int aprec = hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec);
+    // attention input: f16 single plane where q, k are RMS-normalised (hyb), split-bf16 planes otherwise in the strict classes
+    const int aprec_in = hyb ? BD_PREC_F16 : (f8 ? BD_PREC_BF16 : (c8 ? BD_PREC_BF16X3 : prec));
+    const int aprec = c8 ? (hyb ? BD_PREC_F16_OUT_F16C8 : BD_PREC_BF16X3_OUT_F16C8)
+                         : (hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec));
+    const int qkv_out = hyb ? 2 : (f8 ? 3 : (c8 ? 4 : 0));          // f16 plane / bf16 plane / split-bf16 planes / operand class
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D;
     const int64_t qD = (int64_t)Mq * D, q4D = (int64_t)Mq * 4 * D;
     BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
     {
-        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, hyb ? 2 : (f8 ? 3 : 0), M, D, BD_ACT_NONE);
+        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, qkv_out, M, D, BD_ACT_NONE);
         BD_TRY(bd_gemm(&g, prec, stream));
     }
     if (w.q_norm_w) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, aprec_in, stream));
@@ -176,7 +186,7 @@ DecBufs carve_decoder(const bd_betr_weights* w, int B, int T, int prec, void* ws
 
 inline bool bad_prec(int prec) {
     return prec != BD_PREC_BF16 && prec != BD_PREC_F16 && prec != BD_PREC_BF16X3 && prec != BD_PREC_FP8 &&
-           prec != BD_PREC_BF16X3_ATTN_X3 && prec != BD_PREC_BF16X3_ATTN_F16;
+           prec != BD_PREC_BF16X3_ATTN_X3 && prec != BD_PREC_BF16X3_ATTN_F16 && prec != BD_PREC_F16C8;
 }
 
 }  // namespace

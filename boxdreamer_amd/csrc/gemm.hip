@@ -116,7 +116,7 @@ __device__ __forceinline__ unsigned lds_offset_of(const void* p) {
 }
 
 // out_f32 codes
-enum { OUT_OPERAND = 0, OUT_F32 = 1, OUT_F16 = 2, OUT_BF16 = 3 };
+enum { OUT_OPERAND = 0, OUT_F32 = 1, OUT_F16 = 2, OUT_BF16 = 3, OUT_BF16X2 = 4 };
 
 // Accumulators start at the bias of their column (C fragment: col = lane & 31 of tile j) instead of zero, so no epilogue
 // carries a bias add or keeps bias vectors live; with a per-channel weight scale (e4m3) the start value is bias / scale and
@@ -348,17 +348,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
                             store_cvt<_Float16, 8>((_Float16*)p.out + orow * ldo + gc, v);
                         } else if (out_mode == OUT_BF16) {    // bf16 single plane (fp8 mode: attention operands stay bf16)
                             store_cvt<__bf16, 8>((__bf16*)p.out + orow * ldo + gc, v);
+                        } else if (out_mode == OUT_BF16X2) {  // split-bf16 planes (F16C8 mode: DINOv2's split-bf16 attention)
+                            store_operand8<__bf16, 2>((__bf16*)p.out, out_plane, orow * ldo + gc, v);
                         } else {
-                            T* o = (T*)p.out + orow * ldo + gc;
-                            if constexpr (NS == 2) {
-                                float hi8[8], lo8[8];
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) { hi8[e] = to_f32<T>(from_f32<T>(v[e])); lo8[e] = v[e] - hi8[e]; }
-                                store_cvt<T, 8>(o, hi8);
-                                store_cvt<T, 8>(o + out_plane, lo8);
-                            } else {
-                                store_cvt<T, 8>(o, v);
-                            }
+                            store_operand8<T, NS>((T*)p.out, out_plane, orow * ldo + gc, v);
                         }
                     }
                 }
@@ -962,6 +955,232 @@ inline bool wide_epilogue_ok(const bd_gemm_args& p, int ns) {
            (!p.wscale || ((uintptr_t)p.wscale & 15) == 0) && (p.out_f32 || ns == 1 || (p.out_plane % 8 == 0));
 }
 
+// ------------------------------------------------------------------------------------------------
+// BD_PREC_F16C8 GEMM (bd_common.h: f16 hi pass + one e4m3 correction pass; 3 bytes per element through LDS-DMA).
+// Same producer / consumer persistent structure and 256 x 192 tile as gemm_kernel_pc, with
+//   * a stage of four sub-planes per 32-deep slab: A hi (256 x 64 B), W hi (192 x 64 B), A lo8 (256 x 32 B), W lo8 (192 x 32 B)
+//     = 42 KiB, so THREE stages fit next to nothing else (the LDS-staged epilogue's 48 KiB scratch overlays stage 2, which is
+//     where every tile's last slab lives when K / 32 is a multiple of 3 -- K = 768 and 3072 -- and is free while the next
+//     tile's first two slabs land in stages 0 and 1).  With three stages the producers run TWO slabs ahead and wait with a
+//     counted vmcnt: the ~1100-cycle issue-to-landing latency of a slab, which bounds the 2-stage kernels at ~2800 cycles per
+//     slab in this operand class, is off the critical path.  NSTAGE = 2 (scratch separate) serves the other K.
+//   * the e4m3 image q8 of an f16 fragment derived in registers (v_cvt_scalef32_pk_fp8_f16, 4 per fragment), so the
+//     correction pass costs one extra ds_read_b128 per 32-row fragment pair instead of two.
+template <int NSTAGE>
+__global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_args p) {
+    constexpr int WM = 4, WN = 2, MI = 2, NI = 3, NPW = 4, NCW = WM * WN;
+    constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32, BK = 32;
+    constexpr int A0 = TBM * 64, W0 = TBN * 64, A1 = TBM * 32, W1 = TBN * 64;     // W's e4m3 plane carries q8 AND lo8 (weights: packed once)
+    constexpr int OFF_W0 = A0, OFF_A1 = A0 + W0, OFF_W1 = A0 + W0 + A1, STAGE = A0 + W0 + A1 + W1;
+    constexpr int SR = 16, SCRATCH = NCW * SR * NI * 32 * 4;
+    static_assert(SCRATCH == STAGE, "the epilogue scratch overlays stage 2 exactly");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE + SCRATCH];   // stages at 0, STAGE, 2*STAGE; scratch at 2*STAGE
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = p.M, N = p.N;
+    const int nk = p.K / BK;
+    const int tilesM = (M + TBM - 1) / TBM, tilesN = (N + TBN - 1) / TBN, nt = tilesM * tilesN;
+    const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7;
+    const int tq = nt >> 3, tr = nt & 7;
+    const int t_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int t_end = t_begin + tq + (xcd < tr ? 1 : 0);
+    const int stride = (nwg - xcd + 7) >> 3;
+    constexpr int GROUP_M = 4;
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int per_group = GROUP_M * tilesN;
+        const int g = t / per_group, in_g = t % per_group;
+        const int gm0 = g * GROUP_M;
+        const int gh = (tilesM - gm0) < GROUP_M ? (tilesM - gm0) : GROUP_M;
+        m0 = (gm0 + in_g % gh) * TBM;
+        n0 = (in_g / gh) * TBN;
+    };
+    const unsigned lds_off = lds_offset_of(lds);
+
+    if (wid >= NCW) {
+        // ------------------------------------------------------------------ producers
+        const int pw = wid - NCW;
+        const unsigned lda0 = (unsigned)(p.lda * 2), ldw0 = (unsigned)(p.ldw * 2), lda1 = (unsigned)p.lda, ldw1 = (unsigned)(p.ldw * 2);
+        unsigned oA0[4], oW0[3], oA1[2], oW1[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int row = (pw + 4 * i) * 16 + lane / 4; oA0[i] = row * lda0 + swz_chunk<4>(row, lane % 4) * 16; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const int row = (pw + 4 * i) * 16 + lane / 4; oW0[i] = row * ldw0 + swz_chunk<4>(row, lane % 4) * 16; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int row = (pw + 4 * i) * 32 + lane / 2; oA1[i] = row * lda1 + swz_chunk<2>(row, lane % 2) * 16; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const int row = (pw + 4 * i) * 16 + lane / 4; oW1[i] = row * ldw1 + swz_chunk<4>(row, lane % 4) * 16; }
+        const unsigned char* pA0 = (const unsigned char*)p.A;
+        const unsigned char* pW0 = (const unsigned char*)p.W;
+        const unsigned char* pA1 = pA0 + p.a_plane * 2;
+        const unsigned char* pW1 = pW0 + p.w_plane * 2;
+        auto issue = [&](int stage, int m0, int n0, int kt) {
+            const int rows_a = (M - m0) < TBM ? (M - m0) : TBM, rows_w = (N - n0) < TBN ? (N - n0) : TBN;
+            const unsigned la0 = (unsigned)(rows_a - 1) * lda0 + 48, lw0 = (unsigned)(rows_w - 1) * ldw0 + 48;
+            const unsigned la1 = (unsigned)(rows_a - 1) * lda1 + 16, lw1 = (unsigned)(rows_w - 1) * ldw1 + 48;
+            const unsigned st = lds_off + stage * STAGE + pw * 1024;
+            const unsigned char* ba0 = pA0 + (int64_t)m0 * lda0 + (int64_t)kt * 64;
+            const unsigned char* bw0 = pW0 + (int64_t)n0 * ldw0 + (int64_t)kt * 64;
+            const unsigned char* ba1 = pA1 + (int64_t)m0 * lda1 + (int64_t)kt * 32;
+            const unsigned char* bw1 = pW1 + (int64_t)n0 * ldw1 + (int64_t)kt * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16_s(oA0[i] < la0 ? oA0[i] : la0, ba0, st + i * 4096);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) glds16_s(oW0[i] < lw0 ? oW0[i] : lw0, bw0, st + OFF_W0 + i * 4096);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) glds16_s(oA1[i] < la1 ? oA1[i] : la1, ba1, st + OFF_A1 + i * 4096);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) glds16_s(oW1[i] < lw1 ? oW1[i] : lw1, bw1, st + OFF_W1 + i * 4096);
+        };
+        // issue cursor over this workgroup's slab sequence (all tiles, slab by slab); slab number ig goes to stage ig % NSTAGE
+        int ig = 0, ist = 0, it = t_begin + (bid >> 3), ikt = 0, im0 = 0, in0 = 0;
+        if (it < t_end) tile_origin(it, im0, in0);
+        auto issue_next = [&]() {
+            if (it >= t_end) return;
+            issue(ist, im0, in0, ikt);
+            ++ig;
+            ist = ist + 1 == NSTAGE ? 0 : ist + 1;
+            if (++ikt == nk) {
+                ikt = 0;
+                it += stride;
+                if (it < t_end) tile_origin(it, im0, in0);
+            }
+        };
+        // wait until at most `slabs` of this wave's most recent slab fetches are still in flight (12 pieces each)
+        auto wait_landed = [&](int slabs) {
+            if (slabs <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        };
+#ifdef BD_GEMM_PROBE
+        unsigned probe_ts = 0;
+#endif
+#pragma unroll
+        for (int i = 0; i < NSTAGE - 1; ++i) issue_next();
+        int g = 0;
+        for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
+            for (int kt = 0; kt < nk; ++kt) {
+                BD_PROBE_IF(g < 20, g * 3 + 2)
+                wait_landed(ig - g - 1);                  // slab g has landed (later slabs may still fly)
+                BD_PROBE_IF(g < 20, g * 3)
+                pc_barrier();                             // B(g): releases the consumers into slab g; slab g-1 is dead
+                BD_PROBE_IF(g < 20, g * 3 + 1)
+                if (ig <= g + NSTAGE - 1) issue_next();   // refill the stage slab g-1 lived in
+                ++g;
+            }
+            pc_barrier();                                 // X: consumers are done with the tile's last slab (scratch = stage 2 ..)
+        }
+#ifdef BD_GEMM_PROBE
+        if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * 16 + wid) * 64 + lane] = probe_ts;
+#endif
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wm = wid / WN, wn = wid % WN;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int scale_a = 127, scale_w = 127 - (p.w_qexp + BD_F16C8_D);           // E8M0: the cross terms carry 2^(E + D)
+    int g_st = 0;
+#ifdef BD_GEMM_PROBE
+    unsigned probe_ts = 0;
+    int g = 0;
+#endif
+    BD_PROBE(58) BD_PROBE_RT(56)
+    for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
+        f32x16 acc[MI][NI];
+        acc_init_bias<MI, NI>(p, acc, n0 + wn * (NI * 32), lane);
+        for (int kt = 0; kt < nk; ++kt) {
+            BD_PROBE_IF(g < 20, g * 3)
+            pc_barrier();                                 // B
+            BD_PROBE_IF(g < 20, g * 3 + 1)
+#ifdef BD_GEMM_PROBE
+            ++g;
+#endif
+            const unsigned char* base = lds + g_st * STAGE;
+            g_st = g_st + 1 == NSTAGE ? 0 : g_st + 1;
+            f16x8 ah[2][MI], wh[2][NI];
+            u128 al[MI], aq[MI];
+            i32x8 w8[NI];
+#define LD16(dst, ptr, row, ks) dst = __builtin_bit_cast(f16x8, *(const u128*)((ptr) + (row) * 64 + (swz_chunk<4>((row), (ks) * 2 + lhalf) << 4)));
+#define LDLO(dst, ptr, row) dst = *(const u128*)((ptr) + (row) * 32 + (swz_chunk<2>((row), lhalf) << 4));
+            // W's e4m3 operand straight from LDS: 32 bytes = [q8 x 16 | lo8 x 16] of this lane half
+#define LDW8(dst, ptr, row)                                                                                    \
+            {                                                                                                     \
+                const u128 lo_ = *(const u128*)((ptr) + (row) * 64 + (swz_chunk<4>((row), 2 * lhalf) << 4));        \
+                const u128 hi_ = *(const u128*)((ptr) + (row) * 64 + (swz_chunk<4>((row), 2 * lhalf + 1) << 4));    \
+                dst = (i32x8){(int)lo_[0], (int)lo_[1], (int)lo_[2], (int)lo_[3], (int)hi_[0], (int)hi_[1], (int)hi_[2], (int)hi_[3]}; \
+            }
+            // e4m3 image of a lane's two f16 A fragments of one row block (k-steps 0 and 1: 16 values), 4 dwords.
+            // (pairs built element-wise: __builtin_bit_cast of a vector ELEMENT to a 2 x f16 vector is miscompiled by hipcc 7.2
+            // here -- every conversion then reads the first dword)
+#define Q8(dst, f0, f1, sc)                                                                                   \
+            {                                                                                                     \
+                typedef _Float16 h2_ __attribute__((ext_vector_type(2)));                                         \
+                typedef short s2_ __attribute__((ext_vector_type(2)));                                            \
+                s2_ d0_ = {0, 0}, d1_ = {0, 0}, d2_ = {0, 0}, d3_ = {0, 0};                                       \
+                d0_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d0_, (h2_){f0[0], f0[1]}, sc, false);              \
+                d0_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d0_, (h2_){f0[2], f0[3]}, sc, true);               \
+                d1_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d1_, (h2_){f0[4], f0[5]}, sc, false);              \
+                d1_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d1_, (h2_){f0[6], f0[7]}, sc, true);               \
+                d2_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d2_, (h2_){f1[0], f1[1]}, sc, false);              \
+                d2_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d2_, (h2_){f1[2], f1[3]}, sc, true);               \
+                d3_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d3_, (h2_){f1[4], f1[5]}, sc, false);              \
+                d3_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d3_, (h2_){f1[6], f1[7]}, sc, true);               \
+                dst = (u128){__builtin_bit_cast(unsigned, d0_), __builtin_bit_cast(unsigned, d1_),               \
+                             __builtin_bit_cast(unsigned, d2_), __builtin_bit_cast(unsigned, d3_)};               \
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) LD16(wh[ks][j], base + OFF_W0, wn * (NI * 32) + j * 32 + lrow, ks)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) LD16(ah[ks][i], base, wm * (MI * 32) + i * 32 + lrow, ks)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int NMM = MI * NI;
+            // Register rotation (168-VGPR budget): A's q8 images are derived under the first f16 k-step, whose fragments then
+            // die; A's lo8 and W's [q8 | lo8] fragments are loaded into the freed registers under the second k-step.
+#pragma unroll
+            for (int q = 0; q < NMM; ++q) {                       // f16, k-step 0 (+ q8 of A)
+                const int i = q % MI, j = q / MI;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], wh[0][j], acc[i][j], 0, 0, 0);
+                if (q < MI) Q8(aq[q], ah[0][q], ah[1][q], 1.0f)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < NMM; ++q) {                       // f16, k-step 1 (+ the e4m3 fragment loads)
+                const int i = q % MI, j = q / MI;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], wh[1][j], acc[i][j], 0, 0, 0);
+                if (q < NI) LDW8(w8[q], base + OFF_W1, wn * (NI * 32) + q * 32 + lrow)
+                else if (q - NI < MI) LDLO(al[q - NI], base + OFF_A1, wm * (MI * 32) + (q - NI) * 32 + lrow)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < NMM; ++q) {                       // e4m3 correction pass: [lo_A | q_A] . [q_W | lo_W]
+                const int i = q % MI, j = q / MI;
+                const i32x8 a8 = {(int)al[i][0], (int)al[i][1], (int)al[i][2], (int)al[i][3], (int)aq[i][0], (int)aq[i][1], (int)aq[i][2], (int)aq[i][3]};
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, w8[j], acc[i][j], 0, 0, 0, scale_a, 0, scale_w);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef LDW8
+#undef LD16
+#undef LDLO
+#undef Q8
+        }
+        BD_PROBE_IF(g == nk, 60)
+        pc_barrier();                                     // X
+        BD_PROBE_IF(g == nk, 61)
+        unsigned char* scratch = lds + 2 * STAGE + wid * (SR * NI * 32 * 4);
+        gemm_epilogue_lds<f16c8, 2, MI, NI, SR, true>(p, acc, scratch, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+        BD_PROBE_IF(g == nk, 62)
+    }
+    BD_PROBE(59) BD_PROBE_RT(57)
+#ifdef BD_GEMM_PROBE
+    if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * 16 + wid) * 64 + lane] = probe_ts;
+#endif
+}
+
 template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_pc(const bd_gemm_args& a, hipStream_t s, int cus) {
     constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32;
     constexpr int NPW = 4;        // one producer wave per SIMD: a single wave issues one LDS-DMA piece per ~70 cycles, the CU ~23
@@ -1100,6 +1319,23 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
     return BD_OK;
 }
 
+// F16C8 has its own persistent kernel; every shape goes through it
+int launch_f16c8(const bd_gemm_args& a, hipStream_t s) {
+    if (!wide_epilogue_ok(a, 2) || 256 * a.lda * 2 >= ((int64_t)1 << 31) || 256 * a.ldw * 2 >= ((int64_t)1 << 31)) return BD_ERR_ALIGN;
+    if ((a.K % 32) || (a.lda % 32) || (a.ldw % 32)) return BD_ERR_SHAPE;            // the lo8 planes are laid out in 32-element blocks
+    if (a.out_f32 == OUT_OPERAND && (a.ldo % 32)) return BD_ERR_SHAPE;
+    if (a.w_qexp + BD_F16C8_D < -100 || a.w_qexp + BD_F16C8_D > 120) return BD_ERR_SHAPE;
+    const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
+    const int cus = cu_count();
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 191) / 192);
+    const int grid = tiles < cus ? tiles : cus;
+    if ((a.K / 32) % 3 == 0) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3>), dim3(grid), dim3(768), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2>), dim3(grid), dim3(768), 0, s, a);
+    bd_trace_close(s, slot);
+    BD_CHECK_LAUNCH();
+    return BD_OK;
+}
+
 }  // namespace
 
 extern "C" int bd_gemm(const bd_gemm_args* args, int prec, void* stream) {
@@ -1109,9 +1345,10 @@ extern "C" int bd_gemm(const bd_gemm_args* args, int prec, void* stream) {
     const int esz = prec == BD_PREC_FP8 ? 1 : 2;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % kmult) != 0) return BD_ERR_SHAPE;
     if (((a.lda * esz) % 16) || ((a.ldw * esz) % 16) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15)) return BD_ERR_ALIGN;
-    if (prec == BD_PREC_BF16X3 && ((a.a_plane % 8) || (a.w_plane % 8))) return BD_ERR_ALIGN;
+    if ((prec == BD_PREC_BF16X3 || prec == BD_PREC_F16C8) && ((a.a_plane % 8) || (a.w_plane % 8))) return BD_ERR_ALIGN;
     if (a.addtab && a.tab_rows <= 0) return BD_ERR_SHAPE;
-    if (a.out_f32 < 0 || a.out_f32 > 3) return BD_ERR_DTYPE;
+    if (a.out_f32 < 0 || a.out_f32 > 4) return BD_ERR_DTYPE;
+    if (a.out_f32 == 4 && (a.out_plane % 8)) return BD_ERR_ALIGN;
     // the single-plane 16-bit outputs and every fp8-mode output exist only in the wide (16-byte) epilogue
     const bool needs_wide = a.out_f32 >= 2 || (prec == BD_PREC_FP8 && a.out_f32 == 0);
     if (needs_wide && ((a.N % 8) || (a.ldo % 8) || ((uintptr_t)a.out & 15))) return BD_ERR_ALIGN;
@@ -1122,6 +1359,7 @@ extern "C" int bd_gemm(const bd_gemm_args* args, int prec, void* stream) {
         case BD_PREC_F16: return launch<_Float16, 1, 64>(a, s);
         case BD_PREC_BF16X3: return launch<__bf16, 2, 32>(a, s);
         case BD_PREC_FP8: return launch<fp8e4, 1, 128>(a, s);
+        case BD_PREC_F16C8: return launch_f16c8(a, s);
         default: return BD_ERR_DTYPE;
     }
 }

@@ -4,19 +4,6 @@
 
 namespace {
 
-template <class T, int NS>
-__device__ __forceinline__ void store8(T* dst, int64_t plane, const float (&v)[8]) {
-    if constexpr (NS == 2) {
-        float hi8[8], lo8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { hi8[j] = to_f32<T>(from_f32<T>(v[j])); lo8[j] = v[j] - hi8[j]; }
-        store_cvt<T, 8>(dst, hi8);
-        store_cvt<T, 8>(dst + plane, lo8);
-    } else {
-        store_cvt<T, 8>(dst, v);
-    }
-}
-
 // one thread per 8-wide chunk of an output row [n*grid*grid, kpad]; k = c*p*p + py*p + px
 template <class T, int NS>
 __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ img, int dtype, void* __restrict__ out_,
@@ -44,7 +31,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ im
         }
         v[j] = y;
     }
-    store8<T, NS>(out + row * kpad + kc * 8, plane, v);
+    store_operand8<T, NS>(out, plane, row * kpad + kc * 8, v);
 }
 
 // BETR.patchify: chunk j of a row holds the `channels` (= 8) values of pixel (py, px), j = py*p + px
@@ -70,7 +57,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = 0.f;
     }
-    store8<T, NS>(out + row * kpad + j * 8, plane, v);
+    store_operand8<T, NS>(out, plane, row * kpad + j * 8, v);
 }
 
 __global__ __launch_bounds__(256) void prefix_kernel(float* __restrict__ x, const float* __restrict__ prefix,
@@ -109,7 +96,7 @@ __global__ __launch_bounds__(256) void gather_query_kernel(const float* __restri
     const float* src = x + (((int64_t)b * T_ + (qidx ? qidx[b] : 0)) * P + tok) * dim + c * 8;
     const float4 a = *(const float4*)src, bb = *(const float4*)(src + 4);
     const float v[8] = {a.x, a.y, a.z, a.w, bb.x, bb.y, bb.z, bb.w};
-    store8<T, NS>(out + ((int64_t)b * P + tok) * dim + c * 8, plane, v);
+    store_operand8<T, NS>(out, plane, ((int64_t)b * P + tok) * dim + c * 8, v);
 }
 
 __global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ x, const int32_t* __restrict__ qidx,
@@ -218,6 +205,7 @@ inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
         case BD_PREC_F16: hipLaunchKernelGGL((FN<_Float16, 1>), __VA_ARGS__); break;   \
         case BD_PREC_BF16X3: hipLaunchKernelGGL((FN<__bf16, 2>), __VA_ARGS__); break;  \
         case BD_PREC_FP8: hipLaunchKernelGGL((FN<fp8e4, 1>), __VA_ARGS__); break;      \
+        case BD_PREC_F16C8: hipLaunchKernelGGL((FN<f16c8, 2>), __VA_ARGS__); break;    \
         default: return BD_ERR_DTYPE;                                                  \
     }
 

@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             }
             if (out32) *(float4*)(out32 + (int64_t)r * ldo + c) = make_float4(y[0], y[1], y[2], y[3]);
             if (out16) {
-                if constexpr (NS == 2) {
+                if constexpr (__is_same(T, f16c8)) {
+                    f16c8_store4(out16, out16_plane, (int64_t)r * cols + c, y);
+                } else if constexpr (NS == 2) {
                     float hi4[4], lo4[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { hi4[j] = to_f32<T>(from_f32<T>(y[j])); lo4[j] = y[j] - hi4[j]; }
@@ -213,6 +215,9 @@ extern "C" int bd_layernorm(const float* x, int64_t ldx, const float* gamma, con
         case BD_PREC_F16: return launch_ln<_Float16, 1>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
         case BD_PREC_BF16X3: return launch_ln<__bf16, 2>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
         case BD_PREC_FP8: return launch_ln<fp8e4, 1>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
+        case BD_PREC_F16C8:
+            if (out16 && cols % 32) return BD_ERR_SHAPE;      // the lo8 plane is laid out in 32-element blocks
+            return launch_ln<f16c8, 2>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
         default: return BD_ERR_DTYPE;
     }
 }

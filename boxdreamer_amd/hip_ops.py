@@ -23,9 +23,72 @@ def _plane(t: torch.Tensor, prec) -> int:
     return t[0].numel() if planes(prec) == 2 else 0
 
 
+E4M3_MAX = 448.0
+
+
+def f16c8_qexp(w: torch.Tensor) -> int:
+    """Exponent E of a weight tensor's e4m3 planes: the largest power of two that keeps max|w| * 2^E inside e4m3."""
+    m = float(w.detach().abs().max())
+    return 0 if m <= 0 else int(torch.floor(torch.log2(torch.tensor(E4M3_MAX / m))).item())
+
+
+def _f16c8_perm(K: int, device) -> torch.Tensor:
+    """Byte position -> k inside every 32-block of the lo8 plane: byte 16 h + 8 a + j holds k = 16 a + 8 h + j."""
+    pos = torch.arange(32, device=device)
+    h, a, j = pos // 16, (pos // 8) % 2, pos % 8
+    k_of_pos = 16 * a + 8 * h + j
+    return (torch.arange(0, K, 32, device=device)[:, None] + k_of_pos[None, :]).reshape(-1)
+
+
+def f16c8_encode(x: torch.Tensor, qexp: int = 0, weight: bool = False) -> torch.Tensor:
+    """fp32 [rows, K] (K % 32 == 0) -> [2, rows, K] float16 STORAGE of the F16C8 operand class (include/boxdreamer_hip.h):
+    plane 0 = f16(x) (activations clamped to +-448 first); plane 1 = raw bytes:
+      activations: the first rows*K bytes are the lo8 plane e4m3((x - hi) 2^D), k-permuted per 32-block (rest unused);
+      weights:     per 32-block 64 bytes = for each lane half h: [q8 x 16 | lo8 x 16] of its sixteen k (same k order),
+                   q8 = e4m3(hi 2^E), lo8 = e4m3((w - hi) 2^(E + D)).
+    Torch ops: weight packing at load time and test helpers (not on the hot path)."""
+    x = x.float()
+    if not weight:
+        x = x.clamp(-E4M3_MAX, E4M3_MAX)
+    rows, K = x.shape
+    assert K % 32 == 0, "F16C8 operands are laid out in 32-element blocks"
+    hi = x.half()
+    lo = (x - hi.float()) * 2.0 ** (qexp + _lib.F16C8_D)
+    perm = _f16c8_perm(K, x.device)
+    l8 = lo.clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).view(torch.uint8)[:, perm]
+    if weight:
+        q8 = (hi.float() * 2.0 ** qexp).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).view(torch.uint8)[:, perm]
+        mix = torch.stack([q8.reshape(rows, K // 16, 16), l8.reshape(rows, K // 16, 16)], dim=2)     # [rows, K/16, 2, 16]
+        plane1 = mix.reshape(-1).contiguous()
+    else:
+        plane1 = torch.zeros((rows * K * 2,), dtype=torch.uint8, device=x.device)
+        plane1[: rows * K] = l8.reshape(-1)
+    return torch.stack([hi, plane1.view(torch.float16).reshape(rows, K)]).contiguous()
+
+
+def f16c8_decode(t: torch.Tensor, qexp: int = 0, weight: bool = False):
+    """(hi, lo, q) as fp32 [rows, K] -- exactly the three values the GEMM multiplies."""
+    hi = t[0].float()
+    rows, K = hi.shape
+    raw = t[1].contiguous().view(torch.uint8).reshape(-1)
+    inv = torch.empty(K, dtype=torch.long, device=t.device)
+    inv[_f16c8_perm(K, t.device)] = torch.arange(K, device=t.device)
+    dec = lambda b: b[:, inv].contiguous().view(torch.float8_e4m3fn).float()
+    if weight:
+        mix = raw.reshape(rows, K // 16, 2, 16)
+        q = dec(mix[:, :, 0].reshape(rows, K)) * 2.0 ** -qexp
+        lo = dec(mix[:, :, 1].reshape(rows, K)) * 2.0 ** -(qexp + _lib.F16C8_D)
+    else:
+        lo = dec(raw[: rows * K].reshape(rows, K)) * 2.0 ** -(qexp + _lib.F16C8_D)
+        q = (hi * 2.0 ** qexp).to(torch.float8_e4m3fn).float() * 2.0 ** -qexp     # derived by the GEMM in registers
+    return hi, lo, q
+
+
 def to_operand(x: torch.Tensor, prec) -> torch.Tensor:
     """fp32 [rows, cols] -> operand tensor (test helper; torch ops, not on the product path)."""
     dt = _lib.op_dtype(prec)
+    if prec_id(prec) == _lib.PREC_F16C8:
+        return f16c8_encode(x, 0, False)
     if prec_id(prec) == _lib.PREC_FP8:
         return x.float().clamp(-448.0, 448.0).to(dt).contiguous()
     hi = x.to(dt)
@@ -35,14 +98,17 @@ def to_operand(x: torch.Tensor, prec) -> torch.Tensor:
 
 
 def from_operand(t: torch.Tensor, prec) -> torch.Tensor:
+    if prec_id(prec) == _lib.PREC_F16C8:
+        hi, lo, _ = f16c8_decode(t)
+        return hi + lo
     return t.float() if planes(prec) == 1 else t[0].float() + t[1].float()
 
 
-_OUT_DTYPES = {2: torch.float16, 3: torch.bfloat16}
+_OUT_DTYPES = {2: torch.float16, 3: torch.bfloat16}      # 4: split-bf16 planes [2, rows, N]
 
 
 def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, addtab=None, out=None,
-         out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0), wscale=None, out_mode=None):
+         out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0), wscale=None, out_mode=None, w_qexp=0):
     """out[map(r)] = act(wscale * (A W^T) + bias) + addtab[r % rows(addtab)] + resid[map(r)].
     out_mode: None -> operand dtype (or fp32 with out_f32), 2 -> f16 single plane, 3 -> bf16 single plane."""
     lib = _lib.load()
@@ -58,6 +124,8 @@ def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, add
             out = torch.empty((rows_out, N), dtype=torch.float32, device=A2.device)
         elif mode in _OUT_DTYPES:
             out = torch.empty((rows_out, N), dtype=_OUT_DTYPES[mode], device=A2.device)
+        elif mode == 4:
+            out = torch.empty((2, rows_out, N), dtype=torch.bfloat16, device=A2.device)
         else:
             out = _alloc16(rows_out, N, prec, A2.device)
     g = _lib.GemmArgs()
@@ -67,8 +135,10 @@ def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, add
     g.wscale = ptr(wscale)
     g.resid, g.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
     g.addtab, g.tab_rows = ptr(addtab), (addtab.shape[0] if addtab is not None else 0)
-    o2 = out if (mode or np_ == 1) else out[0]
-    g.out, g.ldo, g.out_plane, g.out_f32 = ptr(out), o2.stride(0), (0 if mode else _plane(out, prec)), mode
+    o2 = out[0] if (mode == 4 or (not mode and np_ == 2)) else out
+    g.out, g.ldo, g.out_f32 = ptr(out), o2.stride(0), mode
+    g.out_plane = out[0].numel() if mode == 4 else (0 if mode else _plane(out, prec))
+    g.w_qexp = int(w_qexp)
     g.M, g.N, g.K, g.act = M, N, K, act
     g.rpg_in, g.rpg_out, g.row_off = rpg
     check(lib.bd_gemm(C.byref(g), prec_id(prec), stream()), "bd_gemm")

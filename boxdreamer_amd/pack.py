@@ -56,6 +56,11 @@ def pack_linear_weight(weight: torch.Tensor, prec, kpad: int | None = None,
     if kp != k:
         w = F.pad(w, (0, kp - k))
     scale = None
+    if _lib.prec_id(prec) == _lib.PREC_F16C8:
+        from . import hip_ops
+        qexp = hip_ops.f16c8_qexp(w)
+        packed = hip_ops.f16c8_encode(w, qexp, weight=True)
+        return (packed, qexp) if return_scale else packed
     if _lib.prec_id(prec) == _lib.PREC_FP8:
         scale = (w.abs().amax(dim=1).clamp_min(1e-30) / E4M3_MAX).contiguous()
         packed = (w / scale[:, None]).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).contiguous()
@@ -122,11 +127,13 @@ class Packed:
 
     def linear(self, w, b: torch.Tensor, device) -> _lib.Linear:
         """w: packed weight, or (packed weight, per-channel scale | None) from pack_linear_weight(return_scale=True)."""
-        scale = None
+        scale, qexp = None, 0
         if isinstance(w, tuple):
             w, scale = w
+            if isinstance(scale, int):            # F16C8: the tensor's e4m3 exponent, not a per-channel scale vector
+                scale, qexp = None, scale
         ws = self.keep(scale, device) if scale is not None else C.c_void_p(0)
-        return _lib.Linear(self.keep(w, device), self.keep(b, device), ws)
+        return _lib.Linear(self.keep(w, device), self.keep(b, device), ws, qexp)
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.tensors)

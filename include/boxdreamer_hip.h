@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define BD_ABI_VERSION 2
+#define BD_ABI_VERSION 3
 
 #define BD_DTYPE_BF16 0
 #define BD_DTYPE_F16 1
@@ -56,6 +56,16 @@ extern "C" {
  *   BD_PREC_BF16X3_ATTN_F16  f16 single-pass attention everywhere (measurement: misses the 1e-3 bar) */
 #define BD_PREC_BF16X3_ATTN_X3 6
 #define BD_PREC_BF16X3_ATTN_F16 7
+/* f16 + e4m3 corrections (round 2's strict mode; every entry point):  A.W ~= hi_A.hi_W (one f16 MFMA pass) + lo_A.q_W +
+ * q_A.lo_W (one e4m3 pass over a doubled K on the block-scaled MFMA): 2 pass-equivalents instead of BF16X3's 3, logits
+ * error 1.7e-4 at full depth, and 3 bytes per element through the GEMM's LDS-DMA instead of 4.  Operand [rows][K], K % 32 == 0:
+ * plane 0 = f16 hi; plane 1 (`plane` 2-byte units further) = lo8 = e4m3((x - hi) * 2^(E + 11)), one byte per element, the 32
+ * k of every block stored as byte 16 h + 8 a + j <- k = 16 a + 8 h + j (a, h < 2, j < 8); q8 = e4m3(hi * 2^E) is derived by
+ * the GEMM in registers.  E = 0 for activations, bd_linear.w_qexp / bd_gemm_args.w_qexp for a weight tensor.  Activation
+ * operands are clamped to +-448.  Attention: f16 single pass where q, k are RMS-normalised (BETR), split-bf16 in DINOv2. */
+#define BD_PREC_F16C8 8
+#define BD_PREC_F16_OUT_F16C8 9     /* bd_attention[_q] only: f16 qkv (one plane) in, one f16 MFMA pass, F16C8 operand out */
+#define BD_PREC_BF16X3_OUT_F16C8 10 /* bd_attention[_q] only: split-bf16 qkv planes in, split-bf16 attention, F16C8 operand out */
 
 #define BD_OK 0
 #define BD_ERR_SHAPE (-1)
@@ -92,10 +102,11 @@ typedef struct bd_gemm_args {
     const float* addtab; int tab_rows;             /* fp32 [tab_rows, N] or NULL */
     void* out; int64_t ldo; int64_t out_plane;     /* 16-bit (operand dtype of `prec`) or fp32 */
     int out_f32;                                   /* 0: operand-dtype output (planes per `prec`), 1: fp32, 2: f16 single plane,
-                                                      3: bf16 single plane */
+                                                      3: bf16 single plane, 4: split-bf16 (hi, lo) planes at out_plane */
     int M, N, K;
     int act;
     int rpg_in, rpg_out, row_off;
+    int w_qexp;                                    /* BD_PREC_F16C8: exponent E of the weight's e4m3 planes */
 } bd_gemm_args;
 int bd_gemm(const bd_gemm_args* args /*[host]*/, int prec, void* stream);
 
@@ -202,6 +213,7 @@ typedef struct bd_linear {
     const void* w;       /* [N, Kpad] operand dtype, nn.Linear layout; BF16X3: hi plane then lo plane */
     const float* b;      /* [N] */
     const float* wscale; /* [N] per-output-channel scale of an e4m3 weight (FP8 mode) or NULL */
+    int w_qexp;          /* BD_PREC_F16C8: exponent E of the weight's e4m3 planes (q8 = e4m3(w * 2^E)) */
 } bd_linear;
 
 typedef struct bd_block_weights {

@@ -43,6 +43,45 @@ def test_gemm_plain(hip, prec, M, N, K):
     assert torch.equal(out.cpu(), ai @ wi.t())
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (77, 1568, 768), (1000, 768, 3072), (2048, 768, 128),
+                                   (7500, 2304, 768), (9000, 3072, 640), (16500, 1024, 320)])
+def test_gemm_f16c8(hip, M, N, K):
+    """BD_PREC_F16C8: f16 hi pass + ONE e4m3 pass over [lo_A | q_A] . [q_W | lo_W] on the block-scaled MFMA (fixed
+    power-of-two scales).  Checked against fp64 arithmetic on EXACTLY the three decoded planes the kernel multiplies
+    (hip_ops.f16c8_decode), so only the fp32 accumulation order differs; and against the true product: the scheme must be
+    >= 8x closer to it than a plain f16 pass.  Also every output form of the class: fp32 (+ in-place residual), the operand
+    class itself with GELU (exact erf), an f16 plane, split-bf16 planes."""
+    from boxdreamer_amd import _lib
+    a, w, b = _rand("a", (M, K)), _rand("w", (N, K), 0.03), _rand("b", (N,), 0.1)
+    e = hip_ops.f16c8_qexp(w)
+    a16, w16 = hip_ops.f16c8_encode(a.cuda(), 0, False), hip_ops.f16c8_encode(w.cuda(), e, True)
+    ah, al, aq = (t.cpu().double() for t in hip_ops.f16c8_decode(a16))
+    wh, wl, wq = (t.cpu().double() for t in hip_ops.f16c8_decode(w16, e, True))
+    ref = ah @ wh.t() + al @ wq.t() + aq @ wl.t() + b.double()
+    out = hip_ops.gemm(a16, w16, b.cuda(), prec="f16c8", out_f32=True, w_qexp=e)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5 * K ** 0.5, err
+    true = a.double() @ w.double().t() + b.double()
+    e_scheme = (out.cpu().double() - true).abs().max().item()
+    e_f16 = ((ah @ wh.t() + b.double()) - true).abs().max().item()
+    assert e_scheme * 8 < e_f16 + 1e-6, (e_scheme, e_f16)
+    # in-place fp32 residual
+    res = _rand("res", (M, N), 1.0)
+    buf = res.clone().cuda()
+    hip_ops.gemm(a16, w16, b.cuda(), prec="f16c8", out_f32=True, out=buf, resid=buf, w_qexp=e)
+    assert (buf.cpu().double() - (ref + res.double())).abs().max().item() < 2e-5 * K ** 0.5 + 1e-6
+    if N % 32 == 0:
+        g = F.gelu(ref.float())
+        o = hip_ops.gemm(a16, w16, b.cuda(), prec="f16c8", act=_lib.ACT_GELU, w_qexp=e)          # operand-class output
+        oh, ol, oq = hip_ops.f16c8_decode(o)
+        assert ((oh + ol).cpu() - g).abs().max().item() < 4e-4 * max(1.0, g.abs().max().item()) * 2.0 ** -4 + 2e-5
+        assert ((oq.cpu() - g).abs() <= g.abs() * 2.0 ** -4 + 2.0 ** -9).all()
+        o = hip_ops.gemm(a16, w16, b.cuda(), prec="f16c8", out_mode=2, w_qexp=e)                 # f16 plane
+        assert (o.float().cpu() - ref.float()).abs().max().item() < 2.0 ** -10 * max(1.0, ref.abs().max().item())
+        o = hip_ops.gemm(a16, w16, b.cuda(), prec="f16c8", out_mode=4, w_qexp=e)                 # split-bf16 planes
+        assert ((o[0].float() + o[1].float()).cpu() - ref.float()).abs().max().item() < 2.0 ** -15 * max(1.0, ref.abs().max().item()) + 2e-5 * K ** 0.5
+
+
 @pytest.mark.parametrize("prec", PRECS + ["fp8"])
 @pytest.mark.parametrize("M,N,K", [(7500, 2304, 768), (9000, 3072, 640), (16500, 1024, 320)])
 def test_gemm_block_sized(hip, prec, M, N, K):

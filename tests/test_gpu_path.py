@@ -3,7 +3,8 @@ plugin surface, against the CPU oracle on the same seeded weights/inputs and aga
 golden fixtures (generated from the real reference by oracle/make_golden.py).
 
 Tolerances (max-abs on the heatmap LOGITS, written here as the contract):
-  bf16x3 (strict mode)  <= 1e-3   -- north_star's bar, with identical top-20 index sets expected
+  f16c8 (strict mode)   <= 1e-3   -- north_star's bar (f16 pass + e4m3 correction pass; measured ~2e-4 at full depth)
+  bf16x3 (round-1 strict) <= 1e-3 -- split-bf16, 3 passes (measured ~1.3e-4)
   fp16                  <= 2.5e-2 -- one f16 MFMA pass (operand rounding 2^-11)
   bf16                  <= 1e-1   -- one bf16 MFMA pass (operand rounding 2^-8); the reference's own
                                      bf16-autocast forward is 2.2e-2 off its fp32 forward on the +-1
@@ -22,9 +23,9 @@ from boxdreamer_amd.encoder import DinoV2Wrapper
 from oracle import boxdreamer_oracle as orc
 
 pytestmark = pytest.mark.gpu
-LOGIT_TOL = {"bf16x3": 1e-3, "bf16x3_attn_x3": 1e-3, "fp16": 2.5e-2, "bf16": 1e-1}
-FEAT_TOL = {"bf16x3": 1e-3, "bf16x3_attn_x3": 1e-3, "fp16": 2.5e-2, "bf16": 1e-1}
-STRICT = ("bf16x3", "bf16x3_attn_x3")
+LOGIT_TOL = {"f16c8": 1e-3, "bf16x3": 1e-3, "bf16x3_attn_x3": 1e-3, "fp16": 2.5e-2, "bf16": 1e-1}
+FEAT_TOL = {"f16c8": 1e-3, "bf16x3": 1e-3, "bf16x3_attn_x3": 1e-3, "fp16": 2.5e-2, "bf16": 1e-1}
+STRICT = ("f16c8", "bf16x3", "bf16x3_attn_x3")
 REPORT = {}
 
 
@@ -55,7 +56,7 @@ def _oracle(data, dino_depth, betr_depth):
     return orc.boxdreamer_forward(data, synth.betr_state_dict(1234, betr_depth), synth.dino_state_dict(4321, dino_depth))
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["f16c8", "bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("case", ["tiny_d2_T2", "tiny_d2_T3_B2", "full_T2", "full_T6"])
 def test_path_vs_oracle_and_golden(hip, golden_dir, prec, case):
     g = np.load(os.path.join(golden_dir, f"case_{case}.npz"))

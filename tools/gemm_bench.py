@@ -14,17 +14,21 @@ shapes = [("qkv", 49152, 2304, 768, 0), ("proj", 49152, 768, 768, 0), ("fc1+gelu
 tot_f = tot_t = 0.0
 for name, M, N, K, act in shapes:
     a = hip_ops.to_operand(torch.randn(M, K, device=dev), prec)
-    w = hip_ops.to_operand(torch.randn(N, K, device=dev) * 0.05, prec)
+    wf = torch.randn(N, K, device=dev) * 0.05
+    qe = hip_ops.f16c8_qexp(wf) if prec == "f16c8" else 0
+    w = hip_ops.f16c8_encode(wf, qe, True) if prec == "f16c8" else hip_ops.to_operand(wf, prec)
     b = torch.randn(N, device=dev)
     out16 = act == 1 or name in ("qkv", "dino qkv")
     resid = None if out16 else torch.randn(M, N, device=dev)
-    o = hip_ops.gemm(a, w, b, prec=prec, act=act, out_f32=not out16, resid=resid, out=resid)
+    o = hip_ops.gemm(a, w, b, prec=prec, act=act, out_f32=not out16, resid=resid, out=resid, w_qexp=qe)
+    for _ in range(150):          # the clock governor needs tens of milliseconds of load before the timed launches
+        hip_ops.gemm(a, w, b, prec=prec, act=act, out_f32=not out16, resid=resid, out=o, w_qexp=qe)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 10
+    n = 30
     e0.record()
     for _ in range(n):
-        hip_ops.gemm(a, w, b, prec=prec, act=act, out_f32=not out16, resid=resid, out=o)
+        hip_ops.gemm(a, w, b, prec=prec, act=act, out_f32=not out16, resid=resid, out=o, w_qexp=qe)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     tf = 2.0 * M * N * K / ms / 1e9

@@ -34,22 +34,24 @@ def run(M, N, K, prec="bf16"):
     from boxdreamer_amd import _lib, hip_ops
     lib = _lib.load()
     a = hip_ops.to_operand(torch.randn(M, K, device="cuda"), prec)
-    w = hip_ops.to_operand(torch.randn(N, K, device="cuda") * 0.05, prec)
+    wf = torch.randn(N, K, device="cuda") * 0.05
+    qe = hip_ops.f16c8_qexp(wf) if prec == "f16c8" else 0
+    w = hip_ops.f16c8_encode(wf, qe, True) if prec == "f16c8" else hip_ops.to_operand(wf, prec)
     b = torch.randn(N, device="cuda")
     nwave = 8
     buf = torch.zeros(1024 * nwave * 64, dtype=torch.int32, device="cuda")
     for _ in range(3):
-        hip_ops.gemm(a, w, b, prec=prec)
+        hip_ops.gemm(a, w, b, prec=prec, w_qexp=qe)
     lib.bd_gemm_probe_set.argtypes = [C.c_void_p]
     assert lib.bd_gemm_probe_set(C.c_void_p(buf.data_ptr())) == 0
     torch.cuda.synchronize()
     for _ in range(int(os.environ.get("BD_PROBE_LAUNCHES", "60"))):      # back to back: the stamps of the LAST launch survive,
-        hip_ops.gemm(a, w, b, prec=prec)                                   # taken at sustained (DVFS-settled) clocks
+        hip_ops.gemm(a, w, b, prec=prec, w_qexp=qe)                                   # taken at sustained (DVFS-settled) clocks
     torch.cuda.synchronize()
     if os.environ.get("BD_PROBE_PC", "1") == "1":
         return report_pc(buf.cpu().numpy().astype(np.uint32).reshape(512, 16, 64), M, N, K, prec)
     ts = buf.cpu().numpy().astype(np.uint32).reshape(1024, nwave, 64)
-    nk = min(K // (32 if prec == "bf16x3" else (128 if prec == "fp8" else 64)), 20)
+    nk = min(K // (32 if prec in ("bf16x3", "f16c8") else (128 if prec == "fp8" else 64)), 20)
     first = ts[:256]                                   # first round: one workgroup per CU
     for wv in (0, 4):
         t = first[:, wv, :].astype(np.int64)
@@ -68,7 +70,7 @@ def run(M, N, K, prec="bf16"):
 def report_pc(ts, M, N, K, prec):
     """gemm_kernel_pc (8 consumer + 4 producer waves, persistent): first tile of each of the 256 workgroups."""
     import numpy as np
-    nk = min(K // (32 if prec == "bf16x3" else (128 if prec == "fp8" else 64)), 20)
+    nk = min(K // (32 if prec in ("bf16x3", "f16c8") else (128 if prec == "fp8" else 64)), 20)
     first = ts[:256].astype(np.int64)
     d = lambda w, i, j: ((first[:, w, i] - first[:, w, j]) & 0xFFFFFFFF).astype(np.float64)
     for w in (0, 4):
