@@ -18,10 +18,12 @@ DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 PREC_BF16, PREC_F16, PREC_BF16X3, PREC_F16_OUT_BF16X3, PREC_FP8, PREC_BF16_OUT_FP8 = 0, 1, 2, 3, 4, 5
 PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16 = 6, 7      # whole-path only: attention policy of the strict family
 PREC_F16C8 = 8                                         # f16 + e4m3 corrections (include/boxdreamer_hip.h)
+PREC_BF16X3_QKV16 = 11                                 # whole-path only: split-bf16, BETR's QKV Linear as one f16 pass
 F16C8_D = 11                                           # lo planes are scaled 2^D above their q plane
 PREC_NAMES = {"bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8,
-              "bf16x3_attn_x3": PREC_BF16X3_ATTN_X3, "bf16x3_attn_f16": PREC_BF16X3_ATTN_F16, "f16c8": PREC_F16C8}
-_X3_FAMILY = (PREC_BF16X3, PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16)
+              "bf16x3_attn_x3": PREC_BF16X3_ATTN_X3, "bf16x3_attn_f16": PREC_BF16X3_ATTN_F16, "f16c8": PREC_F16C8,
+              "bf16x3_qkv16": PREC_BF16X3_QKV16}
+_X3_FAMILY = (PREC_BF16X3, PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16, 11)
 ACT_NONE, ACT_GELU = 0, 1
 
 _ERR = {-1: "BD_ERR_SHAPE", -2: "BD_ERR_DTYPE", -3: "BD_ERR_ALIGN", -4: "BD_ERR_WORKSPACE", -5: "BD_ERR_NULL"}
@@ -51,7 +53,7 @@ class Linear(C.Structure):
 class BlockWeights(C.Structure):
     _fields_ = [("ln1_w", C.c_void_p), ("ln1_b", C.c_void_p), ("ln2_w", C.c_void_p), ("ln2_b", C.c_void_p),
                 ("qkv", Linear), ("proj", Linear), ("fc1", Linear), ("fc2", Linear),
-                ("q_norm_w", C.c_void_p), ("k_norm_w", C.c_void_p)]
+                ("q_norm_w", C.c_void_p), ("k_norm_w", C.c_void_p), ("qkv16", Linear)]
 
 
 class DinoWeights(C.Structure):

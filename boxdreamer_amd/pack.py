@@ -156,6 +156,8 @@ def _pack_block(pk: Packed, sd: dict, p: str, prec, device, ls: bool, qk_norm: b
     if qk_norm:
         bw.q_norm_w = pk.keep(sd[p + "attn.q_norm.weight"].float(), device)
         bw.k_norm_w = pk.keep(sd[p + "attn.k_norm.weight"].float(), device)
+        if _lib.prec_id(prec) == _lib.PREC_BF16X3:      # f16 single-plane copy for BD_PREC_BF16X3_QKV16 (2 x 3.5 MB per block)
+            bw.qkv16 = pk.linear(pack_linear_weight(sd[p + "attn.qkv.weight"], "fp16"), pack_bias(sd[p + "attn.qkv.bias"]), device)
     return bw
 
 

@@ -56,6 +56,11 @@ extern "C" {
  *   BD_PREC_BF16X3_ATTN_F16  f16 single-pass attention everywhere (measurement: misses the 1e-3 bar) */
 #define BD_PREC_BF16X3_ATTN_X3 6
 #define BD_PREC_BF16X3_ATTN_F16 7
+/*   BD_PREC_BF16X3_QKV16     as BD_PREC_BF16X3, and the QKV Linear of the blocks whose q, k are RMS-normalised (BETR) runs as
+ *                            ONE f16 pass on an f16 LayerNorm output (needs bd_block_weights.qkv16).  Per-Linear-type sensitivity
+ *                            (oracle/numerics_sim.py): a single f16 pass costs 5.2e-4 on the logits in this Linear and 1.3e-3 to
+ *                            2.6e-3 in every other one, so it is the only Linear that can leave the split scheme inside 1e-3. */
+#define BD_PREC_BF16X3_QKV16 11
 /* f16 + e4m3 corrections (round 2's strict mode; every entry point):  A.W ~= hi_A.hi_W (one f16 MFMA pass) + lo_A.q_W +
  * q_A.lo_W (one e4m3 pass over a doubled K on the block-scaled MFMA): 2 pass-equivalents instead of BF16X3's 3, logits
  * error 1.7e-4 at full depth, and 3 bytes per element through the GEMM's LDS-DMA instead of 4.  Operand [rows][K], K % 32 == 0:
@@ -220,6 +225,7 @@ typedef struct bd_block_weights {
     const float* ln1_w; const float* ln1_b; const float* ln2_w; const float* ln2_b;
     bd_linear qkv, proj, fc1, fc2;   /* DINO: LayerScale gamma pre-folded into proj / fc2 */
     const float* q_norm_w; const float* k_norm_w;   /* [head_dim]; NULL for DINOv2 */
+    bd_linear qkv16;                                /* f16 single-plane copy of qkv (BD_PREC_BF16X3_QKV16) or {NULL} */
 } bd_block_weights;
 
 typedef struct bd_dino_weights {
