@@ -43,7 +43,8 @@ class GemmArgs(C.Structure):
                 ("out_f32", C.c_int),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("act", C.c_int),
-                ("rpg_in", C.c_int), ("rpg_out", C.c_int), ("row_off", C.c_int), ("w_qexp", C.c_int)]
+                ("rpg_in", C.c_int), ("rpg_out", C.c_int), ("row_off", C.c_int), ("w_qexp", C.c_int),
+                ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float)]
 
 
 class Linear(C.Structure):
@@ -85,7 +86,7 @@ EXPORTS = [
     "bd_gather_query_tokens", "bd_unpatchify_sigmoid", "bd_decode_topk",
     "bd_encoder_workspace_bytes", "bd_encoder_forward", "bd_decoder_workspace_bytes", "bd_decoder_forward",
     "bd_trace_begin", "bd_trace_end", "bd_render_corner_heatmaps", "bd_attention_q", "bd_gather_query_rows_f32",
-    "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp",
+    "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm",
 ]
 
 _lib = None
@@ -108,6 +109,7 @@ def load() -> C.CDLL:
     lib.bd_abi_version.restype = i
     lib.bd_target_arch.restype = C.c_char_p
     lib.bd_gemm.argtypes = [C.POINTER(GemmArgs), i, vp]
+    lib.bd_gemm_fuses_qk_rmsnorm.argtypes = [C.POINTER(GemmArgs), i]
     lib.bd_layernorm.argtypes = [vp, i64, vp, vp, f, vp, i64, vp, i64, i, i, i, i, i, i, vp]
     lib.bd_qk_rmsnorm.argtypes = [vp, i64, vp, vp, f, i, i, i, i, vp]
     lib.bd_attention.argtypes = [vp, i64, vp, i64, i, i, i, i, f, i, vp]

@@ -75,18 +75,27 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
     const int aprec = c8 ? (hyb ? BD_PREC_F16_OUT_F16C8 : BD_PREC_BF16X3_OUT_F16C8)
                          : (hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec));
     const int qkv_out = hyb ? 2 : (f8 ? 3 : (c8 ? 4 : 0));          // f16 plane / bf16 plane / split-bf16 planes / operand class
+    bool rms_fused = false;
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D, p4D = (int64_t)M * 4 * D;
     if (wprec == BD_PREC_BF16X3_QKV16 && hyb && w.qkv16.w) {
         // the one Linear that may leave the split scheme: f16 LayerNorm output x f16 weights, one pass, f16 q, k, v out
         BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, 0, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16, stream));
         bd_gemm_args g = gemm_args(b.xn, D, 0, w.qkv16, D, 3 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);
+        g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
+        rms_fused = hd == 96 && bd_gemm_fuses_qk_rmsnorm(&g, BD_PREC_F16);
+        if (!rms_fused) g.rms_wq = g.rms_wk = nullptr;
         BD_TRY(bd_gemm(&g, BD_PREC_F16, stream));
     } else {
         BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
         bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, qkv_out, M, D, BD_ACT_NONE);
+        if (w.q_norm_w && hd == 96) {            // q/k RMSNorm in the QKV epilogue where the launch allows it
+            g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
+            rms_fused = bd_gemm_fuses_qk_rmsnorm(&g, prec);
+            if (!rms_fused) g.rms_wq = g.rms_wk = nullptr;
+        }
         BD_TRY(bd_gemm(&g, prec, stream));
     }
-    if (w.q_norm_w) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, aprec_in, stream));
+    if (w.q_norm_w && !rms_fused) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, aprec_in, stream));
     BD_TRY(bd_attention(b.qkv, p3D, b.ao, pD, batch, seq, heads, hd, 1.0f / sqrtf((float)hd), aprec, stream));
     {
         bd_gemm_args g = gemm_args(b.ao, D, pD, w.proj, D, D, b.x, D, 0, 1, M, D, BD_ACT_NONE);
@@ -122,19 +131,28 @@ int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, flo
     const int aprec = c8 ? (hyb ? BD_PREC_F16_OUT_F16C8 : BD_PREC_BF16X3_OUT_F16C8)
                          : (hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec));
     const int qkv_out = hyb ? 2 : (f8 ? 3 : (c8 ? 4 : 0));          // f16 plane / bf16 plane / split-bf16 planes / operand class
+    bool rms_fused = false;
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D;
     const int64_t qD = (int64_t)Mq * D, q4D = (int64_t)Mq * 4 * D;
     if (wprec == BD_PREC_BF16X3_QKV16 && hyb && w.qkv16.w) {
         // the one Linear that may leave the split scheme: f16 LayerNorm output x f16 weights, one pass, f16 q, k, v out
         BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, 0, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16, stream));
         bd_gemm_args g = gemm_args(b.xn, D, 0, w.qkv16, D, 3 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);
+        g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
+        rms_fused = hd == 96 && bd_gemm_fuses_qk_rmsnorm(&g, BD_PREC_F16);
+        if (!rms_fused) g.rms_wq = g.rms_wk = nullptr;
         BD_TRY(bd_gemm(&g, BD_PREC_F16, stream));
     } else {
         BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
         bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, qkv_out, M, D, BD_ACT_NONE);
+        if (w.q_norm_w && hd == 96) {            // q/k RMSNorm in the QKV epilogue where the launch allows it
+            g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
+            rms_fused = bd_gemm_fuses_qk_rmsnorm(&g, prec);
+            if (!rms_fused) g.rms_wq = g.rms_wk = nullptr;
+        }
         BD_TRY(bd_gemm(&g, prec, stream));
     }
-    if (w.q_norm_w) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, aprec_in, stream));
+    if (w.q_norm_w && !rms_fused) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, aprec_in, stream));
     BD_TRY(bd_attention_q(b.qkv, p3D, b.ao, qD, B, T * P, heads, hd, 1.0f / sqrtf((float)hd), query_idx, P, aprec, stream));
     BD_TRY(bd_gather_query_rows_f32(b.x, query_idx, xc, B, T, P, D, stream));
     {

@@ -308,6 +308,65 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
             for (int cb = 0; cb < NCB; ++cb) load_bias_scale(cb, cb);
         }
         const int out_mode = p.out_f32;
+        if constexpr (LEAN && NI == 3 && PASSES == 1) {
+            if (p.rms_wq) {
+                // Fused q/k RMSNorm: the 96-column wave tile IS one head (host-checked).  A lane owns 3 x 8 columns of one row per
+                // 16-row pass and the 4 lanes of a row combine their sums of squares with two DPP shuffles: fp32 mean / rsqrt on
+                // the accumulators themselves, then the learned weight, then the 16-bit store.  Which third of the output this
+                // wave tile lies in (q: normalise with wq, k: with wk, v: untouched) is wave-uniform.
+                const int part = wn0 / (N / 3);
+                const float* rw = part == 0 ? p.rms_wq : (part == 1 ? p.rms_wk : nullptr);
+                float wv[3][8];
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) wv[cb][e] = rw ? rw[cb * 32 + c8 * 8 + e] : 1.f;
+                const float eps = p.rms_eps;
+#pragma unroll
+                for (int ih = 0; ih < MI * (32 / SR); ++ih) {
+                    const int i = ih / (32 / SR), hc = ih % (32 / SR);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int r = hc * (SR / 2); r < (hc + 1) * (SR / 2); ++r)
+                            sc[((r & 3) + 8 * ((r >> 2) - hc * (SR / 8)) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
+                    const int gr = wm0 + i * 32 + hc * SR + rsub;
+                    float v[3][8];
+                    float ss = 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb) {
+                        const float* src = sc + rsub * COLS + cb * CW + c8 * 8;
+                        const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[cb][e] = a0[e]; v[cb][4 + e] = a1[e]; }
+                        if (wscale) {
+                            const int gcs = wn0 + cb * CW + c8 * 8;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[cb][e] *= wscale[gcs + e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ss = fmaf(v[cb][e], v[cb][e], ss);
+                    }
+                    ss += __shfl_xor(ss, 1);
+                    ss += __shfl_xor(ss, 2);
+                    const float inv = rw ? rsqrtf(ss * (1.0f / 96.0f) + eps) : 1.f;
+                    if (gr < M && !BD_EXP_NOSTORE) {
+#pragma unroll
+                        for (int cb = 0; cb < 3; ++cb) {
+                            const int gc = wn0 + cb * CW + c8 * 8;
+                            float o8[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o8[e] = wv[cb][e] * (v[cb][e] * inv);     // w * (x * rsqrt(..)): blocks.py:51-56
+                            if (out_mode == OUT_F16) store_cvt<_Float16, 8>((_Float16*)p.out + (int64_t)gr * ldo + gc, o8);
+                            else if (out_mode == OUT_BF16) store_cvt<__bf16, 8>((__bf16*)p.out + (int64_t)gr * ldo + gc, o8);
+                            else if (out_mode == OUT_BF16X2) store_operand8<__bf16, 2>((__bf16*)p.out, out_plane, (int64_t)gr * ldo + gc, o8);
+                            else store_operand8<T, NS>((T*)p.out, out_plane, (int64_t)gr * ldo + gc, o8);
+                        }
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int ih = 0; ih < MI * (32 / SR); ++ih) {
             const int i = ih / (32 / SR), hc = ih % (32 / SR);
@@ -1222,9 +1281,28 @@ template <class T> bd_gemm_args row_slice(const bd_gemm_args& a, int64_t row0, i
     return sub;
 }
 
+// does this problem go to the persistent 256 x 192 kernel (every wave tile = 96 consecutive output columns)?
+inline bool pc192_possible(const bd_gemm_args& a, int ns, int esz) {
+    return BD_GEMM_POLICY == 1 && wide_epilogue_ok(a, ns) && 256 * a.lda * esz < ((int64_t)1 << 31) && 256 * a.ldw * esz < ((int64_t)1 << 31);
+}
+inline bool uses_pc192(const bd_gemm_args& a, int ns, int esz, int cus) {
+    if (!pc192_possible(a, ns, esz)) return false;
+    if (a.rms_wq) return true;       // a fused q/k RMSNorm pins the tile shape for EVERY batch size: a sample's q, k must not
+                                     // depend on whether its batch filled the CUs (bit-exact batch independence is tested)
+    if (a.N % 192 || a.M < 1024) return false;
+    const int64_t t192 = (int64_t)((a.M + 255) / 256) * (a.N / 192);
+    return (double)t192 / (double)(((t192 + cus - 1) / cus) * cus) >= 0.88;       // last-round occupancy of the CUs
+}
+// a fused q/k RMSNorm needs: 16-bit output of a plain Linear, N = 3 x heads x 96, row-identity output map
+inline bool rms_geometry_ok(const bd_gemm_args& a) {
+    return a.rms_wq && a.rms_wk && a.out_f32 != OUT_F32 && a.act == BD_ACT_NONE && !a.resid && !a.addtab && a.rpg_in <= 0 &&
+           a.N % 3 == 0 && (a.N / 3) % 96 == 0 && (((uintptr_t)a.rms_wq | (uintptr_t)a.rms_wk) & 3) == 0;
+}
+
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {
-    const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     const int kCUs = cu_count();
+    if (a.rms_wq && !(rms_geometry_ok(a) && pc192_possible(a, NS, OpGeom<T>::ESZ))) return BD_ERR_SHAPE;
+    const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     // the producer wave of gemm_kernel_pc addresses a tile's operand rows with 32-bit byte offsets from the tile origin
     constexpr int ESZ_ = OpGeom<T>::ESZ;
     const bool pc_ok = BD_GEMM_POLICY != 0 && wide_epilogue_ok(a, NS) && 256 * a.lda * ESZ_ < ((int64_t)1 << 31) &&
@@ -1233,9 +1311,7 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
         // 256 x 192 tiles (8 consumer waves of 64 x 96: 96 accumulator + 2 x 20 fragment registers fit the 168-VGPR budget
         // of three waves per SIMD with the fragment double-buffering intact) whenever they tile N exactly -- every Linear of
         // both stacks except the head (N = 2304, 3072, 768 are multiples of 192).
-        const int64_t t192 = (int64_t)((a.M + 255) / 256) * (a.N / 192);
-        const double fill = (double)t192 / (double)(((t192 + kCUs - 1) / kCUs) * kCUs);     // last-round occupancy of the CUs
-        if (BD_GEMM_POLICY == 1 && pc_ok && a.N % 192 == 0 && a.M >= 1024 && fill >= 0.88) {
+        if (uses_pc192(a, NS, ESZ_, kCUs)) {
             launch_pc<T, NS, BK, 4, 2, 2, 3>(a, s, kCUs);
             bd_trace_close(s, slot);
             BD_CHECK_LAUNCH();
@@ -1325,6 +1401,7 @@ int launch_f16c8(const bd_gemm_args& a, hipStream_t s) {
     if ((a.K % 32) || (a.lda % 32) || (a.ldw % 32)) return BD_ERR_SHAPE;            // the lo8 planes are laid out in 32-element blocks
     if (a.out_f32 == OUT_OPERAND && (a.ldo % 32)) return BD_ERR_SHAPE;
     if (a.w_qexp + BD_F16C8_D < -100 || a.w_qexp + BD_F16C8_D > 120) return BD_ERR_SHAPE;
+    if (a.rms_wq && !rms_geometry_ok(a)) return BD_ERR_SHAPE;
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     const int cus = cu_count();
     const int tiles = ((a.M + 255) / 256) * ((a.N + 191) / 192);
@@ -1337,6 +1414,20 @@ int launch_f16c8(const bd_gemm_args& a, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int bd_gemm_fuses_qk_rmsnorm(const bd_gemm_args* args, int prec) {
+    if (!args || !rms_geometry_ok(*args)) return 0;
+#ifdef BD_EXP_NO_RMS_FUSE      // A/B build only (tools/_probe): the separate bd_qk_rmsnorm kernel runs instead
+    return 0;
+#endif
+    switch (prec) {
+        case BD_PREC_BF16: case BD_PREC_F16: return pc192_possible(*args, 1, 2) ? 1 : 0;
+        case BD_PREC_BF16X3: return pc192_possible(*args, 2, 2) ? 1 : 0;
+        case BD_PREC_FP8: return pc192_possible(*args, 1, 1) ? 1 : 0;
+        case BD_PREC_F16C8: return wide_epilogue_ok(*args, 2) ? 1 : 0;
+        default: return 0;
+    }
+}
 
 extern "C" int bd_gemm(const bd_gemm_args* args, int prec, void* stream) {
     if (!args || !args->A || !args->W || !args->out) return BD_ERR_NULL;

@@ -108,7 +108,7 @@ _OUT_DTYPES = {2: torch.float16, 3: torch.bfloat16}      # 4: split-bf16 planes 
 
 
 def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, addtab=None, out=None,
-         out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0), wscale=None, out_mode=None, w_qexp=0):
+         out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0), wscale=None, out_mode=None, w_qexp=0, rms=None):
     """out[map(r)] = act(wscale * (A W^T) + bias) + addtab[r % rows(addtab)] + resid[map(r)].
     out_mode: None -> operand dtype (or fp32 with out_f32), 2 -> f16 single plane, 3 -> bf16 single plane."""
     lib = _lib.load()
@@ -139,6 +139,8 @@ def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, add
     g.out, g.ldo, g.out_f32 = ptr(out), o2.stride(0), mode
     g.out_plane = out[0].numel() if mode == 4 else (0 if mode else _plane(out, prec))
     g.w_qexp = int(w_qexp)
+    if rms is not None:                      # (wq, wk, eps): fused q/k RMSNorm of a QKV Linear
+        g.rms_wq, g.rms_wk, g.rms_eps = ptr(rms[0]), ptr(rms[1]), float(rms[2])
     g.M, g.N, g.K, g.act = M, N, K, act
     g.rpg_in, g.rpg_out, g.row_off = rpg
     check(lib.bd_gemm(C.byref(g), prec_id(prec), stream()), "bd_gemm")

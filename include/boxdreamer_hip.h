@@ -112,8 +112,15 @@ typedef struct bd_gemm_args {
     int act;
     int rpg_in, rpg_out, row_off;
     int w_qexp;                                    /* BD_PREC_F16C8: exponent E of the weight's e4m3 planes */
+    /* Fused q/k RMSNorm (LlamaRMSNorm on q and k after the head split, blocks.py:44-56,257) for a QKV Linear whose output
+     * columns are [q | k | v] x heads x head_dim with head_dim == 96: q, k <- w * x * rsqrt(mean_96(x^2) + eps) on the fp32
+     * accumulators, before the 16-bit store (no extra rounding, no separate pass over qkv).  Only where the launch uses 256 x 192
+     * tiles (each wave tile is one head); bd_gemm returns BD_ERR_SHAPE otherwise -- ask bd_gemm_fuses_qk_rmsnorm first. */
+    const float* rms_wq; const float* rms_wk; float rms_eps;
 } bd_gemm_args;
 int bd_gemm(const bd_gemm_args* args /*[host]*/, int prec, void* stream);
+/* 1 if bd_gemm(args, prec) with args->rms_wq set would fuse the q/k RMSNorm (tile shape and head geometry fit), else 0. */
+int bd_gemm_fuses_qk_rmsnorm(const bd_gemm_args* args /*[host]*/, int prec);
 
 /* LayerNorm over the last dim (fp32 statistics), optional affine, fp32 input rows gathered by
  * in_row(r) = r if rpg_in == 0 else (r / rpg_in) * rpg_out + r % rpg_in + row_off.

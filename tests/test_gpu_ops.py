@@ -180,6 +180,44 @@ def test_qk_rmsnorm(hip, prec, hd, heads):
     assert torch.equal(got[:, 2], src[:, 2])           # v untouched
 
 
+@pytest.mark.parametrize("prec,out_mode", [("bf16", None), ("fp16", None), ("bf16x3", None), ("bf16x3", 2), ("f16c8", 2), ("f16c8", 4)])
+@pytest.mark.parametrize("M", [300, 4096, 49152 // 8])
+def test_gemm_fused_qk_rmsnorm(hip, prec, out_mode, M):
+    """QKV Linear with the q/k RMSNorm (LlamaRMSNorm, blocks.py:44-56, applied after the head split, :257) fused into the
+    epilogue: q and k heads come out as  w * x * rsqrt(mean_96(x^2) + eps)  of the fp32 Linear result, v untouched.  Checked
+    against fp64 on the operands as stored; every output form the whole-path modes use; M below one tile and ragged."""
+    from boxdreamer_amd import _lib
+    heads, hd, K = 8, 96, 768
+    N = 3 * heads * hd
+    a, w, b = _rand("a", (M, K)), _rand("w", (N, K), 0.05), _rand("b", (N,), 0.1)
+    wq, wk = (_rand("wq", (hd,), 0.1) + 1).cuda(), (_rand("wk", (hd,), 0.1) + 1).cuda()
+    if prec == "f16c8":
+        e = hip_ops.f16c8_qexp(w)
+        a16, w16 = hip_ops.f16c8_encode(a.cuda(), 0, False), hip_ops.f16c8_encode(w.cuda(), e, True)
+        ah, al, aq = (t.cpu().double() for t in hip_ops.f16c8_decode(a16))
+        wh, wl, wqq = (t.cpu().double() for t in hip_ops.f16c8_decode(w16, e, True))
+        lin = ah @ wh.t() + al @ wqq.t() + aq @ wl.t() + b.double()
+    else:
+        e = 0
+        a16, w16 = hip_ops.to_operand(a.cuda(), prec), hip_ops.to_operand(w.cuda(), prec)
+        lin = _q(a, prec).double() @ _q(w, prec).double().t() + b.double()
+    g = _lib.GemmArgs()
+    out = hip_ops.gemm(a16, w16, b.cuda(), prec=prec, out_mode=out_mode, w_qexp=e, rms=(wq, wk, 1e-6))
+    x = lin.reshape(M, 3, heads, hd)
+    ref = x.clone()
+    ref[:, 0] = wq.cpu().double() * (x[:, 0] * torch.rsqrt(x[:, 0].pow(2).mean(-1, keepdim=True) + 1e-6))
+    ref[:, 1] = wk.cpu().double() * (x[:, 1] * torch.rsqrt(x[:, 1].pow(2).mean(-1, keepdim=True) + 1e-6))
+    ref = ref.reshape(M, N).float()
+    if out_mode == 2:
+        got, eps = out.float().cpu(), 2.0 ** -11
+    elif out_mode == 4:
+        got, eps = (out[0].float() + out[1].float()).cpu(), 2.0 ** -15
+    else:
+        got, eps = hip_ops.from_operand(out, prec).cpu(), EPS[prec]
+    err = (got - ref).abs().max().item()
+    assert err < 2 * eps * max(1.0, ref.abs().max().item()) + 1e-4, (prec, out_mode, err)
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("batch,seq,heads,hd", [(2, 261, 12, 64), (2, 512, 8, 96), (1, 1536, 8, 96), (3, 70, 2, 64)])
 def test_attention(hip, prec, batch, seq, heads, hd):
