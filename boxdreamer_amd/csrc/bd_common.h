@@ -63,7 +63,15 @@ template <class T, int N> __device__ __forceinline__ void store_cvt(T* dst, cons
     typedef __attribute__((__vector_size__(N * sizeof(T)))) T vecN;
     vecN o;
 #pragma unroll
-    for (int j = 0; j < N; ++j) o[j] = (T)v[j];
+    for (int j = 0; j < N; ++j) {
+        // The fp32 value is rounded to T as a SEPARATE step, everywhere: left alone, hipcc fuses a trailing multiply with the
+        // conversion (v_fma_mixlo_f16: one rounding instead of two) in some inlining contexts and not in others, and the same
+        // row then differs in near-tie cases between two kernels that compute the same fp32 result (found by the tile-shape
+        // invariance property: 63 of 3.5M f16 GELU outputs).  The empty asm makes the value opaque; it emits nothing.
+        float x = v[j];
+        asm("" : "+v"(x));
+        o[j] = (T)x;
+    }
     // BD_STORE_NT (set by gemm.hip only): non-temporal stores for the GEMM's 16/8-bit outputs.  qkv and the MLP hidden
     // are 226-302 MB per launch, written once and read by a LATER kernel; kept out of the 4 MB L2s' write-back path they
     // no longer evict the operand tiles of the running GEMM: whole step +3.2 %.  The LayerNorm / layout / attention
@@ -130,7 +138,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 //   1 + erf(z) = erfc(-z);  erfc(|z|) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p |z|)
 // (Abramowitz & Stegun 7.1.26, |abs err| <= 1.5e-7 -- fp32-rounding class).  ~12 VALU ops + v_exp + v_rcp per
 // element instead of ocml erff's branchy ~40: the fc1 epilogue was costing 40 % of that GEMM.
+// (All GELU forms: every fused multiply-add is written out and contraction is off inside, so that the arithmetic does not
+// depend on the inlining context -- two kernels computing the same row must agree bit for bit.)
 __device__ __forceinline__ float gelu_erf(float x) {
+#pragma clang fp contract(off)
     const float z = fabsf(x) * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
     float poly = fmaf(t, 1.061405429f, -1.453152027f);
@@ -148,6 +159,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // hide under the next tile's MFMAs.  Only the single-pass modes use it; the strict split-bf16 mode and every fp32
 // output keep gelu_erf.  The argument is clamped to +-8 where the fitted polynomial is still monotone (Phi saturates).
 __device__ __forceinline__ float gelu_fast(float x) {
+#pragma clang fp contract(off)
     const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
     const float x2 = xc * xc;
     const float pz = fmaf(x2, fmaf(x2, -1.10189899e-03f, 1.07380689e-01f), 2.30034092f);
@@ -160,18 +172,20 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // is 8x finer), fp32 / split-bf16 results keep gelu_erf.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
+#pragma clang fp contract(off)
     f32x2 xc;
     xc.x = __builtin_amdgcn_fmed3f(x.x, -4.0f, 4.0f);
     xc.y = __builtin_amdgcn_fmed3f(x.y, -4.0f, 4.0f);
     const f32x2 x2 = xc * xc;
-    f32x2 pz = x2 * -1.411566826e-09f + 1.110951978e-07f;
-    pz = pz * x2 + -3.829025890e-06f;
-    pz = pz * x2 + 7.702150218e-05f;
-    pz = pz * x2 + -1.020914998e-03f;
-    pz = pz * x2 + 9.552915274e-03f;
-    pz = pz * x2 + -6.594778014e-02f;
-    pz = pz * x2 + 3.986759341e-01f;
-    return x * (xc * pz + 0.5f);
+    auto c2 = [](float c) { return (f32x2){c, c}; };
+    f32x2 pz = __builtin_elementwise_fma(x2, c2(-1.411566826e-09f), c2(1.110951978e-07f));
+    pz = __builtin_elementwise_fma(pz, x2, c2(-3.829025890e-06f));
+    pz = __builtin_elementwise_fma(pz, x2, c2(7.702150218e-05f));
+    pz = __builtin_elementwise_fma(pz, x2, c2(-1.020914998e-03f));
+    pz = __builtin_elementwise_fma(pz, x2, c2(9.552915274e-03f));
+    pz = __builtin_elementwise_fma(pz, x2, c2(-6.594778014e-02f));
+    pz = __builtin_elementwise_fma(pz, x2, c2(3.986759341e-01f));
+    return x * __builtin_elementwise_fma(xc, pz, c2(0.5f));
 }
 // GELU of N (even) values headed for a 16/8-bit store: KIND 0 exact erf, 1 exp-based fit, 2 packed polynomial
 template <int KIND, int N> __device__ __forceinline__ void gelu_n(float (&v)[N]) {

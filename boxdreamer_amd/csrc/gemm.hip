@@ -34,13 +34,6 @@
 #ifndef BD_GEMM_POLICY
 #define BD_GEMM_POLICY 1
 #endif
-// Epilogue of the persistent kernel: 0 = LDS-staged, full-line 16-byte stores (default); 1 = transposed accumulators with
-// row-per-lane 16-byte accesses straight from registers -- measured 2.1x SLOWER (27-29k vs 12.8k cycles per 256x192 tile: a
-// wave store touching 32 rows x 32 bytes is issue-bound in the texture path), kept for the record.
-#ifndef BD_PC_EPI
-#define BD_PC_EPI 0
-#endif
-
 
 #include "bd_common.h"
 
@@ -118,24 +111,44 @@ __device__ __forceinline__ unsigned lds_offset_of(const void* p) {
 // out_f32 codes
 enum { OUT_OPERAND = 0, OUT_F32 = 1, OUT_F16 = 2, OUT_BF16 = 3, OUT_BF16X2 = 4 };
 
-// Accumulators start at the bias of their column (C fragment: col = lane & 31 of tile j) instead of zero, so no epilogue
-// carries a bias add or keeps bias vectors live; with a per-channel weight scale (e4m3) the start value is bias / scale and
-// the epilogue's  scale * acc  restores it.  Every kernel uses the same convention (results stay bit-identical across tile
-// shapes: the property tests compare a sample run alone with the same sample inside a batch).
+// Accumulator start values and where the epilogue terms enter -- ONE convention for every kernel, so that a row's result
+// does not depend on the tile shape that computed it (the property tests compare a sample run alone with the same sample
+// inside a batch, bit for bit):
+//   * a plain fp32 residual (identity row map, no per-channel weight scale) is loaded INTO the accumulators before the first
+//     MFMA (C fragment layout: 2 rows x 128 contiguous bytes per load instruction), so no epilogue reads global memory for
+//     it -- on gfx9 loads and stores share the in-order vmcnt, and an epilogue that loads after it has stored waits for its
+//     own stores to be acknowledged (measured: 13.8k cycles per 256x192 tile for a LONE workgroup, profiles/r2_gemm_epilogue.md);
+//   * everything else starts at zero;
+//   * scale * acc + bias is applied when the accumulators leave the registers (per-column values, one register per 32-column
+//     tile), then the activation, the table rows and a remapped / scaled-mode residual.
+__device__ __forceinline__ bool resid_in_acc(const bd_gemm_args& p) { return p.resid && p.rpg_in <= 0 && !p.wscale; }
+
 template <int MI, int NI>
-__device__ __forceinline__ void acc_init_bias(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wn0, int lane) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int col = wn0 + j * 32 + (lane & 31);
-        float b = 0.f;
-        if (p.bias && col < p.N) {
-            b = p.bias[col];
-            if (p.wscale) b = b / p.wscale[col];
-        }
+__device__ __forceinline__ void acc_init(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wm0, int wn0, int lane) {
+    if (resid_in_acc(p)) {
+        // rows / columns past the edge are clamped: those accumulators are never stored
+        const int lrow = lane & 31, lhalf = lane >> 5;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+            for (int r = 0; r < 16; ++r) {
+                int gr = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                gr = gr < p.M ? gr : p.M - 1;
+                const float* rp = p.resid + (int64_t)gr * p.ldr;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int gc = wn0 + j * 32 + lrow;
+                    gc = gc < p.N ? gc : p.N - 1;
+                    acc[i][j][r] = rp[gc];
+                }
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
 }
 
@@ -145,8 +158,8 @@ template <class T, int NS, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wm0, int wn0, int lane) {
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int M = p.M, N = p.N;
-    const float* bias = nullptr;       // the bias is folded into the accumulator initialisation (acc_init_bias)
-    const float* resid = p.resid;
+    const float* bias = p.bias;
+    const float* resid = resid_in_acc(p) ? nullptr : p.resid;      // else already in the accumulators (acc_init)
     const float* addtab = p.addtab;
     const float* wscale = p.wscale;
     const int act = p.act, out_f32 = p.out_f32, rpg_in = p.rpg_in, rpg_out = p.rpg_out, row_off = p.row_off;
@@ -173,7 +186,7 @@ __device__ __forceinline__ void gemm_epilogue(const bd_gemm_args& p, f32x16 (&ac
                 for (int j = 0; j < NI; ++j) {
                     const int gc = gcs[j];
                     if (gc < N) {
-                        float v = acc[i][j][r] * sj[j] + bj[j];
+                        float v = fmaf(acc[i][j][r], sj[j], bj[j]);
                         if (act == BD_ACT_GELU) v = gelu_erf(v);
                         if (tab) v += tab[gc];
                         if (resid) v += resid[orow * ldr + gc];
@@ -210,13 +223,26 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
     constexpr int COLS = NI * 32;                      // wave-tile width (fp32 words per scratch row)
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int M = p.M, N = p.N;
-    const float* bias = nullptr;       // the bias is folded into the accumulator initialisation (acc_init_bias)
-    const float* resid = p.resid;
+    const float* resid = resid_in_acc(p) ? nullptr : p.resid;      // else already in the accumulators (acc_init)
     const float* addtab = p.addtab;
-    const float* wscale = p.wscale;
     const int act = p.act, rpg_in = p.rpg_in, rpg_out = p.rpg_out, row_off = p.row_off, tab_rows = p.tab_rows;
     const int64_t ldr = p.ldr, ldo = p.ldo, out_plane = p.out_plane;
     float* sc = (float*)scratch;
+    // scale * acc + bias on the way INTO the scratch: one column per lane and 32-column tile
+    float bj[NI], sj[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int gc = wn0 + j * 32 + lrow;
+        bj[j] = (p.bias && gc < N) ? p.bias[gc] : 0.f;
+        sj[j] = (p.wscale && gc < N) ? p.wscale[gc] : 1.f;
+    }
+    auto to_scratch = [&](int i, int hc) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = hc * (SR / 2); r < (hc + 1) * (SR / 2); ++r)
+                sc[((r & 3) + 8 * ((r >> 2) - hc * (SR / 8)) + 4 * lhalf) * COLS + j * 32 + lrow] = fmaf(acc[i][j][r], sj[j], bj[j]);
+    };
     // the wave tile is flushed in column blocks of CW columns (all of it when it is 32 or 64 wide; 3 x 32 for the 96-wide
     // wave tile of the 256 x 192 workgroup tile) so that the lanes of a pass always cover whole rows of a block
     constexpr int CW = (NI % 2 == 0) ? 64 : 32, NCB = COLS / CW;
@@ -225,31 +251,18 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
         constexpr int RPI = 64 / LPR;                  // rows per pass
         constexpr int PASSES = SR / RPI;
         const int c4 = lane % LPR, rsub = lane / LPR;
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
-        f32x4 bv4[NCB], sv4[NCB];
-        bool cok[NCB];
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-            const int gc = wn0 + cb * CW + c4 * 4;
-            cok[cb] = gc < N;
-            bv4[cb] = zero4; sv4[cb] = one4;
-            if (bias && cok[cb]) bv4[cb] = *(const f32x4*)(bias + gc);
-            if (wscale && cok[cb]) sv4[cb] = *(const f32x4*)(wscale + gc);
-        }
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ih = 0; ih < MI * (32 / SR); ++ih) {
             const int i = ih / (32 / SR), hc = ih % (32 / SR);
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int r = hc * (SR / 2); r < (hc + 1) * (SR / 2); ++r)
-                    sc[((r & 3) + 8 * ((r >> 2) - hc * (SR / 8)) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
+            to_scratch(i, hc);
             // global reads are issued in batches of PB passes (register budget); native vector types only -- HIP's
             // float4 struct in a local array lands in scratch
             constexpr int PB = LEAN ? (PASSES > 2 ? 2 : PASSES) : (PASSES > 4 ? 4 : PASSES);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const int gc = wn0 + cb * CW + c4 * 4;
+                const bool cok = gc < N;
 #pragma unroll
                 for (int t0 = 0; t0 < PASSES; t0 += PB) {
                     f32x4 rv[PB], tv[PB];
@@ -258,7 +271,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
 #pragma unroll
                     for (int u = 0; u < PB; ++u) {
                         const int gr = wm0 + i * 32 + hc * SR + (t0 + u) * RPI + rsub;
-                        ok[u] = cok[cb] && gr < M;
+                        ok[u] = cok && gr < M;
                         const int grc = gr < M ? gr : M - 1;
                         orow[u] = rpg_in > 0 ? (int64_t)(grc / rpg_in) * rpg_out + grc % rpg_in + row_off : (int64_t)grc;
                         rv[u] = zero4;
@@ -268,7 +281,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
                     }
 #pragma unroll
                     for (int u = 0; u < PB; ++u) {
-                        f32x4 v = *(const f32x4*)(sc + ((t0 + u) * RPI + rsub) * COLS + cb * CW + c4 * 4) * sv4[cb] + bv4[cb];
+                        f32x4 v = *(const f32x4*)(sc + ((t0 + u) * RPI + rsub) * COLS + cb * CW + c4 * 4);
                         if (act == BD_ACT_GELU) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -284,35 +297,24 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
         constexpr int RPI = 64 / LPR;
         constexpr int PASSES = SR / RPI;
         const int c8 = lane % LPR, rsub = lane / LPR;
-        constexpr int NBV = LEAN ? 1 : NCB;            // LEAN: one live bias / scale vector, re-loaded per column block
-        float bv[NBV][8], sv[NBV][8];
-        bool cok[NCB];
-        auto load_bias_scale = [&](int cb, int slot) {
-            const int gc = wn0 + cb * CW + c8 * 8;
-            cok[cb] = gc < N;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { bv[slot][e] = 0.f; sv[slot][e] = 1.f; }
-            if (bias && cok[cb]) {
-                const f32x4 b0 = *(const f32x4*)(bias + gc), b1 = *(const f32x4*)(bias + gc + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { bv[slot][e] = b0[e]; bv[slot][4 + e] = b1[e]; }
-            }
-            if (wscale && cok[cb]) {
-                const f32x4 s0 = *(const f32x4*)(wscale + gc), s1 = *(const f32x4*)(wscale + gc + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { sv[slot][e] = s0[e]; sv[slot][4 + e] = s1[e]; }
+        const int out_mode = p.out_f32;
+        auto store8 = [&](int64_t orow, int gc, const float (&v)[8]) {
+            if (BD_EXP_NOSTORE) return;
+            if (out_mode == OUT_F16) {            // f16 single plane (optional f16 attention of the strict mode)
+                store_cvt<_Float16, 8>((_Float16*)p.out + orow * ldo + gc, v);
+            } else if (out_mode == OUT_BF16) {    // bf16 single plane (fp8 mode: attention operands stay bf16)
+                store_cvt<__bf16, 8>((__bf16*)p.out + orow * ldo + gc, v);
+            } else if (out_mode == OUT_BF16X2) {  // split-bf16 planes (F16C8 mode: DINOv2's split-bf16 attention)
+                store_operand8<__bf16, 2>((__bf16*)p.out, out_plane, orow * ldo + gc, v);
+            } else {
+                store_operand8<T, NS>((T*)p.out, out_plane, orow * ldo + gc, v);
             }
         };
-        if constexpr (!LEAN) {
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) load_bias_scale(cb, cb);
-        }
-        const int out_mode = p.out_f32;
         if constexpr (LEAN && NI == 3 && PASSES == 1) {
             if (p.rms_wq) {
                 // Fused q/k RMSNorm: the 96-column wave tile IS one head (host-checked).  A lane owns 3 x 8 columns of one row per
-                // 16-row pass and the 4 lanes of a row combine their sums of squares with two DPP shuffles: fp32 mean / rsqrt on
-                // the accumulators themselves, then the learned weight, then the 16-bit store.  Which third of the output this
+                // 16-row pass and the 4 lanes of a row (one quad) combine their sums of squares: fp32 mean / rsqrt on the
+                // accumulators themselves, then the learned weight, then the 16-bit store.  Which third of the output this
                 // wave tile lies in (q: normalise with wq, k: with wk, v: untouched) is wave-uniform.
                 const int part = wn0 / (N / 3);
                 const float* rw = part == 0 ? p.rms_wq : (part == 1 ? p.rms_wk : nullptr);
@@ -325,11 +327,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
 #pragma unroll
                 for (int ih = 0; ih < MI * (32 / SR); ++ih) {
                     const int i = ih / (32 / SR), hc = ih % (32 / SR);
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-#pragma unroll
-                        for (int r = hc * (SR / 2); r < (hc + 1) * (SR / 2); ++r)
-                            sc[((r & 3) + 8 * ((r >> 2) - hc * (SR / 8)) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
+                    to_scratch(i, hc);
                     const int gr = wm0 + i * 32 + hc * SR + rsub;
                     float v[3][8];
                     float ss = 0.f;
@@ -339,28 +337,19 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
                         const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[cb][e] = a0[e]; v[cb][4 + e] = a1[e]; }
-                        if (wscale) {
-                            const int gcs = wn0 + cb * CW + c8 * 8;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[cb][e] *= wscale[gcs + e];
-                        }
 #pragma unroll
                         for (int e = 0; e < 8; ++e) ss = fmaf(v[cb][e], v[cb][e], ss);
                     }
                     ss += __shfl_xor(ss, 1);
                     ss += __shfl_xor(ss, 2);
                     const float inv = rw ? rsqrtf(ss * (1.0f / 96.0f) + eps) : 1.f;
-                    if (gr < M && !BD_EXP_NOSTORE) {
+                    if (gr < M) {
 #pragma unroll
                         for (int cb = 0; cb < 3; ++cb) {
-                            const int gc = wn0 + cb * CW + c8 * 8;
                             float o8[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o8[e] = wv[cb][e] * (v[cb][e] * inv);     // w * (x * rsqrt(..)): blocks.py:51-56
-                            if (out_mode == OUT_F16) store_cvt<_Float16, 8>((_Float16*)p.out + (int64_t)gr * ldo + gc, o8);
-                            else if (out_mode == OUT_BF16) store_cvt<__bf16, 8>((__bf16*)p.out + (int64_t)gr * ldo + gc, o8);
-                            else if (out_mode == OUT_BF16X2) store_operand8<__bf16, 2>((__bf16*)p.out, out_plane, (int64_t)gr * ldo + gc, o8);
-                            else store_operand8<T, NS>((T*)p.out, out_plane, (int64_t)gr * ldo + gc, o8);
+                            store8((int64_t)gr, wn0 + cb * CW + c8 * 8, o8);
                         }
                     }
                 }
@@ -370,18 +359,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
 #pragma unroll
         for (int ih = 0; ih < MI * (32 / SR); ++ih) {
             const int i = ih / (32 / SR), hc = ih % (32 / SR);
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int r = hc * (SR / 2); r < (hc + 1) * (SR / 2); ++r)
-                    sc[((r & 3) + 8 * ((r >> 2) - hc * (SR / 8)) + 4 * lhalf) * COLS + j * 32 + lrow] = acc[i][j][r];
+            to_scratch(i, hc);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const int gc = wn0 + cb * CW + c8 * 8;
-                constexpr int dummy_ = 0;
-                const int bs = LEAN ? 0 : cb;
-                if constexpr (LEAN) load_bias_scale(cb, 0);
-                (void)dummy_;
 #pragma unroll
                 for (int t = 0; t < PASSES; ++t) {
                     const int gr = wm0 + i * 32 + hc * SR + t * RPI + rsub;
@@ -389,9 +370,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
                     const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = a0[e] * sv[bs][e] + bv[bs][e]; v[4 + e] = a1[e] * sv[bs][4 + e] + bv[bs][4 + e]; }
+                    for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[4 + e] = a1[e]; }
                     if (act == BD_ACT_GELU) gelu_n<GeluKind<T, NS>::value, 8>(v);   // 16/8-bit result: fitted forms (bd_common.h)
-                    if (cok[cb] && gr < M && !BD_EXP_NOSTORE) {
+                    if (gc < N && gr < M) {
                         const int64_t orow = rpg_in > 0 ? (int64_t)(gr / rpg_in) * rpg_out + gr % rpg_in + row_off : (int64_t)gr;
                         if (addtab) {
                             const float* tp = addtab + (int64_t)(gr % tab_rows) * N + gc;
@@ -403,15 +384,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] += rp[e];
                         }
-                        if (out_mode == OUT_F16) {            // f16 single plane (optional f16 attention of the strict mode)
-                            store_cvt<_Float16, 8>((_Float16*)p.out + orow * ldo + gc, v);
-                        } else if (out_mode == OUT_BF16) {    // bf16 single plane (fp8 mode: attention operands stay bf16)
-                            store_cvt<__bf16, 8>((__bf16*)p.out + orow * ldo + gc, v);
-                        } else if (out_mode == OUT_BF16X2) {  // split-bf16 planes (F16C8 mode: DINOv2's split-bf16 attention)
-                            store_operand8<__bf16, 2>((__bf16*)p.out, out_plane, orow * ldo + gc, v);
-                        } else {
-                            store_operand8<T, NS>((T*)p.out, out_plane, orow * ldo + gc, v);
-                        }
+                        store8(orow, gc, v);
                     }
                 }
             }
@@ -470,7 +443,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gem
     }
 
     f32x16 acc[MI][NI];
-    acc_init_bias<MI, NI>(p, acc, n0 + wn * (NI * 32), lane);
+    acc_init<MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
 
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int nk = p.K / BK;
@@ -551,153 +524,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gem
 #endif
 }
 
-// ---- row-per-lane epilogue for TRANSPOSED accumulators (gemm_kernel_pc).  The persistent kernel issues its MFMAs with the
-// operand roles swapped (D^T = W . A^T): a lane then owns output row (lane & 31) of tile i and, per 32-column tile j, the
-// sixteen columns  8 q + 4 h + c  (q = r >> 2, c = r & 3, h = lane >> 5) -- four CONSECUTIVE columns per register quad.  Every
-// epilogue operand is therefore a 16-byte global access straight from / to registers: fp32 outputs (residual stream) load
-// the residual quad, add and store it; 16-bit outputs pack a quad to 8 bytes and one v_permlane32_swap per dword pairs the
-// two half-waves' quads into 16-byte stores (lower lanes: columns 16 k .. 16 k + 7 of the tile, upper lanes: the next eight).
-// No LDS round trip (the LDS-staged epilogue spends ~3000 cycles per tile in ds_write_b32 alone and needs a stage of the
-// operand ring as scratch), a fraction of the registers, and nothing to synchronise with the producers.
-template <int MI, int NI>
-__device__ __forceinline__ void acc_init_bias_t(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wn0, int lane) {
-    const int lhalf = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int col = wn0 + j * 32 + q * 8 + lhalf * 4;
-            f32x4 b = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && col < p.N) {
-                b = *(const f32x4*)(p.bias + col);
-                if (p.wscale) b = b / *(const f32x4*)(p.wscale + col);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[i][j][q * 4 + c] = b[c];
-        }
-}
-
-template <class T> __device__ __forceinline__ unsigned pack2_16(float x, float y) {
-    typedef __attribute__((__vector_size__(2 * sizeof(T)))) T vec2;
-    vec2 v; v[0] = (T)x; v[1] = (T)y;
-    return __builtin_bit_cast(unsigned, v);
-}
-
-// 16-bit image of one row of a 32-column tile: g[k] = this lane's quad k (columns 8 k + 4 h + c) in final fp32 form.  One
-// v_permlane32_swap per dword (lanes 32-63 of the first operand <-> lanes 0-31 of the second) leaves the lower lanes with
-// [own quad k | upper lanes' quad k] = columns 8 k .. 8 k + 7 and the upper lanes with [lower lanes' quad k+1 | own quad k+1] =
-// the next eight: one 16-byte store per lane and pair of quads.  rb = &out[row][first column of the tile]; n_left = N - that column.
-template <class T>
-__device__ __forceinline__ void store_row_pairs16(T* rb, const float (&g)[4][4], int lhalf, bool row_ok, int n_left) {
-#pragma unroll
-    for (int k = 0; k < 4; k += 2) {
-        const unsigned ax = pack2_16<T>(g[k][0], g[k][1]), ay = pack2_16<T>(g[k][2], g[k][3]);
-        const unsigned bx = pack2_16<T>(g[k + 1][0], g[k + 1][1]), by = pack2_16<T>(g[k + 1][2], g[k + 1][3]);
-        const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-        const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-        const u128 v = {rx[0], ry[0], rx[1], ry[1]};
-        const int col = k * 8 + lhalf * 8;
-        if (row_ok && col < n_left) __builtin_nontemporal_store(v, (u128*)(rb + col));   // written once, read by a later kernel
-    }
-}
-
-template <class T, int NS, int MI, int NI>
-__device__ __forceinline__ void gemm_epilogue_rowlane(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wm0, int wn0, int lane) {
-    const int lrow = lane & 31, lhalf = lane >> 5;
-    const int M = p.M, N = p.N;
-    const float* resid = p.resid;
-    const float* addtab = p.addtab;
-    const float* wscale = p.wscale;
-    const int act = p.act, out_mode = p.out_f32;
-    const int64_t ldr = p.ldr, ldo = p.ldo, out_plane = p.out_plane;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int gr = wm0 + i * 32 + lrow;
-        const bool rok = gr < M;
-        const int grc = rok ? gr : M - 1;
-        const int64_t orow = p.rpg_in > 0 ? (int64_t)(grc / p.rpg_in) * p.rpg_out + grc % p.rpg_in + p.row_off : (int64_t)grc;
-        const float* rrow = resid ? resid + orow * ldr : nullptr;
-        const float* trow = addtab ? addtab + (int64_t)(grc % p.tab_rows) * N : nullptr;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int c0 = wn0 + j * 32;                   // first column of this 32-wide tile
-            // the column-validity test is per quad and, because N % 8 == 0, the same for both quads of a 16-byte store pair
-            float g[4][4];
-            f32x4 rv[4], tv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int gc = c0 + q * 8 + lhalf * 4;
-                const bool ok = rok && gc < N;
-                rv[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                tv[q] = rv[q];
-                if (rrow && ok) rv[q] = *(const f32x4*)(rrow + gc);
-                if (trow && ok) tv[q] = *(const f32x4*)(trow + gc);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int gc = c0 + q * 8 + lhalf * 4;
-                float v[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = acc[i][j][q * 4 + c];
-                if (wscale) {
-                    const f32x4 sv = gc < N ? *(const f32x4*)(wscale + gc) : (f32x4){1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] *= sv[c];
-                }
-                if (act == BD_ACT_GELU) {
-                    if (out_mode == OUT_F32) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
-                    } else {
-                        gelu_n<GeluKind<T, NS>::value, 4>(v);
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) g[q][c] = v[c] + tv[q][c] + rv[q][c];
-            }
-            if (out_mode == OUT_F32) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int gc = c0 + q * 8 + lhalf * 4;
-                    if (rok && gc < N) *(f32x4*)((float*)p.out + orow * ldo + gc) = (f32x4){g[q][0], g[q][1], g[q][2], g[q][3]};
-                }
-            } else {
-                if (out_mode == OUT_F16) {
-                    store_row_pairs16<_Float16>((_Float16*)p.out + orow * ldo + c0, g, lhalf, rok, N - c0);
-                } else if (out_mode == OUT_BF16) {
-                    store_row_pairs16<__bf16>((__bf16*)p.out + orow * ldo + c0, g, lhalf, rok, N - c0);
-                } else if constexpr (sizeof(T) == 2) {
-                    T* rb = (T*)p.out + orow * ldo + c0;
-                    store_row_pairs16<T>(rb, g, lhalf, rok, N - c0);                 // plane 0: hi = T(g)
-                    if constexpr (NS == 2) {
-                        float lo[4][4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) lo[q][c] = g[q][c] - to_f32<T>(from_f32<T>(g[q][c]));
-                        store_row_pairs16<T>(rb + out_plane, lo, lhalf, rok, N - c0);
-                    }
-                } else {
-                    // e4m3 operand output: a quad is one dword; one swap pairs the half-waves' quads into 8-byte stores
-                    fp8e4* rb = (fp8e4*)p.out + orow * ldo + c0;
-#pragma unroll
-                    for (int k = 0; k < 4; k += 2) {
-                        int a0 = 0, b0 = 0;
-                        a0 = __builtin_amdgcn_cvt_pk_fp8_f32(g[k][0], g[k][1], a0, false);
-                        a0 = __builtin_amdgcn_cvt_pk_fp8_f32(g[k][2], g[k][3], a0, true);
-                        b0 = __builtin_amdgcn_cvt_pk_fp8_f32(g[k + 1][0], g[k + 1][1], b0, false);
-                        b0 = __builtin_amdgcn_cvt_pk_fp8_f32(g[k + 1][2], g[k + 1][3], b0, true);
-                        const auto rx = __builtin_amdgcn_permlane32_swap((unsigned)a0, (unsigned)b0, false, false);
-                        if (rok && c0 + k * 8 + lhalf * 8 < N) *(uint2*)(rb + k * 8 + lhalf * 8) = make_uint2(rx[0], rx[1]);
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Producer / consumer, persistent form of the same GEMM  (round 2).
 //
@@ -714,16 +540,168 @@ __device__ __forceinline__ void gemm_epilogue_rowlane(const bd_gemm_args& p, f32
 // tile lists), which buys two more overlaps: the first slab of the NEXT tile is fetched under the last slab of this one, and
 // the epilogue's global stores are not waited for by anyone -- they drain under the next tile's MFMAs (in the one-tile kernel
 // all CUs write their tiles at the same moment: QKV's 128 KiB per CU sit at the HBM write floor of ~10k cycles while the
-// matrix pipes idle).  The MFMAs run with swapped operand roles (D^T = W . A^T) so that a lane owns output ROWS: the epilogue
-// is 16-byte global accesses straight from registers (gemm_epilogue_rowlane), needs no LDS, and both stages of the ring refill
-// under it.  Barriers per tile: nk (B) + 1 (X: every consumer is done reading the last slab).
+// matrix pipes idle).  Barriers per tile: nk (B) + 1 (X: every consumer is done reading the last slab).
+//
+// Consumers execute NO vector-memory LOAD anywhere in the specialised epilogues (EP 1-3 below): on gfx9 loads and stores share
+// the in-order vmcnt, so a load issued after the epilogue's stores (a bias vector, a residual row, a register-spill reload)
+// can only be waited for together with those stores' acknowledgements.  The first version of this kernel had exactly that
+// (generic epilogue under the 168-VGPR cap: scratch reloads and per-column-block bias loads between the stores) and a LONE
+// workgroup spent 13.8k cycles per tile in its epilogue against 1.9k for the bare stores (profiles/r2_gemm_epilogue.md).  Now:
+//   * per-column vectors (bias, e4m3 weight scale) of a tile arrive in a small LDS side buffer with the tile's first slab
+//     (one extra 1-KiB DMA piece each, producer wave 0; double-buffered by tile parity); the q/k RMSNorm weights once per kernel;
+//   * a plain fp32 residual is loaded INTO the accumulators of the NEXT tile (acc_init convention) from inside this tile's
+//     epilogue, chunk by chunk as the accumulator registers are flushed to the LDS scratch -- before that chunk's stores;
+//   * the epilogue kind is a template parameter (EP), so no path carries the other paths' live values or branches.
+// EP: 0 = generic (gemm_epilogue_lds: table add, row remap, residual in scaled modes, odd output kinds),
+//     1 = 16-bit / 8-bit result (OUTK: operand-native, f16, bf16), optional GELU,
+//     2 = 16-bit result with the fused q/k RMSNorm,
+//     3 = fp32 result (+ fp32 residual through the accumulators).
 // What still bounds it (profiles/r2_gemm_phase_probe.md): per slab the producers need ~1000 cycles to issue + ~840 to land
-// the next slab (a 2-stage ring cannot hide that latency: 2045 cycles per slab for 1536 of matrix work per SIMD), and the
-// epilogue's global stores: dropping them takes QKV from 909 to 1211 TF/s and fc1 from 741 to 1074.  Non-temporal vs plain
-// stores: equal.  Start-up staggers that spread the CUs' epilogues over the tile period -- 4 phase groups inside every XCD, or
-// one phase per XCD -- were measured at +1 % / -9 % (QKV) and -7 % / -2 % (fc1): dropped.
+// the next slab (a 2-stage ring cannot hide that latency: 2045 cycles per slab for 1536 of matrix work per SIMD).
+// Negative results kept in the profile notes: a row-per-lane epilogue on transposed accumulators (no LDS, 2.1x slower: a wave
+// store touching 32 rows x 32 bytes is issue-bound in the texture path), non-temporal vs plain stores (equal), start-up
+// staggers that spread the CUs' epilogues over the tile period (+1 % / -9 % QKV, -7 % / -2 % fc1).
 
-template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NPW>
+// quad all-reduce (lanes 4k .. 4k+3) on the VALU: two DPP quad_perm adds
+__device__ __forceinline__ float quad_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // [2,3,0,1]
+    return x;
+}
+
+// Epilogue of gemm_kernel_pc for the 64 x 96 wave tile (MI = 2, NI = 3), 16 rows per pass through this wave's 6-KiB scratch.
+//   colp: this tile's per-column vectors in LDS (bias at [0, 256), weight scale at [256, 512)), indexed by tile column
+//   rmsw: q weights at [0, 96), k weights at [256, 352)
+//   wcol: first column of the wave tile inside the workgroup tile;  (wm0, wn0): its global origin
+//   next: the wave tile origin of this workgroup's next tile (EP 3 pre-loads its residual), has_next = there is one
+template <class T, int NS, int EP, int OUTK, bool GELU>
+__device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)[2][3], float* sc, const float* colp, const float* rmsw,
+                                            int wcol, int wm0, int wn0, int lane, bool has_next, int nwm0, int nwn0) {
+    constexpr int COLS = 96;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int M = p.M;
+    float bj[3], sj[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        bj[j] = p.bias ? colp[wcol + j * 32 + lrow] : 0.f;
+        sj[j] = 1.f;
+        if constexpr (sizeof(T) == 1) sj[j] = p.wscale ? colp[256 + wcol + j * 32 + lrow] : 1.f;
+    }
+    auto to_scratch = [&](int i, int hc) {          // rows 16 hc .. 16 hc + 15 of 32-row block i: registers r with (r >> 2) in {2 hc, 2 hc + 1}
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = hc * 8; r < hc * 8 + 8; ++r) {
+                const float a = acc[i][j][r];
+                sc[((r & 3) + 8 * ((r >> 2) - hc * 2) + 4 * lhalf) * COLS + j * 32 + lrow] = sizeof(T) == 1 ? fmaf(a, sj[j], bj[j]) : a + bj[j];
+            }
+    };
+    if constexpr (EP == 3) {
+        // fp32 rows: 8 lanes x 16 bytes = one 128-byte line per row and 32-column block; 8 rows per pass, 2 passes per chunk
+        const int c4 = lane & 7, rsub = lane >> 3;
+        const bool pre = has_next && p.resid != nullptr;
+#pragma unroll
+        for (int ih = 0; ih < 4; ++ih) {
+            const int i = ih >> 1, hc = ih & 1;
+            to_scratch(i, hc);
+            // these accumulator registers are free now: the next tile's residual (or zero) goes in
+            if (pre) {
+#pragma unroll
+                for (int r = hc * 8; r < hc * 8 + 8; ++r) {
+                    int gr = nwm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    gr = gr < M ? gr : M - 1;
+                    const float* rp = p.resid + (int64_t)gr * p.ldr + nwn0 + lrow;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i][j][r] = rp[j * 32];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = hc * 8; r < hc * 8 + 8; ++r) acc[i][j][r] = 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int gr = wm0 + i * 32 + hc * 16 + t * 8 + rsub;
+                f32x4 v[3];
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) v[cb] = *(const f32x4*)(sc + (t * 8 + rsub) * COLS + cb * 32 + c4 * 4);
+                if (gr < M) {
+                    float* op = (float*)p.out + (int64_t)gr * p.ldo + wn0 + c4 * 4;
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb) *(f32x4*)(op + cb * 32) = v[cb];
+                }
+            }
+        }
+    } else {
+        // 16-bit rows: 4 lanes x 16 bytes per row and 32-column block, 16 rows per pass
+        const int c8 = lane & 3, rsub = lane >> 2;
+        auto store8 = [&](int64_t e, const float (&v)[8]) {
+            if (BD_EXP_NOSTORE) return;
+            if constexpr (OUTK == OUT_F16) store_cvt<_Float16, 8>((_Float16*)p.out + e, v);
+            else if constexpr (OUTK == OUT_BF16) store_cvt<__bf16, 8>((__bf16*)p.out + e, v);
+            else store_operand8<T, NS>((T*)p.out, p.out_plane, e, v);
+        };
+        float wv[EP == 2 ? 3 : 1][8];
+        bool norm = false;
+        if constexpr (EP == 2) {
+            // the 96-column wave tile IS one head (host-checked); which third of the output it lies in is wave-uniform
+            const int part = wn0 / (p.N / 3);
+            norm = part < 2;
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const float* src = rmsw + (part & 1) * 256 + cb * 32 + c8 * 8;
+                const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wv[cb][e] = a0[e]; wv[cb][4 + e] = a1[e]; }
+            }
+        }
+#pragma unroll
+        for (int ih = 0; ih < 4; ++ih) {
+            const int i = ih >> 1, hc = ih & 1;
+            to_scratch(i, hc);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = hc * 8; r < hc * 8 + 8; ++r) acc[i][j][r] = 0.f;
+            const int gr = wm0 + i * 32 + hc * 16 + rsub;
+            float v[3][8];
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const float* src = sc + rsub * COLS + cb * 32 + c8 * 8;
+                const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[cb][e] = a0[e]; v[cb][4 + e] = a1[e]; }
+            }
+            if constexpr (GELU) {
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) gelu_n<GeluKind<T, NS>::value, 8>(v[cb]);   // 16/8-bit result: fitted forms (bd_common.h)
+            }
+            if constexpr (EP == 2) {
+                float ss = 0.f;
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss = fmaf(v[cb][e], v[cb][e], ss);
+                ss = quad_sum(ss);
+                const float inv = rsqrtf(ss * (1.0f / 96.0f) + p.rms_eps);
+                if (norm) {
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[cb][e] = wv[cb][e] * (v[cb][e] * inv);     // w * (x * rsqrt(..)): blocks.py:51-56
+                }
+            }
+            if (gr < M) {
+                const int64_t e0 = (int64_t)gr * p.ldo + wn0 + c8 * 8;
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) store8(e0 + cb * 32, v[cb]);
+            }
+        }
+    }
+}
+
+template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NPW, int EP, int OUTK, bool GELU>
 __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const bd_gemm_args p) {
     typedef typename Op16<T>::vec8 frag_t;
     constexpr int ESZ = OpGeom<T>::ESZ, KSTEP = OpGeom<T>::KSTEP, CPF = OpGeom<T>::CPF;
@@ -739,8 +717,12 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
     static_assert(KS >= 1 && CH * 16 == ROWB && (CH == 4 || CH == 8) && A_BYTES % 1024 == 0 && W_BYTES % 1024 == 0, "slab geometry");
     static_assert(PA % NPW == 0 && PW % NPW == 0, "pieces split evenly over the producer waves");
     constexpr int SR = (NCW * 32 * NI * 32 * 4 <= STAGE_BYTES) ? 32 : 16;      // LDS-staged epilogue: scratch rows per pass
-    static_assert(BD_PC_EPI == 1 || NCW * SR * NI * 32 * 4 <= STAGE_BYTES, "the epilogue scratch must fit one stage");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
+    static_assert(NCW * SR * NI * 32 * 4 <= STAGE_BYTES, "the epilogue scratch must fit one stage");
+    static_assert(EP == 0 || (MI == 2 && NI == 3 && SR == 16 && TBN <= 256), "pc_epilogue is written for the 64 x 96 wave tile");
+    // side buffer behind the ring: per-column vectors of the current / next tile (2 x [bias 1 KiB | weight scale 1 KiB]) and
+    // the q / k RMSNorm weights (2 x 1 KiB)
+    constexpr int AUX_COLP = 2 * STAGE_BYTES, AUX_RMS = AUX_COLP + 4096, AUX_BYTES = EP == 0 ? 0 : 6144;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES + AUX_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -811,10 +793,27 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
         // is free, so slab g+1 may be fetched.  At a tile boundary the consumers signal "done with the tile's last slab" with
         // one extra barrier X before they start their (LDS-free) epilogue: the producers then already fetch the SECOND slab
         // of the next tile, so both of its first slabs land while the epilogue runs.
-        int ig = 0, it = t_begin + (bid >> 3), ikt = 0, im0 = 0, in0 = 0;
+        int ig = 0, it = t_begin + (bid >> 3), ikt = 0, im0 = 0, in0 = 0, itn = 0;
         if (it < t_end) tile_origin(it, im0, in0);
+        if constexpr (EP == 2) {
+            if (pw == 1) {        // q / k RMSNorm weights (96 floats each), once
+                const unsigned off = (unsigned)lane * 16 < 368u ? (unsigned)lane * 16 : 368u;
+                glds16_s(off, (const unsigned char*)p.rms_wq, lds_off + AUX_RMS);
+                glds16_s(off, (const unsigned char*)p.rms_wk, lds_off + AUX_RMS + 1024);
+            }
+        }
         auto issue_next = [&]() {
             if (it >= t_end) return;
+            if constexpr (EP != 0) {
+                if (ikt == 0) {   // the tile's per-column vectors ride with its first slab (N % TBN == 0: TBN floats are in bounds)
+                    if (pw == 0) {
+                        const unsigned off = (unsigned)lane * 16 < (unsigned)(TBN * 4 - 16) ? (unsigned)lane * 16 : (unsigned)(TBN * 4 - 16);
+                        if (p.bias) glds16_s(off, (const unsigned char*)(p.bias + in0), lds_off + AUX_COLP + (itn & 1) * 2048);
+                        if (sizeof(T) == 1 && p.wscale) glds16_s(off, (const unsigned char*)(p.wscale + in0), lds_off + AUX_COLP + (itn & 1) * 2048 + 1024);
+                    }
+                    ++itn;
+                }
+            }
             issue(ig & 1, im0, in0, ikt);
             ++ig;
             if (++ikt == nk) {
@@ -837,9 +836,6 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 ++g;
             }
             pc_barrier();                              // X: every consumer is done with the tile's last slab
-#if BD_PC_EPI == 1
-            if (ig == g + 1) issue_next();             // second slab of the next tile, under the (LDS-free) epilogue
-#endif
         }
 #ifdef BD_GEMM_PROBE
         if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * 16 + wid) * 64 + lane] = probe_ts;
@@ -855,15 +851,17 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
 #endif
     BD_PROBE(58) BD_PROBE_RT(56)
     int g = 0;       // (the host launches this kernel only when the wide, 16-byte epilogue applies: wide_epilogue_ok)
-    for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
+    int ti = 0;      // tiles done by this workgroup (parity = side-buffer slot of the tile's column vectors)
+    f32x16 acc[MI][NI];
+    if constexpr (EP != 0) {      // first tile; later tiles are initialised inside the previous tile's epilogue
+        int m0, n0;
+        tile_origin(t_begin + (bid >> 3), m0, n0);
+        acc_init<MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+    }
+    for (int t = t_begin + (bid >> 3); t < t_end; t += stride, ++ti) {
         int m0, n0;
         tile_origin(t, m0, n0);
-        f32x16 acc[MI][NI];
-#if BD_PC_EPI == 1
-        acc_init_bias_t<MI, NI>(p, acc, n0 + wn * (NI * 32), lane);     // transposed accumulators (row-per-lane)
-#else
-        acc_init_bias<MI, NI>(p, acc, n0 + wn * (NI * 32), lane);
-#endif
+        if constexpr (EP == 0) acc_init<MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
         for (int kt = 0; kt < nk; ++kt, ++g) {
             BD_PROBE_IF(g < 20, g * 3)
             pc_barrier();                              // B(kt)
@@ -914,11 +912,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
 #pragma unroll
                     for (int q = 0; q < NMM; ++q) {
                         const int i = q % MI, j = q / MI;
-#if BD_PC_EPI == 1
-                        acc[i][j] = Op16<T>::mfma(b[cur][0][j], a[cur][0][i], acc[i][j]);      // D^T = W . A^T
-#else
                         acc[i][j] = Op16<T>::mfma(a[cur][0][i], b[cur][0][j], acc[i][j]);
-#endif
                         if (ks + 1 < KS && q < NRD) load_q(cur ^ 1, ks + 1, q);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -990,14 +984,19 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
         BD_PROBE_IF(g == nk, 60)
         pc_barrier();                                  // X: this wave is done reading the tile's last slab
         BD_PROBE_IF(g == nk, 61)
-#if BD_PC_EPI == 1
-        gemm_epilogue_rowlane<T, NS, MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
-#else
         {   // LDS-staged epilogue; its scratch is the stage the tile's last slab lived in (free after X)
             unsigned char* scratch = lds + ((g - 1) & 1) * STAGE_BYTES + wid * (SR * NI * 32 * 4);
-            gemm_epilogue_lds<T, NS, MI, NI, SR, true>(p, acc, scratch, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+            if constexpr (EP == 0) {
+                gemm_epilogue_lds<T, NS, MI, NI, SR, true>(p, acc, scratch, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+            } else {
+                const bool has_next = t + stride < t_end;
+                int nm0 = 0, nn0 = 0;
+                if (has_next) tile_origin(t + stride, nm0, nn0);
+                pc_epilogue<T, NS, EP, OUTK, GELU>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
+                                                  (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
+                                                  lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
+            }
         }
-#endif
         BD_PROBE_IF(g == nk, 62)
     }
     BD_PROBE(59) BD_PROBE_RT(57)
@@ -1148,7 +1147,7 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
         int m0, n0;
         tile_origin(t, m0, n0);
         f32x16 acc[MI][NI];
-        acc_init_bias<MI, NI>(p, acc, n0 + wn * (NI * 32), lane);
+        acc_init<MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
         for (int kt = 0; kt < nk; ++kt) {
             BD_PROBE_IF(g < 20, g * 3)
             pc_barrier();                                 // B
@@ -1240,12 +1239,42 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
 #endif
 }
 
+// Which epilogue specialisation of gemm_kernel_pc serves these arguments (0 = the generic one): see the kernel's header
+template <class T, int NS> int pc_epilogue_kind(const bd_gemm_args& a, int& outk, bool& gelu) {
+    outk = a.out_f32;
+    gelu = a.act == BD_ACT_GELU;
+    if (a.addtab || a.rpg_in > 0) return 0;
+    if (a.bias && ((uintptr_t)a.bias & 15)) return 0;
+    if (a.out_f32 == OUT_F32) {
+        if (a.wscale || gelu || a.rms_wq) return 0;
+        return 3;
+    }
+    if (a.resid) return 0;
+    if (a.wscale && (sizeof(T) != 1 || ((uintptr_t)a.wscale & 15))) return 0;
+    // output kinds instantiated per operand class: native everywhere; f16 from split-bf16 (strict f16 attention), bf16 from e4m3
+    const bool outk_ok = outk == OUT_OPERAND || (outk == OUT_F16 && NS == 2 && sizeof(T) == 2) || (outk == OUT_BF16 && sizeof(T) == 1);
+    if (!outk_ok) return 0;
+    if (a.rms_wq) return gelu ? 0 : 2;
+    return 1;
+}
+
 template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_pc(const bd_gemm_args& a, hipStream_t s, int cus) {
     constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32;
     constexpr int NPW = 4;        // one producer wave per SIMD: a single wave issues one LDS-DMA piece per ~70 cycles, the CU ~23
     const int tiles = ((a.M + TBM - 1) / TBM) * ((a.N + TBN - 1) / TBN);
     const int grid = tiles < cus ? tiles : cus;
-    hipLaunchKernelGGL((gemm_kernel_pc<T, NS, BK, WM, WN, MI, NI, NPW>), dim3(grid), dim3((WM * WN + NPW) * 64), 0, s, a);
+    const dim3 g(grid), b((WM * WN + NPW) * 64);
+    int outk = 0;
+    bool gelu = false;
+    const int ep = (a.N % TBN == 0) ? pc_epilogue_kind<T, NS>(a, outk, gelu) : 0;
+#define BD_PC_LAUNCH(EP_, OUTK_, GELU_) hipLaunchKernelGGL((gemm_kernel_pc<T, NS, BK, WM, WN, MI, NI, NPW, EP_, OUTK_, GELU_>), g, b, 0, s, a)
+    constexpr int ALT = (NS == 2 && sizeof(T) == 2) ? OUT_F16 : (sizeof(T) == 1 ? OUT_BF16 : OUT_OPERAND);   // the one non-native 16-bit kind
+    if (ep == 3) BD_PC_LAUNCH(3, OUT_F32, false);
+    else if (ep == 2) { if (outk == OUT_OPERAND) BD_PC_LAUNCH(2, OUT_OPERAND, false); else BD_PC_LAUNCH(2, ALT, false); }
+    else if (ep == 1 && gelu && outk == OUT_OPERAND) BD_PC_LAUNCH(1, OUT_OPERAND, true);
+    else if (ep == 1 && !gelu) { if (outk == OUT_OPERAND) BD_PC_LAUNCH(1, OUT_OPERAND, false); else BD_PC_LAUNCH(1, ALT, false); }
+    else BD_PC_LAUNCH(0, OUT_OPERAND, false);
+#undef BD_PC_LAUNCH
 }
 
 template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_glds(const bd_gemm_args& a, hipStream_t s) {

@@ -180,6 +180,41 @@ def test_qk_rmsnorm(hip, prec, hd, heads):
     assert torch.equal(got[:, 2], src[:, 2])           # v untouched
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "bf16x3", "fp8"])
+@pytest.mark.parametrize("N,K,kind", [(2304, 768, "plain"), (2304, 768, "rms"), (3072, 768, "gelu"), (768, 768, "resid"),
+                                      (768, 3072, "resid"), (768, 768, "f32")])
+def test_gemm_row_result_independent_of_tile_shape(hip, prec, N, K, kind):
+    """A row's result must not depend on the kernel / tile shape that computed it: the first rows of a 49152-row launch
+    (persistent 256x192 kernel, specialised epilogues) equal, bit for bit, the same rows launched alone at 1536 / 300 / 4096
+    rows (128x128, 64x64 and hybrid tiles, generic epilogue).  This is what makes a sample's output independent of its batch
+    (tests/test_gpu_path.py::test_full_size_properties); it pins the accumulator-start / bias / residual convention, the
+    GELU arithmetic and the separate fp32 -> 16-bit rounding across every kernel."""
+    M = 49152
+    a, w, b = _rand("a", (M, K)).cuda(), (_rand("w", (N, K), 0.05)).cuda(), _rand("b", (N,), 0.5).cuda()
+    a16, w16 = hip_ops.to_operand(a, prec), hip_ops.to_operand(w, prec)
+    res = _rand("r", (M, N)).cuda() if kind == "resid" else None
+    ws = (torch.rand(N, generator=torch.Generator().manual_seed(5)) + 0.5).cuda() if prec == "fp8" else None
+
+    def go(rows):
+        aa = a16[:, :rows].contiguous() if a16.dim() == 3 else a16[:rows].contiguous()
+        kw = {"wscale": ws}
+        if kind == "resid":
+            kw.update(resid=res[:rows].clone(), out_f32=True)
+        elif kind == "gelu":
+            kw.update(act=1)
+        elif kind == "f32":
+            kw.update(out_f32=True)
+        elif kind == "rms":
+            kw.update(rms=((_rand("wq", (96,), 0.1) + 1).cuda(), (_rand("wk", (96,), 0.1) + 1).cuda(), 1e-6))
+        return hip_ops.gemm(aa, w16, b, prec=prec, **kw)
+
+    big = go(M)
+    for rows in (1536, 300, 4096):
+        small = go(rows)
+        head = big[:, :rows] if big.dim() == 3 else big[:rows]
+        assert torch.equal(head.contiguous().view(torch.uint8), small.contiguous().view(torch.uint8)), (prec, kind, rows)
+
+
 @pytest.mark.parametrize("prec,out_mode", [("bf16", None), ("fp16", None), ("bf16x3", None), ("bf16x3", 2), ("f16c8", 2), ("f16c8", 4)])
 @pytest.mark.parametrize("M", [300, 4096, 49152 // 8])
 def test_gemm_fused_qk_rmsnorm(hip, prec, out_mode, M):

@@ -40,13 +40,16 @@ def run(M, N, K, prec="bf16"):
     b = torch.randn(N, device="cuda")
     nwave = 8
     buf = torch.zeros(1024 * nwave * 64, dtype=torch.int32, device="cuda")
+    rms = None
+    if os.environ.get("BD_PROBE_RMS") == "1":          # fused q/k RMSNorm: also forces the persistent kernel at ANY M (lone-CU runs)
+        rms = (torch.ones(96, device="cuda"), torch.ones(96, device="cuda"), 1e-6)
     for _ in range(3):
-        hip_ops.gemm(a, w, b, prec=prec, w_qexp=qe)
+        hip_ops.gemm(a, w, b, prec=prec, w_qexp=qe, rms=rms)
     lib.bd_gemm_probe_set.argtypes = [C.c_void_p]
     assert lib.bd_gemm_probe_set(C.c_void_p(buf.data_ptr())) == 0
     torch.cuda.synchronize()
     for _ in range(int(os.environ.get("BD_PROBE_LAUNCHES", "60"))):      # back to back: the stamps of the LAST launch survive,
-        hip_ops.gemm(a, w, b, prec=prec, w_qexp=qe)                                   # taken at sustained (DVFS-settled) clocks
+        hip_ops.gemm(a, w, b, prec=prec, w_qexp=qe, rms=rms)                          # taken at sustained (DVFS-settled) clocks
     torch.cuda.synchronize()
     if os.environ.get("BD_PROBE_PC", "1") == "1":
         return report_pc(buf.cpu().numpy().astype(np.uint32).reshape(512, 16, 64), M, N, K, prec)
@@ -71,7 +74,7 @@ def report_pc(ts, M, N, K, prec):
     """gemm_kernel_pc (8 consumer + 4 producer waves, persistent): first tile of each of the 256 workgroups."""
     import numpy as np
     nk = min(K // (32 if prec in ("bf16x3", "f16c8") else (128 if prec == "fp8" else 64)), 20)
-    first = ts[:256].astype(np.int64)
+    first = ts[:min(256, ((M + 255) // 256) * (N // 192))].astype(np.int64)
     d = lambda w, i, j: ((first[:, w, i] - first[:, w, j]) & 0xFFFFFFFF).astype(np.float64)
     for w in (0, 4):
         wait = np.stack([d(w, 3 * k + 1, 3 * k) for k in range(nk)], 1)
