@@ -19,7 +19,7 @@ struct Carver {
 
 inline int planes_of(int prec) {      // 2-byte units per element of a 16-bit operand buffer (F16C8: f16 plane + e4m3 plane)
     return (prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_BF16X3_ATTN_F16 ||
-            prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16C8) ? 2 : 1;
+            prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16C8 || prec == BD_PREC_F16C8_QKV16) ? 2 : 1;
 }
 
 struct BlockBufs {
@@ -55,8 +55,10 @@ inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const
 //   BD_PREC_BF16X3_ATTN_F16  f16 attention everywhere (1.18e-3: the f16 Q.K^T on DINOv2's un-normalised q/k eats the whole
 //                            1e-3 budget -- kept for measurement, misses the bar)
 inline int gemm_prec(int prec) {
+    if (prec == BD_PREC_F16C8_QKV16) return BD_PREC_F16C8;
     return (prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_BF16X3_ATTN_F16 || prec == BD_PREC_BF16X3_QKV16) ? BD_PREC_BF16X3 : prec;
 }
+inline bool qkv_single_f16(int prec) { return prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16C8_QKV16; }
 inline bool x3_f16_attention(int prec, bool qk_normed) {
     return prec == BD_PREC_BF16X3_ATTN_F16 || ((prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_QKV16) && qk_normed);
 }
@@ -77,7 +79,7 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
     const int qkv_out = hyb ? 2 : (f8 ? 3 : (c8 ? 4 : 0));          // f16 plane / bf16 plane / split-bf16 planes / operand class
     bool rms_fused = false;
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D, p4D = (int64_t)M * 4 * D;
-    if (wprec == BD_PREC_BF16X3_QKV16 && hyb && w.qkv16.w) {
+    if (qkv_single_f16(wprec) && hyb && w.qkv16.w) {
         // the one Linear that may leave the split scheme: f16 LayerNorm output x f16 weights, one pass, f16 q, k, v out
         BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, 0, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16, stream));
         bd_gemm_args g = gemm_args(b.xn, D, 0, w.qkv16, D, 3 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);
@@ -134,7 +136,7 @@ int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, flo
     bool rms_fused = false;
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D;
     const int64_t qD = (int64_t)Mq * D, q4D = (int64_t)Mq * 4 * D;
-    if (wprec == BD_PREC_BF16X3_QKV16 && hyb && w.qkv16.w) {
+    if (qkv_single_f16(wprec) && hyb && w.qkv16.w) {
         // the one Linear that may leave the split scheme: f16 LayerNorm output x f16 weights, one pass, f16 q, k, v out
         BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, 0, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16, stream));
         bd_gemm_args g = gemm_args(b.xn, D, 0, w.qkv16, D, 3 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);
@@ -215,7 +217,7 @@ DecBufs carve_decoder(const bd_betr_weights* w, int B, int T, int prec, void* ws
 inline bool bad_prec(int prec) {
     return prec != BD_PREC_BF16 && prec != BD_PREC_F16 && prec != BD_PREC_BF16X3 && prec != BD_PREC_FP8 &&
            prec != BD_PREC_BF16X3_ATTN_X3 && prec != BD_PREC_BF16X3_ATTN_F16 && prec != BD_PREC_BF16X3_QKV16 &&
-           prec != BD_PREC_F16C8;
+           prec != BD_PREC_F16C8 && prec != BD_PREC_F16C8_QKV16;
 }
 
 }  // namespace

@@ -640,6 +640,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
             if (BD_EXP_NOSTORE) return;
             if constexpr (OUTK == OUT_F16) store_cvt<_Float16, 8>((_Float16*)p.out + e, v);
             else if constexpr (OUTK == OUT_BF16) store_cvt<__bf16, 8>((__bf16*)p.out + e, v);
+            else if constexpr (OUTK == OUT_BF16X2) store_operand8<__bf16, 2>((__bf16*)p.out, p.out_plane, e, v);
             else store_operand8<T, NS>((T*)p.out, p.out_plane, e, v);
         };
         float wv[EP == 2 ? 3 : 1][8];
@@ -1024,7 +1025,7 @@ inline bool wide_epilogue_ok(const bd_gemm_args& p, int ns) {
 //     slab in this operand class, is off the critical path.  NSTAGE = 2 (scratch separate) serves the other K.
 //   * the e4m3 image q8 of an f16 fragment derived in registers (v_cvt_scalef32_pk_fp8_f16, 4 per fragment), so the
 //     correction pass costs one extra ds_read_b128 per 32-row fragment pair instead of two.
-template <int NSTAGE>
+template <int NSTAGE, int EP, int OUTK, bool GELU>
 __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_args p) {
     constexpr int WM = 4, WN = 2, MI = 2, NI = 3, NPW = 4, NCW = WM * WN;
     constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32, BK = 32;
@@ -1032,7 +1033,9 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
     constexpr int OFF_W0 = A0, OFF_A1 = A0 + W0, OFF_W1 = A0 + W0 + A1, STAGE = A0 + W0 + A1 + W1;
     constexpr int SR = 16, SCRATCH = NCW * SR * NI * 32 * 4;
     static_assert(SCRATCH == STAGE, "the epilogue scratch overlays stage 2 exactly");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE + SCRATCH];   // stages at 0, STAGE, 2*STAGE; scratch at 2*STAGE
+    // side buffer behind the ring + scratch (gemm_kernel_pc): per-column vectors of the current / next tile, q / k RMSNorm weights
+    constexpr int AUX_COLP = 2 * STAGE + SCRATCH, AUX_RMS = AUX_COLP + 4096, AUX_BYTES = EP == 0 ? 0 : 6144;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE + SCRATCH + AUX_BYTES];   // stages at 0, STAGE, 2*STAGE; scratch at 2*STAGE
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1091,10 +1094,28 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
             for (int i = 0; i < 3; ++i) glds16_s(oW1[i] < lw1 ? oW1[i] : lw1, bw1, st + OFF_W1 + i * 4096);
         };
         // issue cursor over this workgroup's slab sequence (all tiles, slab by slab); slab number ig goes to stage ig % NSTAGE
-        int ig = 0, ist = 0, it = t_begin + (bid >> 3), ikt = 0, im0 = 0, in0 = 0;
+        int ig = 0, ist = 0, it = t_begin + (bid >> 3), ikt = 0, im0 = 0, in0 = 0, itn = 0;
         if (it < t_end) tile_origin(it, im0, in0);
+        if constexpr (EP == 2) {
+            if (pw == 1) {        // q / k RMSNorm weights (96 floats each), once
+                const unsigned off = (unsigned)lane * 16 < 368u ? (unsigned)lane * 16 : 368u;
+                glds16_s(off, (const unsigned char*)p.rms_wq, lds_off + AUX_RMS);
+                glds16_s(off, (const unsigned char*)p.rms_wk, lds_off + AUX_RMS + 1024);
+            }
+        }
         auto issue_next = [&]() {
             if (it >= t_end) return;
+            if constexpr (EP != 0) {
+                // the tile's bias vector rides in FRONT of its first slab (the counted vmcnt below covers everything but the
+                // most recent slab's 12 pieces); the host sends K >= 128 here, so a slot is rewritten only after its tile is done
+                if (ikt == 0) {
+                    if (pw == 0 && p.bias) {
+                        const unsigned off = (unsigned)lane * 16 < (unsigned)(TBN * 4 - 16) ? (unsigned)lane * 16 : (unsigned)(TBN * 4 - 16);
+                        glds16_s(off, (const unsigned char*)(p.bias + in0), lds_off + AUX_COLP + (itn & 1) * 2048);
+                    }
+                    ++itn;
+                }
+            }
             issue(ist, im0, in0, ikt);
             ++ig;
             ist = ist + 1 == NSTAGE ? 0 : ist + 1;
@@ -1143,11 +1164,17 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
     int g = 0;
 #endif
     BD_PROBE(58) BD_PROBE_RT(56)
-    for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
+    int ti = 0;
+    f32x16 acc[MI][NI];
+    if constexpr (EP != 0) {      // first tile; later tiles are initialised inside the previous tile's epilogue
+        int m0, n0;
+        tile_origin(t_begin + (bid >> 3), m0, n0);
+        acc_init<MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+    }
+    for (int t = t_begin + (bid >> 3); t < t_end; t += stride, ++ti) {
         int m0, n0;
         tile_origin(t, m0, n0);
-        f32x16 acc[MI][NI];
-        acc_init<MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+        if constexpr (EP == 0) acc_init<MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
         for (int kt = 0; kt < nk; ++kt) {
             BD_PROBE_IF(g < 20, g * 3)
             pc_barrier();                                 // B
@@ -1158,7 +1185,7 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
             const unsigned char* base = lds + g_st * STAGE;
             g_st = g_st + 1 == NSTAGE ? 0 : g_st + 1;
             f16x8 ah[2][MI], wh[2][NI];
-            u128 al[MI], aq[MI];
+            u128 al[MI];
             i32x8 w8[NI];
 #define LD16(dst, ptr, row, ks) dst = __builtin_bit_cast(f16x8, *(const u128*)((ptr) + (row) * 64 + (swz_chunk<4>((row), (ks) * 2 + lhalf) << 4)));
 #define LDLO(dst, ptr, row) dst = *(const u128*)((ptr) + (row) * 32 + (swz_chunk<2>((row), lhalf) << 4));
@@ -1169,68 +1196,77 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
                 const u128 hi_ = *(const u128*)((ptr) + (row) * 64 + (swz_chunk<4>((row), 2 * lhalf + 1) << 4));    \
                 dst = (i32x8){(int)lo_[0], (int)lo_[1], (int)lo_[2], (int)lo_[3], (int)hi_[0], (int)hi_[1], (int)hi_[2], (int)hi_[3]}; \
             }
-            // e4m3 image of a lane's two f16 A fragments of one row block (k-steps 0 and 1: 16 values), 4 dwords.
+            // e4m3 image of one f16 A fragment (8 values of a k-step), 2 dwords; scale 1.0 (activations are clamped to +-448).
             // (pairs built element-wise: __builtin_bit_cast of a vector ELEMENT to a 2 x f16 vector is miscompiled by hipcc 7.2
             // here -- every conversion then reads the first dword)
-#define Q8(dst, f0, f1, sc)                                                                                   \
+#define Q8H(d0, d1, f)                                                                                        \
             {                                                                                                     \
                 typedef _Float16 h2_ __attribute__((ext_vector_type(2)));                                         \
                 typedef short s2_ __attribute__((ext_vector_type(2)));                                            \
-                s2_ d0_ = {0, 0}, d1_ = {0, 0}, d2_ = {0, 0}, d3_ = {0, 0};                                       \
-                d0_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d0_, (h2_){f0[0], f0[1]}, sc, false);              \
-                d0_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d0_, (h2_){f0[2], f0[3]}, sc, true);               \
-                d1_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d1_, (h2_){f0[4], f0[5]}, sc, false);              \
-                d1_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d1_, (h2_){f0[6], f0[7]}, sc, true);               \
-                d2_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d2_, (h2_){f1[0], f1[1]}, sc, false);              \
-                d2_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d2_, (h2_){f1[2], f1[3]}, sc, true);               \
-                d3_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d3_, (h2_){f1[4], f1[5]}, sc, false);              \
-                d3_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(d3_, (h2_){f1[6], f1[7]}, sc, true);               \
-                dst = (u128){__builtin_bit_cast(unsigned, d0_), __builtin_bit_cast(unsigned, d1_),               \
-                             __builtin_bit_cast(unsigned, d2_), __builtin_bit_cast(unsigned, d3_)};               \
+                s2_ a_ = {0, 0}, b_ = {0, 0};                                                                     \
+                a_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(a_, (h2_){f[0], f[1]}, 1.0f, false);                \
+                a_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(a_, (h2_){f[2], f[3]}, 1.0f, true);                 \
+                b_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b_, (h2_){f[4], f[5]}, 1.0f, false);                \
+                b_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b_, (h2_){f[6], f[7]}, 1.0f, true);                 \
+                d0 = __builtin_bit_cast(unsigned, a_);                                                            \
+                d1 = __builtin_bit_cast(unsigned, b_);                                                            \
             }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int j = 0; j < NI; ++j) LD16(wh[0][j], base + OFF_W0, wn * (NI * 32) + j * 32 + lrow, 0)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) LD16(wh[ks][j], base + OFF_W0, wn * (NI * 32) + j * 32 + lrow, ks)
-#pragma unroll
-                for (int i = 0; i < MI; ++i) LD16(ah[ks][i], base, wm * (MI * 32) + i * 32 + lrow, ks)
-            }
+            for (int i = 0; i < MI; ++i) LD16(ah[0][i], base, wm * (MI * 32) + i * 32 + lrow, 0)
             __builtin_amdgcn_sched_barrier(0);
             constexpr int NMM = MI * NI;
-            // Register rotation (168-VGPR budget): A's q8 images are derived under the first f16 k-step, whose fragments then
-            // die; A's lo8 and W's [q8 | lo8] fragments are loaded into the freed registers under the second k-step.
+            static_assert(MI == 2 && NI == 3, "the interleave below is written for 2 x 3 MFMA tiles per wave");
+            unsigned qd[MI][4];
 #pragma unroll
-            for (int q = 0; q < NMM; ++q) {                       // f16, k-step 0 (+ q8 of A)
+            for (int q = 0; q < NMM; ++q) {                       // f16, k-step 0
                 const int i = q % MI, j = q / MI;
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], wh[0][j], acc[i][j], 0, 0, 0);
-                if (q < MI) Q8(aq[q], ah[0][q], ah[1][q], 1.0f)
+                if (q < MI) LD16(ah[1][q], base, wm * (MI * 32) + q * 32 + lrow, 1)
+                else if (q < MI + NI) LD16(wh[1][q - MI], base + OFF_W0, wn * (NI * 32) + (q - MI) * 32 + lrow, 1)
+                if (q == 3) Q8H(qd[0][0], qd[0][1], ah[0][0])
+                if (q == 4) Q8H(qd[1][0], qd[1][1], ah[0][1])
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int q = 0; q < NMM; ++q) {                       // f16, k-step 1 (+ the e4m3 fragment loads)
+            for (int q = 0; q < NMM; ++q) {                       // f16, k-step 1
                 const int i = q % MI, j = q / MI;
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], wh[1][j], acc[i][j], 0, 0, 0);
-                if (q < NI) LDW8(w8[q], base + OFF_W1, wn * (NI * 32) + q * 32 + lrow)
-                else if (q - NI < MI) LDLO(al[q - NI], base + OFF_A1, wm * (MI * 32) + (q - NI) * 32 + lrow)
+                if (q < MI) LDLO(al[q], base + OFF_A1, wm * (MI * 32) + q * 32 + lrow)
+                if (q == 2) LDW8(w8[0], base + OFF_W1, wn * (NI * 32) + lrow)
+                if (q == 4) LDW8(w8[1], base + OFF_W1, wn * (NI * 32) + 32 + lrow)
+                if (q == 2) Q8H(qd[0][2], qd[0][3], ah[1][0])
+                if (q == 3) Q8H(qd[1][2], qd[1][3], ah[1][1])
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int q = 0; q < NMM; ++q) {                       // e4m3 correction pass: [lo_A | q_A] . [q_W | lo_W]
                 const int i = q % MI, j = q / MI;
-                const i32x8 a8 = {(int)al[i][0], (int)al[i][1], (int)al[i][2], (int)al[i][3], (int)aq[i][0], (int)aq[i][1], (int)aq[i][2], (int)aq[i][3]};
+                const i32x8 a8 = {(int)al[i][0], (int)al[i][1], (int)al[i][2], (int)al[i][3], (int)qd[i][0], (int)qd[i][1], (int)qd[i][2], (int)qd[i][3]};
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, w8[j], acc[i][j], 0, 0, 0, scale_a, 0, scale_w);
+                if (q == 0) LDW8(w8[2], base + OFF_W1, wn * (NI * 32) + 64 + lrow)
                 __builtin_amdgcn_sched_barrier(0);
             }
 #undef LDW8
 #undef LD16
 #undef LDLO
-#undef Q8
+#undef Q8H
         }
         BD_PROBE_IF(g == nk, 60)
         pc_barrier();                                     // X
         BD_PROBE_IF(g == nk, 61)
         unsigned char* scratch = lds + 2 * STAGE + wid * (SR * NI * 32 * 4);
-        gemm_epilogue_lds<f16c8, 2, MI, NI, SR, true>(p, acc, scratch, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+        if constexpr (EP == 0) {
+            gemm_epilogue_lds<f16c8, 2, MI, NI, SR, true>(p, acc, scratch, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+        } else {
+            const bool has_next = t + stride < t_end;
+            int nm0 = 0, nn0 = 0;
+            if (has_next) tile_origin(t + stride, nm0, nn0);
+            pc_epilogue<f16c8, 2, EP, OUTK, GELU>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
+                                                 (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
+                                                 lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
+        }
         BD_PROBE_IF(g == nk, 62)
     }
     BD_PROBE(59) BD_PROBE_RT(57)
@@ -1435,8 +1471,29 @@ int launch_f16c8(const bd_gemm_args& a, hipStream_t s) {
     const int cus = cu_count();
     const int tiles = ((a.M + 255) / 256) * ((a.N + 191) / 192);
     const int grid = tiles < cus ? tiles : cus;
-    if ((a.K / 32) % 3 == 0) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3>), dim3(grid), dim3(768), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2>), dim3(grid), dim3(768), 0, s, a);
+    // epilogue specialisation (gemm_kernel_pc's header): native / f16 / split-bf16 16-bit results, fp32 (+ residual)
+    int ep = 0, outk = a.out_f32;
+    const bool gelu = a.act == BD_ACT_GELU;
+    if (!a.addtab && a.rpg_in <= 0 && !a.wscale && a.N % 192 == 0 && a.K >= 128 && !(a.bias && ((uintptr_t)a.bias & 15))) {
+        if (a.out_f32 == OUT_F32) ep = (gelu || a.rms_wq) ? 0 : 3;
+        else if (!a.resid && (outk == OUT_OPERAND || outk == OUT_F16 || outk == OUT_BF16X2)) ep = a.rms_wq ? (gelu ? 0 : 2) : 1;
+    }
+    if (ep == 1 && gelu && outk != OUT_OPERAND) ep = 0;
+    const bool s3 = (a.K / 32) % 3 == 0;
+    const dim3 g(grid), b(768);
+#define BD_C8_LAUNCH(EP_, OUTK_, GELU_)                                                                     \
+    { if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_>), g, b, 0, s, a);                 \
+      else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, EP_, OUTK_, GELU_>), g, b, 0, s, a); }
+    if (ep == 3) BD_C8_LAUNCH(3, OUT_F32, false)
+    else if (ep == 2 && outk == OUT_OPERAND) BD_C8_LAUNCH(2, OUT_OPERAND, false)
+    else if (ep == 2 && outk == OUT_F16) BD_C8_LAUNCH(2, OUT_F16, false)
+    else if (ep == 2) BD_C8_LAUNCH(2, OUT_BF16X2, false)
+    else if (ep == 1 && gelu) BD_C8_LAUNCH(1, OUT_OPERAND, true)
+    else if (ep == 1 && outk == OUT_OPERAND) BD_C8_LAUNCH(1, OUT_OPERAND, false)
+    else if (ep == 1 && outk == OUT_F16) BD_C8_LAUNCH(1, OUT_F16, false)
+    else if (ep == 1) BD_C8_LAUNCH(1, OUT_BF16X2, false)
+    else BD_C8_LAUNCH(0, OUT_OPERAND, false)
+#undef BD_C8_LAUNCH
     bd_trace_close(s, slot);
     BD_CHECK_LAUNCH();
     return BD_OK;

@@ -156,7 +156,7 @@ def _pack_block(pk: Packed, sd: dict, p: str, prec, device, ls: bool, qk_norm: b
     if qk_norm:
         bw.q_norm_w = pk.keep(sd[p + "attn.q_norm.weight"].float(), device)
         bw.k_norm_w = pk.keep(sd[p + "attn.k_norm.weight"].float(), device)
-        if _lib.prec_id(prec) == _lib.PREC_BF16X3:      # f16 single-plane copy for BD_PREC_BF16X3_QKV16 (2 x 3.5 MB per block)
+        if _lib.prec_id(prec) in (_lib.PREC_BF16X3, _lib.PREC_F16C8):   # f16 single-plane copy for the *_QKV16 modes (3.5 MB per block)
             bw.qkv16 = pk.linear(pack_linear_weight(sd[p + "attn.qkv.weight"], "fp16"), pack_bias(sd[p + "attn.qkv.bias"]), device)
     return bw
 

@@ -69,6 +69,9 @@ extern "C" {
  * the GEMM in registers.  E = 0 for activations, bd_linear.w_qexp / bd_gemm_args.w_qexp for a weight tensor.  Activation
  * operands are clamped to +-448.  Attention: f16 single pass where q, k are RMS-normalised (BETR), split-bf16 in DINOv2. */
 #define BD_PREC_F16C8 8
+/*   BD_PREC_F16C8_QKV16      whole-path only: BD_PREC_F16C8 Linears with BD_PREC_BF16X3_QKV16's exception (BETR's QKV Linear as ONE f16
+ *                            pass on an f16 LayerNorm output; needs bd_block_weights.qkv16): round 2's fastest mode inside 1e-3. */
+#define BD_PREC_F16C8_QKV16 12
 #define BD_PREC_F16_OUT_F16C8 9     /* bd_attention[_q] only: f16 qkv (one plane) in, one f16 MFMA pass, F16C8 operand out */
 #define BD_PREC_BF16X3_OUT_F16C8 10 /* bd_attention[_q] only: split-bf16 qkv planes in, split-bf16 attention, F16C8 operand out */
 
