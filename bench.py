@@ -301,7 +301,7 @@ def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, traf
     a = [(4.0 * m * n * n * k, ms) for kind, m, n, k, ms in recs if kind == 1]   # 4*S^2*d per (batch*head)
     gemm_tf = sum(f for f, _ in g) / max(sum(ms for _, ms in g), 1e-9) / 1e9 if g else 0.0
     attn_tf = sum(f for f, _ in a) / max(sum(ms for _, ms in a), 1e-9) / 1e9 if a else 0.0
-    r = {"bound": "mfma", "kernel": "gemm_kernel_glds (256x256 / 256x192 / 128x128 tiles, LDS-DMA operands, v_mfma_f32_32x32x16)",
+    r = {"bound": "mfma", "kernel": "gemm_kernel_pc (persistent producer/consumer, 256x192 tiles, LDS-DMA operands, v_mfma_f32_32x32x16) + gemm_kernel_glds for the shapes it does not take",
          "achieved": round(gemm_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tf / peak, 4),
          "traffic": traffic[0], "traffic_source": traffic[1],
          "algorithmic_flops_per_launch": round(sum(f for f, _ in g) / max(len(g), 1)), "launches": len(g),

@@ -40,7 +40,7 @@ for cls in sorted(set(fetch) | set(write)):
 g = per.get("gemm", {"launches": 0, "fetch_bytes_per_launch": 0, "write_bytes_per_launch": 0, "hbm_bytes_per_launch": 0})
 json.dump({"hbm_bytes_per_launch": g["hbm_bytes_per_launch"], "fetch_bytes_per_launch": g["fetch_bytes_per_launch"],
            "write_bytes_per_launch": g["write_bytes_per_launch"], "launches": g["launches"], "per_kernel_class": per,
-           "source": "round 1: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace) over "
+           "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace) over "
                      "`bench.py --steps 2 --warmup 1 --no-graph` (bf16, B=32, T=6); bytes = counter KB x 1024, FETCH_SIZE x2 "
                      "(gfx950 correction, MI355X_MICROARCH.md HBM section); mean over all gemm_kernel launches (tools/hbm_traffic.py)"},
           open(out, "w"), indent=1)
