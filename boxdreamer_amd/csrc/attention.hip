@@ -20,6 +20,15 @@
 // hi*hi + hi*lo + lo*hi.
 #include "bd_common.h"
 
+#ifdef BD_ATTN_PROBE
+// Measurement build only (tools/attn_phase_probe.py): per-wave shader-clock stamps of the ping-pong kernel's segments.
+__device__ unsigned* bd_attn_probe_buf = nullptr;
+extern "C" int bd_attn_probe_set(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(bd_attn_probe_buf), &buf, sizeof(buf)); }
+#define AP(idx) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((idx) < 64) probe_ts = (lane == (idx)) ? (unsigned)t__ : probe_ts; }
+#else
+#define AP(idx) {}
+#endif
+
 namespace {
 
 struct AttnArgs {
@@ -337,6 +346,313 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined form (round 2) for the single-plane operand classes: 8 waves, 256 queries per workgroup, one per CU.
+//
+// Why (tools/attn_phase_probe.py, profiles/r2_attention.md): attn_kernel runs S(t), softmax(t), PV(t) one after the other in
+// every wave; with two independent 4-wave workgroups per CU the two waves of a SIMD fell into the same phase (VALU 55 % + MFMA
+// 29 % busy adding up instead of overlapping).  A first round-2 attempt put the two waves of a SIMD into ONE workgroup, a
+// barrier-enforced segment apart (one in its MFMA segment while the other does its softmax): measured 1376-1759 cycles for a
+// 768-cycle MFMA segment and 504 vs 1419 cycles for the same softmax depending on which wave wins the issue arbitration --
+// a dense VALU stream and an MFMA stream of two different waves do not share a SIMD's issue port gracefully.  What does work
+// is interleaving them inside ONE instruction stream: an MFMA occupies the issue port for 4 of its 32 cycles, and the same
+// wave's next 6-7 VALU instructions ride in the rest.  So each wave here runs, per key tile t,
+//     24 MFMA slots = PV(t-1) (12) + S(t+1) (12),   with the VALU work of softmax(t) spread over the slots,
+// i.e. the softmax of a tile executes under the matrix work of its two neighbours (two S accumulator sets, two P fragment
+// sets; order pinned with sched_barrier).  Operand fragments are read three slots ahead into a ring of four registers.
+// Staging: all 512 threads fetch tile t+2 (global -> registers) at the top of iteration t and store it (K as is, V transposed,
+// attn_kernel's LDS images) at its end; K ring 2 tiles, V^T ring 4 tiles, ONE barrier per tile.
+template <class T, int HD, int OUTMODE>
+__global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
+    typedef typename Op16<T>::vec8 vec8;
+    constexpr int NT = 512;
+    constexpr int DCH = HD / 8;
+    constexpr int KSTRIDE = HD * 2 + 16;
+    constexpr int K_BYTES = KT * KSTRIDE;
+    constexpr int V_BYTES = HD * 128;
+    constexpr int KBUF = 2, VBUF = 4;
+    constexpr int KCH = KT * DCH;
+    constexpr int KCPT = (KCH + NT - 1) / NT;
+    constexpr int VMT = (KT / 4) * DCH;
+    static_assert(VMT <= NT, "one V micro-tile per thread");
+    constexpr int QB = 256;
+    constexpr int DM = HD / 32;
+    constexpr int KS = HD / 16;
+    constexpr int NPV = 4 * DM, NS_ = 2 * KS, NSLOT = NPV + NS_;
+    static_assert(NSLOT >= 22, "softmax schedule below needs 22 slots");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[KBUF * K_BYTES + VBUF * V_BYTES];
+    unsigned char* const vring = lds;
+    unsigned char* const kring = lds + VBUF * V_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, lh = lane >> 5;
+    const int seq = p.seq, heads = p.heads;
+    const int q_len = p.q_len;
+    const int nqb = (q_len + QB - 1) / QB;
+
+    int wg;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int qb = wg % nqb;
+    const int bh = wg / nqb;
+    const int head = bh % heads, b = bh / heads;
+
+    const int ld = 3 * heads * HD;
+    const T* base = (const T*)p.qkv + (int64_t)b * seq * ld + head * HD;
+    const T* kbase = base + heads * HD;
+    const T* vbase = base + 2 * heads * HD;
+
+    const int q0 = qb * QB + wid * 32;
+    const int qbase_row = p.q_view ? p.q_view[b] * q_len : 0;
+    int qrow = q0 + lq; qrow = (qrow < q_len ? qrow : q_len - 1) + qbase_row;
+    vec8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = as_vec8<T>(*(const u128*)(base + (unsigned)(qrow * ld + ks * 16 + lh * 8)));
+
+    // ---- staging coordinates
+    int kc_row[KCPT], kc_col[KCPT];
+#pragma unroll
+    for (int i = 0; i < KCPT; ++i) {
+        const int c = tid + NT * i;
+        kc_row[i] = c / DCH;
+        kc_col[i] = c % DCH;
+    }
+    const int vm_kq = tid / DCH, vm_dc = tid % DCH;
+    const bool vm_active = tid < VMT;
+    const bool ragged = (seq % KT) != 0;
+    int vdst;
+    {
+        const int g = vm_kq >> 2, qi = vm_kq & 3;
+        const int qp = (qi == 1) ? 2 : (qi == 2 ? 1 : qi);
+        vdst = ((g * 2 + (qp >> 1)) << 4) | ((qp & 1) << 3);
+    }
+    u128 rk[KCPT], rv[4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < KCPT; ++i) {
+            if (KCH % NT == 0 || tid + NT * i < KCH) {
+                int row = kt * KT + kc_row[i];
+                if (ragged && row >= seq) row = seq - 1;
+                rk[i] = *(const u128*)(kbase + (unsigned)(row * ld + kc_col[i] * 8));
+            }
+        }
+        if (vm_active) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int row = kt * KT + vm_kq * 4 + j;
+                if (ragged && row >= seq) row = seq - 1;
+                rv[j] = *(const u128*)(vbase + (unsigned)(row * ld + vm_dc * 8));
+            }
+        }
+    };
+    auto store_tile = [&](int kt, int kbi, int vbi) {
+        (void)kt;
+        unsigned char* kl = kring + kbi * K_BYTES;
+        unsigned char* vl = vring + vbi * V_BYTES;
+#pragma unroll
+        for (int i = 0; i < KCPT; ++i)
+            if (KCH % NT == 0 || tid + NT * i < KCH) *(u128*)(kl + kc_row[i] * KSTRIDE + kc_col[i] * 16) = rk[i];
+        if (vm_active) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const unsigned a0 = rv[0][w], a1 = rv[1][w], a2 = rv[2][w], a3 = rv[3][w];
+                const int d = vm_dc * 8 + 2 * w;
+                uint2 lo, hi;
+                lo.x = (a0 & 0xffffu) | (a1 << 16); lo.y = (a2 & 0xffffu) | (a3 << 16);
+                hi.x = (a0 >> 16) | (a1 & 0xffff0000u); hi.y = (a2 >> 16) | (a3 & 0xffff0000u);
+                *(uint2*)(vl + d * 128 + (vdst ^ (vswz(d) << 4))) = lo;
+                *(uint2*)(vl + (d + 1) * 128 + (vdst ^ (vswz(d + 1) << 4))) = hi;
+            }
+        }
+    };
+
+    f32x16 oacc[DM];
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.scale_log2e;
+    const int nt = (seq + KT - 1) / KT;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: tiles 0 and 1 staged; the V^T buffer of "tile -1" zeroed (iteration 0 runs PV(-1) = 0 . 0 through it)
+    load_tile(0);
+    store_tile(0, 0, 0);
+    if (nt > 1) { load_tile(1); store_tile(1, 1, 1); }
+    for (int i = tid * 16; i < V_BYTES; i += NT * 16) *(u128*)(vring + (VBUF - 1) * V_BYTES + i) = (u128){0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    // S[t & 1] = scores of tile t, P[t & 1] = probability fragments of tile t.  The loop is unrolled over the ring period (4)
+    // so that every LDS address is a loop-invariant per-lane register plus an immediate and no register set is ever copied.
+    // The P fragments are ONE set, rewritten in place: PV(t-1) reads group g in slots 3 g .. 3 g + 2 and softmax(t) writes group g in
+    // slots 5 + 4 g .. 8 + 4 g, always later.
+    f32x16 S[2][2];
+    vec8 P[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) P[g][j] = from_f32<T>(0.f);                    // "P(-1)"
+    const unsigned kfrag = (unsigned)(lq * KSTRIDE + lh * 16);                      // K fragment: + km*32*KSTRIDE + ks*32 (immediates)
+    unsigned vfrag[DM];               // V^T fragment of (dm, 16-key group g) = vfrag[dm] ^ (g << 5): chunk (2 g + lh) ^ vswz(d)
+#pragma unroll
+    for (int dm = 0; dm < DM; ++dm) {
+        const int d = dm * 32 + lq;
+        vfrag[dm] = (unsigned)(d * 128 + ((lh ^ vswz(d)) << 4));
+    }
+    {   // S(0)
+#pragma unroll
+        for (int km = 0; km < 2; ++km)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const vec8 kf = as_vec8<T>(*(const u128*)(kring + kfrag + km * 32 * KSTRIDE + ks * 32));
+                S[0][km] = Op16<T>::mfma(kf, qf[ks], ks == 0 ? zero16 : S[0][km]);
+            }
+    }
+#ifdef BD_ATTN_PROBE
+    unsigned probe_ts = 0;
+#endif
+    // one key tile; TI = t % 4 at compile time
+#define PP_LOADF(dst, n)                                                                                         \
+    {                                                                                                             \
+        if ((n) < NPV) {                                                                                          \
+            dst = as_vec8<T>(*(const u128*)(vring + ((TI + 3) % VBUF) * V_BYTES + (vfrag[(n) % DM] ^ (unsigned)(((n) / DM) << 5)))); \
+        } else {                                                                                                  \
+            const int ks_ = ((n) - NPV) / 2, km_ = ((n) - NPV) % 2;    /* alternate the two S accumulators */      \
+            dst = as_vec8<T>(*(const u128*)(kring + ((TI + 1) % KBUF) * K_BYTES + kfrag + km_ * 32 * KSTRIDE + ks_ * 32)); \
+        }                                                                                                         \
+    }
+#define PP_MFMA(n, f)                                                                                            \
+    {                                                                                                             \
+        if ((n) < NPV) {                                                                                          \
+            oacc[(n) % DM] = Op16<T>::mfma(f, P[(n) / DM], oacc[(n) % DM]);                                       \
+        } else {                                                                                                  \
+            const int ks_ = ((n) - NPV) / 2, km_ = ((n) - NPV) % 2;                                               \
+            S[(TI + 1) & 1][km_] = Op16<T>::mfma(f, qf[ks_], ks_ == 0 ? zero16 : S[(TI + 1) & 1][km_]);          \
+        }                                                                                                         \
+    }
+#define PP_ITER(TI_)                                                                                             \
+    {                                                                                                             \
+        constexpr int TI = (TI_);                                                                                 \
+        if (t >= 4 && t < 16) AP((t - 4) * 5)                                                                     \
+        const bool stage = t + 2 < nt;                                                                            \
+        if (stage) load_tile(t + 2);                                                                              \
+        if ((t + 1) * KT > seq) {      /* tail mask of tile t (before anything reads the scores) */               \
+            _Pragma("unroll") for (int km = 0; km < 2; ++km)                                                      \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
+                    const int key = t * KT + km * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;                           \
+                    if (key >= seq) S[TI & 1][km][r] = -INFINITY;                                                 \
+                }                                                                                                 \
+        }                                                                                                         \
+        vec8 fr[4];                                                                                               \
+        float tmax = -INFINITY, psum = 0.f, mneg = 0.f, alpha = 1.f;                                              \
+        bool moved = false;                                                                                       \
+        _Pragma("unroll") for (int n = 0; n < 3; ++n) PP_LOADF(fr[n & 3], n)                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        _Pragma("unroll") for (int n = 0; n < NSLOT; ++n) {                                                       \
+            PP_MFMA(n, fr[n & 3])                                                                                 \
+            if (n + 3 < NSLOT) PP_LOADF(fr[(n + 3) & 3], n + 3)                                                   \
+            if (n < 4) {                        /* row max, 8 scores per slot */                                  \
+                _Pragma("unroll") for (int e = n * 8; e < n * 8 + 8; ++e) tmax = fmaxf(tmax, S[TI & 1][e >> 4][e & 15]); \
+                asm volatile("" : "+v"(tmax));   /* pin: IR passes sink side-effect-free code past sched_barrier */  \
+            } else if (n == 4) {                /* the other half of the query's keys lives in lane ^ 32 */       \
+                float other;      /* two DISTINCT registers: the builtin given one value twice swaps nothing */    \
+                asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(tmax), "=&v"(other)); \
+                tmax = fmaxf(tmax, other);                                                                        \
+                const float m_new = fmaxf(m_run, tmax);                                                           \
+                moved = !__all(m_new == m_run);                                                                   \
+                alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);   /* 1 where the max did not move */        \
+                m_run = m_new;                                                                                    \
+                mneg = -m_new * sc;                                                                               \
+            } else if (n < 21) {                /* 2 probabilities per slot: exp2, row sum, conversion */         \
+                _Pragma("unroll") for (int e = (n - 5) * 2; e < (n - 5) * 2 + 2; ++e) {                           \
+                    float pv = __builtin_amdgcn_exp2f(fmaf(S[TI & 1][e >> 4][e & 15], sc, mneg));                \
+                    asm volatile("" : "+v"(pv));                                                                  \
+                    psum += pv;                                                                                   \
+                    P[e >> 3][e & 7] = from_f32<T>(pv);                                                           \
+                }                                                                                                 \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+        if (moved) {                    /* O and l follow the new max (PV(t-1) was added under the old one) */    \
+            _Pragma("unroll") for (int i = 0; i < DM; ++i)                                                        \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;                               \
+            l_run *= alpha;                                                                                       \
+        }                                                                                                         \
+        l_run += psum;                                                                                            \
+        if (t >= 4 && t < 16) AP((t - 4) * 5 + 1)                                                                 \
+        if (stage) store_tile(t + 2, (TI + 2) % KBUF, (TI + 2) % VBUF);                                           \
+        if (t >= 4 && t < 16) AP((t - 4) * 5 + 2)                                                                 \
+        __syncthreads();                                                                                          \
+        if (t >= 4 && t < 16) AP((t - 4) * 5 + 3)                                                                 \
+        ++t;                                                                                                      \
+    }
+    int t = 0;
+    while (t + 4 <= nt) { PP_ITER(0) PP_ITER(1) PP_ITER(2) PP_ITER(3) }
+    const int rem = nt - t;                 // t % 4 == 0 here
+    if (rem > 0) PP_ITER(0)
+    if (rem > 1) PP_ITER(1)
+    if (rem > 2) PP_ITER(2)
+#undef PP_ITER
+#undef PP_LOADF
+#undef PP_MFMA
+#ifdef BD_ATTN_PROBE
+    if (bd_attn_probe_buf && blockIdx.x < 512) bd_attn_probe_buf[((size_t)blockIdx.x * 8 + wid) * 64 + lane] = probe_ts;
+#endif
+    {   // PV(nt-1): V^T buffer (nt-1) % 4 -- a run-time index here, once per kernel
+        const unsigned char* vcur = vring + ((nt - 1) % VBUF) * V_BYTES;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int dm = 0; dm < DM; ++dm) {
+                const vec8 vf = as_vec8<T>(*(const u128*)(vcur + (vfrag[dm] ^ (unsigned)(g << 5))));
+                oacc[dm] = Op16<T>::mfma(vf, P[g], oacc[dm]);
+            }
+    }
+
+    // ---- finalise: O[q][d] = O^T / l ; lane (q, h) owns d = dm*32 + 8*(r>>2) + 4*h + (r&3)
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + lq;
+    if (q < q_len) {
+        const int64_t e0 = ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
+#pragma unroll
+        for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                float v4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v4[j] = oacc[dm][rq * 4 + j] * inv;
+                const int64_t e = e0 + dm * 32 + 8 * rq + 4 * lh;
+                if constexpr (OUTMODE == 2) {
+                    store_cvt<fp8e4, 4>((fp8e4*)p.out + e, v4);
+                } else if constexpr (OUTMODE == 3) {
+                    f16c8_store4((f16c8*)p.out, p.out_plane, e, v4);
+                } else if constexpr (OUTMODE == 1) {
+                    float hi4[4], lo4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { hi4[j] = (float)(__bf16)v4[j]; lo4[j] = v4[j] - hi4[j]; }
+                    store_cvt<__bf16, 4>((__bf16*)p.out + e, hi4);
+                    store_cvt<__bf16, 4>((__bf16*)p.out + p.out_plane + e, lo4);
+                } else {
+                    store_cvt<T, 4>((T*)p.out + e, v4);
+                }
+            }
+    }
+}
+
+template <class T, int HD, int OUTMODE> int launch_pp(const AttnArgs& a, hipStream_t s) {
+    const int nqb = (a.q_len + 255) / 256;
+    const int slot = bd_trace_open(s, 1, a.batch * a.heads, a.seq, HD);
+    hipLaunchKernelGGL((attn_kernel_pp<T, HD, OUTMODE>), dim3(nqb * a.heads * a.batch), dim3(512), 0, s, a);
+    bd_trace_close(s, slot);
+    BD_CHECK_LAUNCH();
+    return BD_OK;
+}
+
 template <class T, int NS, int HD, int NW, int OUTMODE = 0> int launch(const AttnArgs& a, hipStream_t s) {
     const int nqb = (a.q_len + NW * 32 - 1) / (NW * 32);
     const int slot = bd_trace_open(s, 1, a.batch * a.heads, a.seq, HD);
@@ -350,6 +666,10 @@ template <class T, int NS, int OUTMODE = 0> int dispatch(const AttnArgs& a, int 
     // 3 waves (96-query blocks) when that tiles the sequence with less waste (DINOv2: 261 -> 3 x 96)
     const int waste4 = ((a.q_len + 127) / 128) * 128 - a.q_len, waste3 = ((a.q_len + 95) / 96) * 96 - a.q_len;
     const bool use3 = waste3 < waste4;
+    if constexpr (NS == 1) {
+        // ping-pong kernel where its 256-query blocks tile the query range without waste (BETR: 1536 = 6 x 256; last block: 256)
+        if (head_dim == 96 && a.q_len % 256 == 0) return launch_pp<T, 96, OUTMODE>(a, s);
+    }
     if (head_dim == 96) return use3 ? launch<T, NS, 96, 3, OUTMODE>(a, s) : launch<T, NS, 96, 4, OUTMODE>(a, s);
     if (head_dim == 64) return use3 ? launch<T, NS, 64, 3, OUTMODE>(a, s) : launch<T, NS, 64, 4, OUTMODE>(a, s);
     return BD_ERR_SHAPE;
