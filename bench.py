@@ -237,6 +237,8 @@ class ModeRun:
         self.kp_all = torch.empty((self.B, 8, 2), dtype=torch.float32, device=device)
         self.graphed = None
         self.cached = None
+        self.lanes = []              # batches in flight: one captured graph + stream each (lane 0 = self.graphed on its own stream)
+        self.k = 0
         if args.cache_refs:
             from boxdreamer_amd.cache import RefFeatureCache
             cache = RefFeatureCache(self.enc)
@@ -249,6 +251,19 @@ class ModeRun:
             from boxdreamer_amd.graph import GraphedPath
             self.graphed = GraphedPath(self.enc, self.dec, self.B, self.T, 224, torch.bfloat16, device)
             self.graphed.set_inputs(images, bbox)
+            # Two batches in flight (default): a second, independent copy of the path (own weights, workspace and captured graph)
+            # replayed on a second stream, batch k on lane k % 2.  The kernels of one batch fill the idle CUs of the other's
+            # tail rounds (DINOv2's N = 768 GEMMs run 3.06 rounds of 256 CUs, attention 13.5, ...); every batch is still
+            # computed in full and in order on its lane.  `--in-flight 1` is the single-stream step.
+            self.lanes.append({"g": self.graphed, "s": torch.cuda.Stream(device=device), "done": torch.cuda.Event(), "free": torch.cuda.Event()})
+            for _ in range(1, max(1, args.in_flight)):
+                enc2, dec2 = build_models(prec, device)
+                g2 = GraphedPath(enc2, dec2, self.B, self.T, 224, torch.bfloat16, device)
+                g2.set_inputs(images, bbox)
+                self.lanes.append({"g": g2, "s": torch.cuda.Stream(device=device), "done": torch.cuda.Event(), "free": torch.cuda.Event()})
+            main = torch.cuda.current_stream(device)
+            for ln in self.lanes:
+                ln["free"].record(main)
 
     def eager(self):
         if self.cached is not None:
@@ -261,12 +276,31 @@ class ModeRun:
         self.kp_all.copy_(kp)
         return self.kp_all
 
-    def step(self):
+    def step_single(self):
         kp = self.graphed.replay()[1] if self.graphed is not None else self.eager()
         return self.gather(kp, self.world) if self.world > 1 else kp
 
+    def step(self):
+        if len(self.lanes) <= 1:
+            return self.step_single()
+        ln = self.lanes[self.k % len(self.lanes)]
+        self.k += 1
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(ln["s"]):
+            ln["s"].wait_event(ln["free"])           # the lane's previous corners have been gathered / consumed
+            kp = ln["g"].replay()[1]
+            ln["done"].record(ln["s"])
+        if self.world > 1:                           # the one collective of the sweep stays on the main stream, in batch order
+            main.wait_event(ln["done"])
+            out = self.gather(kp, self.world)
+            ln["free"].record(main)
+            return out
+        ln["free"].record(ln["s"])
+        return kp
+
     def close(self):
         self.graphed = None          # lifts the modules' freeze (graph.py) and releases the capture pool
+        self.lanes = []
 
 
 def trace_launches(lib, _lib, run_once, n_runs: int, cap: int = 8192):
@@ -326,7 +360,11 @@ def measure_mode(prec, args, device, world, rank, dist, images, bbox, mask, with
     dt, per_rank, out = timed_steps(run.step, args.steps, args.warmup, world, dist, torch.cuda.synchronize, device)
     B, T = run.B, run.T
     assert out.shape[0] == B * world and torch.isfinite(out).all()
-    res = {"dt": dt, "per_rank": per_rank, "out": out, "run": run}
+    res = {"dt": dt, "per_rank": per_rank, "out": out, "run": run, "in_flight": max(1, len(run.lanes))}
+    if len(run.lanes) > 1:        # the same K steps one batch at a time on one stream, for the record
+        dt1, _, out1 = timed_steps(run.step_single, args.steps, 1, world, dist, torch.cuda.synchronize, device)
+        assert torch.equal(out1, out)
+        res["single_stream"] = {"value": round(B * world * args.steps / dt1, 2), "ms_per_step": round(dt1 / args.steps * 1e3, 3)}
     if rank == 0:
         TRACE = 3
         recs, _ = trace_launches(lib, _lib, run.eager, TRACE)
@@ -426,7 +464,7 @@ def pnp_inclusive(run: "ModeRun", one, steps: int, step_ms: float) -> dict:
     def solve(kp_dev):
         return solve_poses_host(kp_dev.float().cpu().numpy(), b3, Kq)
 
-    kp = run.step()[:B]
+    kp = run.step_single()[:B]
     tp = []
     for _ in range(3):
         t1 = time.perf_counter()
@@ -436,7 +474,7 @@ def pnp_inclusive(run: "ModeRun", one, steps: int, step_ms: float) -> dict:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        solve(run.step()[:B])
+        solve(run.step_single()[:B])
     ser = (time.perf_counter() - t0) / steps
     # overlapped: corners of batch i are copied to a pinned host buffer (async, event), the solver thread waits for the
     # event and solves while the main thread has already enqueued batch i+1
@@ -447,7 +485,7 @@ def pnp_inclusive(run: "ModeRun", one, steps: int, step_ms: float) -> dict:
     t0 = time.perf_counter()
     for i in range(steps):
         b = i & 1
-        out = run.step()[:B]
+        out = run.step_single()[:B]
         host_kp[b].copy_(out, non_blocking=True)
         evs[b].record()
         if worker[0] is not None:
@@ -483,6 +521,9 @@ def main():
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="replay the step from a captured HIP graph (default)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel from the host each step")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight in graph mode: 2 = two captured copies of the path replayed alternately on two streams "
+                         "(default), 1 = one batch at a time")
     ap.add_argument("--no-strict", action="store_true", help="skip the second (strict-mode) timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -531,11 +572,16 @@ def main():
                                        f"per rank), DINOv2 ViT-B/14-reg + BETR-12 + top-20 decode, random-init weights, "
                                        f"inputs bf16 in HBM",
                            "global_batch": B * world, "views": T, "parallelism": f"dp{world}",
-                           "hip_graph": main_res["run"].graphed is not None, "gflop_per_pose": round(fpp / 1e9, 2)},
+                           "hip_graph": main_res["run"].graphed is not None, "gflop_per_pose": round(fpp / 1e9, 2),
+                           "batches_in_flight": main_res["in_flight"],
+                           "batches_in_flight_note": "2 = two captured copies of the whole path replayed alternately on two streams (each "
+                                                     "batch computed in full on its lane; `single_stream` is the same K steps one at a time)"},
                 "poses_per_s_per_gpu": round(value / world, 2),
                 "value_is": "whole-job aggregate over n_gpus (bench contract); the per-GPU figure of the metric is poses_per_s_per_gpu",
                 "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in main_res["per_rank"]],
                 "roofline": main_res["roofline"]}
+        if "single_stream" in main_res:
+            line["single_stream"] = main_res["single_stream"]
     if world > 1:
         lat = gather_latency_ms(main_res["run"].kp_all, world, dist, main_res["run"].gather)
         if rank == 0:
@@ -559,15 +605,16 @@ def main():
         if rank == 0:
             srun = sres["run"]
             line["strict"] = {"mode": STRICT_PREC,
-                              "what": "split-bf16 Linears (hi*hi + hi*lo + lo*hi, fp32 accumulate) except BETR's QKV (one f16 pass: the "
-                                      "only Linear type whose f16 error, 5e-4, fits the bar); f16 attention where q/k are "
-                                      "RMS-normalised, split-bf16 attention in DINOv2.  Alternatives measured on the same box "
-                                      "(profiles/r2_strict_modes.md): bf16x3 (all Linears split, 1.1e-4) ~5 % slower, f16c8 (f16 + "
-                                      "e4m3 correction pass, 1.9e-4) equal to bf16x3",
+                              "what": "Linears: one f16 MFMA pass + one e4m3 correction pass over a doubled K (BD_PREC_F16C8) except BETR's "
+                                      "QKV (one f16 pass: the only Linear type whose f16 error, 5e-4, fits the bar); f16 attention "
+                                      "where q/k are RMS-normalised, split-bf16 attention in DINOv2.  Alternatives measured on the "
+                                      "same box (profiles/r2_strict_modes.md): f16c8 2.3e-4 -4 %, bf16x3_qkv16 5.2e-4 -15 %, bf16x3 1.1e-4 -19 %",
                               "value": round(sres["value"], 2), "unit": "poses/s",
                               "poses_per_s_per_gpu": round(sres["value"] / world, 2),
                               "ms_per_step": round(sres["ms_per_step"], 3), "dtype": DTYPE_LABEL[STRICT_PREC],
-                              "roofline": sres["roofline"]}
+                              "roofline": sres["roofline"], "batches_in_flight": sres["in_flight"]}
+            if "single_stream" in sres:
+                line["strict"]["single_stream"] = sres["single_stream"]
             if not args.no_parity:
                 line["strict"]["parity"] = parity_probe(STRICT_PREC, T, device, (srun.enc, srun.dec))
         sres["run"].close()
