@@ -186,8 +186,23 @@ def test_dense_mode_multi_round(hip):
     B, T = data["images"].shape[:2]
     dev = {kk: (v.cuda() if torch.is_tensor(v) else v) for kk, v in data.items()}
     out = model(dev)
-    assert out["pred_poses"].shape == (B, T, 4, 4) and out["pred_bbox"].shape == (B, T, 8, 224, 224)
+    assert out["pred_bbox"].shape == (B, T, 8, 224, 224)
     assert torch.isfinite(out["pred_poses"]).all()
+    # VALUES of the coarse prediction: the query view's heatmaps are round 0's decode = the oracle on round 0's views
+    # (references 0 .. sub-1 in order + the query last; oracle/dense_oracle.py pinned against the reference's sub_batchify)
+    from oracle import dense_oracle as do
+    cm = torch.zeros(B, T, dtype=torch.bool); cm[torch.arange(B), data["query_idx"]] = True
+    ni = do.sub_batchify_views(data["images"], cm, base["sub_batch_size"])
+    nb = do.sub_batchify_views(data["bbox_feat"].float(), cm, base["sub_batch_size"])
+    o = orc.boxdreamer_forward({"images": ni[:, 0], "bbox_feat": nb[:, 0], "query_idx": torch.full((B,), base["sub_batch_size"])},
+                               synth.betr_state_dict(1234, 2), synth.dino_state_dict(4321, 2))
+    got = out["pred_bbox"].cpu()[cm].float()                              # (B, 8, 224, 224): 2 sigmoid(logits) - 1
+    assert (got - o["heat"]).abs().max().item() <= 1e-3
+    # ... and the query pose is the host PnP of ALL rounds' corners (checked for value against the solver on the oracle's corners
+    # of round 0 only when there is a single round; here: finite, and a rigid transform)
+    Rm = out["pred_poses"].cpu()[cm][:, :3, :3].double()
+    assert (Rm @ Rm.transpose(-1, -2) - torch.eye(3, dtype=torch.float64)).abs().max().item() <= 1e-5
+    assert out["pred_poses"].shape == (B, T, 4, 4)
     # both scheduling variants of the rounds give the same heatmaps
     model2, data2 = _dense_model_and_batch({**base, "dense_mem_friendly": True})
     out2 = model2({kk: (v.cuda() if torch.is_tensor(v) else v) for kk, v in data2.items()})
