@@ -1356,7 +1356,10 @@ inline bool uses_pc192(const bd_gemm_args& a, int ns, int esz, int cus) {
                                      // depend on whether its batch filled the CUs (bit-exact batch independence is tested)
     if (a.N % 192 || a.M < 1024) return false;
     const int64_t t192 = (int64_t)((a.M + 255) / 256) * (a.N / 192);
-    return (double)t192 / (double)(((t192 + cus - 1) / cus) * cus) >= 0.88;       // last-round occupancy of the CUs
+    // (0.75: DINOv2's N = 768 GEMMs at M = 50112 are 784 tiles = 3.06 rounds, fill 0.77.  One batch at a time the persistent kernel
+    // is then +1.8 % on the step against the one-tile kernels' hybrid split; with two batches in flight -- the other batch's kernels
+    // run on the CUs this kernel's tail leaves idle -- +5 %: 1221 -> 1282 poses/s same box.)
+    return (double)t192 / (double)(((t192 + cus - 1) / cus) * cus) >= 0.75;       // last-round occupancy of the CUs
 }
 // a fused q/k RMSNorm needs: 16-bit output of a plain Linear, N = 3 x heads x 96, row-identity output map
 inline bool rms_geometry_ok(const bd_gemm_args& a) {
