@@ -114,14 +114,15 @@ enum { OUT_OPERAND = 0, OUT_F32 = 1, OUT_F16 = 2, OUT_BF16 = 3, OUT_BF16X2 = 4 }
 // Accumulator start values and where the epilogue terms enter -- ONE convention for every kernel, so that a row's result
 // does not depend on the tile shape that computed it (the property tests compare a sample run alone with the same sample
 // inside a batch, bit for bit):
-//   * a plain fp32 residual (identity row map, no per-channel weight scale) is loaded INTO the accumulators before the first
+//   * a plain fp32 residual (identity row map) is loaded INTO the accumulators (divided by the column's weight scale in the e4m3
+//     class, whose epilogue multiplies by it again) before the first
 //     MFMA (C fragment layout: 2 rows x 128 contiguous bytes per load instruction), so no epilogue reads global memory for
 //     it -- on gfx9 loads and stores share the in-order vmcnt, and an epilogue that loads after it has stored waits for its
 //     own stores to be acknowledged (measured: 13.8k cycles per 256x192 tile for a LONE workgroup, profiles/r2_gemm_epilogue.md);
 //   * everything else starts at zero;
 //   * scale * acc + bias is applied when the accumulators leave the registers (per-column values, one register per 32-column
 //     tile), then the activation, the table rows and a remapped / scaled-mode residual.
-__device__ __forceinline__ bool resid_in_acc(const bd_gemm_args& p) { return p.resid && p.rpg_in <= 0 && !p.wscale; }
+__device__ __forceinline__ bool resid_in_acc(const bd_gemm_args& p) { return p.resid && p.rpg_in <= 0; }
 
 template <int MI, int NI>
 __device__ __forceinline__ void acc_init(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wm0, int wn0, int lane) {
@@ -139,7 +140,7 @@ __device__ __forceinline__ void acc_init(const bd_gemm_args& p, f32x16 (&acc)[MI
                 for (int j = 0; j < NI; ++j) {
                     int gc = wn0 + j * 32 + lrow;
                     gc = gc < p.N ? gc : p.N - 1;
-                    acc[i][j][r] = rp[gc];
+                    acc[i][j][r] = p.wscale ? rp[gc] / p.wscale[gc] : rp[gc];
                 }
             }
     } else {
@@ -575,8 +576,8 @@ __device__ __forceinline__ float quad_sum(float x) {
 //   wcol: first column of the wave tile inside the workgroup tile;  (wm0, wn0): its global origin
 //   next: the wave tile origin of this workgroup's next tile (EP 3 pre-loads its residual), has_next = there is one
 template <class T, int NS, int EP, int OUTK, bool GELU>
-__device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)[2][3], float* sc, const float* colp, const float* rmsw,
-                                            int wcol, int wm0, int wn0, int lane, bool has_next, int nwm0, int nwn0) {
+__device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)[2][3], float* sc, const float* colp, const float* colp_next,
+                                            const float* rmsw, int wcol, int wm0, int wn0, int lane, bool has_next, int nwm0, int nwn0) {
     constexpr int COLS = 96;
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int M = p.M;
@@ -600,6 +601,13 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
         // fp32 rows: 8 lanes x 16 bytes = one 128-byte line per row and 32-column block; 8 rows per pass, 2 passes per chunk
         const int c4 = lane & 7, rsub = lane >> 3;
         const bool pre = has_next && p.resid != nullptr;
+        float rsn[3] = {1.f, 1.f, 1.f};       // e4m3 class: the NEXT tile's column scales (its side-buffer slot landed with its first slab)
+        if constexpr (sizeof(T) == 1) {
+            if (pre && p.wscale) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) rsn[j] = colp_next[256 + wcol + j * 32 + lrow];
+            }
+        }
 #pragma unroll
         for (int ih = 0; ih < 4; ++ih) {
             const int i = ih >> 1, hc = ih & 1;
@@ -612,7 +620,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
                     gr = gr < M ? gr : M - 1;
                     const float* rp = p.resid + (int64_t)gr * p.ldr + nwn0 + lrow;
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[i][j][r] = rp[j * 32];
+                    for (int j = 0; j < 3; ++j) acc[i][j][r] = (sizeof(T) == 1 && p.wscale) ? rp[j * 32] / rsn[j] : rp[j * 32];
                 }
             } else {
 #pragma unroll
@@ -994,7 +1002,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 int nm0 = 0, nn0 = 0;
                 if (has_next) tile_origin(t + stride, nm0, nn0);
                 pc_epilogue<T, NS, EP, OUTK, GELU>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
-                                                  (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
+                                                  (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
                                                   lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
             }
         }
@@ -1264,7 +1272,7 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
             int nm0 = 0, nn0 = 0;
             if (has_next) tile_origin(t + stride, nm0, nn0);
             pc_epilogue<f16c8, 2, EP, OUTK, GELU>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
-                                                 (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
+                                                 (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
                                                  lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
         }
         BD_PROBE_IF(g == nk, 62)
@@ -1282,7 +1290,8 @@ template <class T, int NS> int pc_epilogue_kind(const bd_gemm_args& a, int& outk
     if (a.addtab || a.rpg_in > 0) return 0;
     if (a.bias && ((uintptr_t)a.bias & 15)) return 0;
     if (a.out_f32 == OUT_F32) {
-        if (a.wscale || gelu || a.rms_wq) return 0;
+        if (gelu || a.rms_wq) return 0;
+        if (a.wscale && (sizeof(T) != 1 || ((uintptr_t)a.wscale & 15))) return 0;
         return 3;
     }
     if (a.resid) return 0;
