@@ -590,7 +590,7 @@ def main():
     if rank == 0:
         run = main_res["run"]
         if not args.no_parity:
-            line["parity"] = parity_probe(prec, T, device, (run.enc, run.dec))
+            line["parity"] = parity_probe(prec, T, device, (run.enc, run.dec) if B >= 2 else None)   # a captured B = 1 path is frozen
         if world == 1 and not args.no_h2d and not args.cache_refs:
             line["h2d_inclusive"] = h2d_inclusive(run, max(4, args.steps))
         if world == 1 and not args.no_pnp:
@@ -616,7 +616,7 @@ def main():
             if "single_stream" in sres:
                 line["strict"]["single_stream"] = sres["single_stream"]
             if not args.no_parity:
-                line["strict"]["parity"] = parity_probe(STRICT_PREC, T, device, (srun.enc, srun.dec))
+                line["strict"]["parity"] = parity_probe(STRICT_PREC, T, device, (srun.enc, srun.dec) if B >= 2 else None)
         sres["run"].close()
         del sres
     if rank == 0:
