@@ -257,9 +257,13 @@ class ModeRun:
             # computed in full and in order on its lane.  `--in-flight 1` is the single-stream step.
             self.lanes.append({"g": self.graphed, "s": torch.cuda.Stream(device=device), "done": torch.cuda.Event(), "free": torch.cuda.Event()})
             for _ in range(1, max(1, args.in_flight)):
-                enc2, dec2 = build_models(prec, device)
-                g2 = GraphedPath(enc2, dec2, self.B, self.T, 224, torch.bfloat16, device)
-                g2.set_inputs(images, bbox)
+                try:
+                    enc2, dec2 = build_models(prec, device)
+                    g2 = GraphedPath(enc2, dec2, self.B, self.T, 224, torch.bfloat16, device)
+                    g2.set_inputs(images, bbox)
+                except (RuntimeError, MemoryError) as e:          # e.g. not enough memory for a second copy: one batch at a time
+                    print(f"bench: second in-flight lane not available ({type(e).__name__}: {e}); timing one batch at a time", file=sys.stderr)
+                    break
                 self.lanes.append({"g": g2, "s": torch.cuda.Stream(device=device), "done": torch.cuda.Event(), "free": torch.cuda.Event()})
             main = torch.cuda.current_stream(device)
             for ln in self.lanes:
