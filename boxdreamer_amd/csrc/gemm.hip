@@ -641,6 +641,55 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
                 }
             }
         }
+    } else if constexpr (EP == 1 && NS == 1 && sizeof(T) == 2 && OUTK == OUT_OPERAND) {
+        // Plain bf16 / f16 result (optional GELU): rounded to 16 bits BEFORE the LDS round trip, two adjacent rows per dword
+        // (registers r, r + 1 of a C fragment are rows 2 k, 2 k + 1 of the same column), so the transposition moves half the bytes:
+        // per 32-row block 24 ds_write_b32 + 6 ds_read_b128 per lane instead of 48 + 12.  A lane then owns 8 consecutive columns of
+        // one row PAIR, splits the dwords with two byte permutes each and stores two 16-byte row pieces; 12 lanes cover a row
+        // (192-byte runs).  Same values, same roundings as the fp32 staging (the conversion is the separate step of store_cvt).
+        unsigned* sp = (unsigned*)sc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) {
+                    float v2[2] = {acc[i][j][2 * pp] + bj[j], acc[i][j][2 * pp + 1] + bj[j]};
+                    if constexpr (GELU) gelu_n<GeluKind<T, NS>::value, 2>(v2);
+                    float x0 = v2[0], x1 = v2[1];
+                    asm("" : "+v"(x0));          // separate fp32 -> 16-bit rounding (store_cvt's rule)
+                    asm("" : "+v"(x1));
+                    typedef T pair_t __attribute__((ext_vector_type(2)));
+                    const pair_t pr = {(T)x0, (T)x1};
+                    const int prow = (pp & 1) + 4 * (pp >> 1) + 2 * lhalf;
+                    sp[prow * COLS + j * 32 + lrow] = __builtin_bit_cast(unsigned, pr);
+                }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int t = u * 64 + lane, prow = t / 12, cg = t % 12;
+                const u128 d0 = *(const u128*)(sp + prow * COLS + cg * 8), d1 = *(const u128*)(sp + prow * COLS + cg * 8 + 4);
+                u128 ra, rb;          // even row: low halves, odd row: high halves
+                ra[0] = __builtin_amdgcn_perm(d0[1], d0[0], 0x05040100u); ra[1] = __builtin_amdgcn_perm(d0[3], d0[2], 0x05040100u);
+                ra[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x05040100u); ra[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x05040100u);
+                rb[0] = __builtin_amdgcn_perm(d0[1], d0[0], 0x07060302u); rb[1] = __builtin_amdgcn_perm(d0[3], d0[2], 0x07060302u);
+                rb[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x07060302u); rb[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x07060302u);
+                const int gr = wm0 + i * 32 + 2 * prow;
+                T* op = (T*)p.out + (int64_t)gr * p.ldo + wn0 + cg * 8;
+                if (!BD_EXP_NOSTORE) {
+#if defined(BD_STORE_NT) && BD_STORE_NT
+                    if (gr < M) __builtin_nontemporal_store(ra, (u128*)op);
+                    if (gr + 1 < M) __builtin_nontemporal_store(rb, (u128*)(op + p.ldo));
+#else
+                    if (gr < M) *(u128*)op = ra;
+                    if (gr + 1 < M) *(u128*)(op + p.ldo) = rb;
+#endif
+                }
+            }
+        }
     } else {
         // 16-bit rows: 4 lanes x 16 bytes per row and 32-column block, 16 rows per pass
         const int c8 = lane & 3, rsub = lane >> 2;
