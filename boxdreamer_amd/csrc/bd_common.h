@@ -128,10 +128,18 @@ __device__ __forceinline__ float load_any(const void* p, size_t i, int dtype) {
     return (float)((const _Float16*)p)[i];
 }
 
+// Wave-wide sum, result in every lane.  On the VALU: four DPP butterfly steps leave every lane of a 16-lane row with its row's sum
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), four v_readlane + three adds combine the rows.  (__shfl_xor is
+// ds_bpermute_b32 + lgkmcnt(0) per step: six dependent LDS round trips per reduction, twelve per LayerNorm row.)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // Exact-erf GELU  0.5 x (1 + erf(x / sqrt2))  evaluated in erfc form so the negative tail has no cancellation:
