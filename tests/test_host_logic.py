@@ -262,8 +262,14 @@ def test_precision_ids():
     for name in ("bf16x3", "bf16x3_attn_x3", "bf16x3_attn_f16"):
         assert _lib.planes(name) == 2 and _lib.operand_prec(name) == _lib.PREC_BF16X3 and _lib.op_dtype(name) == torch.bfloat16
     assert _lib.operand_prec("fp8") == _lib.PREC_FP8 and _lib.planes("fp8") == 1
+    # the strict family of round 2: f16 + e4m3-correction operand class and its whole-path variant with BETR's single-pass qkv
+    assert _lib.prec_id("f16c8") == 8 and _lib.prec_id("bf16x3_qkv16") == 11 and _lib.prec_id("f16c8_qkv16") == 12
+    for name in ("f16c8", "f16c8_qkv16"):
+        assert _lib.planes(name) == 2 and _lib.operand_prec(name) == _lib.PREC_F16C8 and _lib.op_dtype(name) == torch.float16
+    assert _lib.operand_prec("bf16x3_qkv16") == _lib.PREC_BF16X3
     hdr = open(os.path.join(ROOT, "include", "boxdreamer_hip.h")).read()
-    for name, val in (("BD_PREC_BF16X3_ATTN_X3", 6), ("BD_PREC_BF16X3_ATTN_F16", 7), ("BD_ABI_VERSION", 3)):
+    for name, val in (("BD_PREC_BF16X3_ATTN_X3", 6), ("BD_PREC_BF16X3_ATTN_F16", 7), ("BD_PREC_F16C8", 8), ("BD_PREC_BF16X3_QKV16", 11),
+                      ("BD_PREC_F16C8_QKV16", 12), ("BD_ABI_VERSION", 3)):
         assert re.search(rf"#define {name} {val}\b", hdr), name
     # the library keeps no environment switches: nothing under csrc/ reads the environment
     for f in os.listdir(os.path.join(ROOT, "boxdreamer_amd", "csrc")):
