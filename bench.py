@@ -265,6 +265,10 @@ class ModeRun:
                     print(f"bench: second in-flight lane not available ({type(e).__name__}: {e}); timing one batch at a time", file=sys.stderr)
                     break
                 self.lanes.append({"g": g2, "s": torch.cuda.Stream(device=device), "done": torch.cuda.Event(), "free": torch.cuda.Event()})
+            if world > 1:           # every rank must time the same number of lanes (the single-stream leg has its own barriers)
+                n = torch.tensor([len(self.lanes)], dtype=torch.int32, device=device)
+                dist.all_reduce(n, op=dist.ReduceOp.MIN)
+                self.lanes = self.lanes[: int(n.item())]
             main = torch.cuda.current_stream(device)
             for ln in self.lanes:
                 ln["free"].record(main)
