@@ -124,6 +124,38 @@ def test_hip_graph_replay_matches_eager(hip):
         assert torch.equal(heat, ref) and torch.equal(kp, rkp) and torch.equal(idx, ridx)
 
 
+def test_two_batches_in_flight_match_one_at_a_time(hip):
+    """bench.py's default step keeps two batches in flight: two independent captured copies of the path (own modules, workspace,
+    graph) replayed alternately on two streams.  Every batch must still be computed in full: with different inputs on the two
+    lanes, interleaved replays give, bit for bit, what each lane gives alone -- overlapping kernels of the other lane (they fill each
+    other's idle CUs) must not leak into its buffers."""
+    from boxdreamer_amd.graph import GraphedPath
+    B, T = 2, 3
+    lanes = []
+    for seed in (21, 22):
+        model = BoxDreamer(_config("bf16"))
+        model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
+        model = model.cuda().eval()
+        g = GraphedPath(model.rgb_encoder, model.decoder, B, T, 224, torch.float32, "cuda")
+        data = synth.make_batch(seed=seed, B=B, T=T)
+        g.set_inputs(data["images"].cuda(), data["bbox_feat"].cuda(), torch.tensor([T - 1, 0]))
+        lanes.append((g, torch.cuda.Stream()))
+    torch.cuda.synchronize()
+    alone = []
+    for g, _ in lanes:                                   # one at a time, on the current stream
+        heat, kp, _, _ = g.replay()
+        torch.cuda.synchronize()
+        alone.append((heat.clone(), kp.clone()))
+    assert not torch.equal(alone[0][0], alone[1][0])      # the lanes really hold different batches
+    for _ in range(3):                                   # interleaved, nothing between the two enqueues
+        for g, s in lanes:
+            with torch.cuda.stream(s):
+                g.replay()
+        torch.cuda.synchronize()
+        for (g, _), (heat0, kp0) in zip(lanes, alone):
+            assert torch.equal(g.out[0], heat0) and torch.equal(g.out[1], kp0)
+
+
 def _dense_model_and_batch(dense_cfg, B=2, T=7, seed=13):
     cfg = _config("bf16x3")
     cfg["modules"]["dense_cfg"] = dense_cfg
