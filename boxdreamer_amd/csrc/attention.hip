@@ -371,8 +371,6 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
     constexpr int K_BYTES = KT * KSTRIDE;
     constexpr int V_BYTES = HD * 128;
     constexpr int KBUF = 2, VBUF = 4;
-    constexpr int KCH = KT * DCH;
-    constexpr int KCPT = (KCH + NT - 1) / NT;
     constexpr int VMT = (KT / 4) * DCH;
     static_assert(VMT <= NT, "one V micro-tile per thread");
     constexpr int QB = 256;
@@ -380,7 +378,13 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
     constexpr int KS = HD / 16;
     constexpr int NPV = 4 * DM, NS_ = 2 * KS, NSLOT = NPV + NS_;
     static_assert(NSLOT >= 22, "softmax schedule below needs 22 slots");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[KBUF * K_BYTES + VBUF * V_BYTES];
+    // output staging (plain 16-bit and F16C8 results): one row image per query, [hi plane | lo8 plane], 16 bytes of padding
+    constexpr bool OUT_VIA_LDS = (OUTMODE == 0 || OUTMODE == 3);
+    constexpr int OROW = (OUTMODE == 3) ? HD * 3 : HD * 2;
+    constexpr int OSTRIDE = OROW + 16;
+    constexpr int RING_BYTES = KBUF * K_BYTES + VBUF * V_BYTES;
+    constexpr int LDS_BYTES = (OUT_VIA_LDS && 8 * 32 * OSTRIDE > RING_BYTES) ? 8 * 32 * OSTRIDE : RING_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* const vring = lds;
     unsigned char* const kring = lds + VBUF * V_BYTES;
 
@@ -413,13 +417,11 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
     for (int ks = 0; ks < KS; ++ks) qf[ks] = as_vec8<T>(*(const u128*)(base + (unsigned)(qrow * ld + ks * 16 + lh * 8)));
 
     // ---- staging coordinates
-    int kc_row[KCPT], kc_col[KCPT];
-#pragma unroll
-    for (int i = 0; i < KCPT; ++i) {
-        const int c = tid + NT * i;
-        kc_row[i] = c / DCH;
-        kc_col[i] = c % DCH;
-    }
+    // K tile: 8 threads per key row; thread (row, j) moves 16-byte pieces j and j + 8 (< DCH) of the row, so that the second piece's
+    // global and LDS addresses are the first one's plus an immediate (no second set of address registers: the loop's budget is full)
+    static_assert(KT * 8 == NT && DCH > 8 && DCH <= 16, "K staging: 8 threads per key row, two pieces each");
+    const int kc_row = tid >> 3, kc_col = tid & 7;
+    const bool kc_two = kc_col < DCH - 8;
     const int vm_kq = tid / DCH, vm_dc = tid % DCH;
     const bool vm_active = tid < VMT;
     const bool ragged = (seq % KT) != 0;
@@ -429,15 +431,14 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
         const int qp = (qi == 1) ? 2 : (qi == 2 ? 1 : qi);
         vdst = ((g * 2 + (qp >> 1)) << 4) | ((qp & 1) << 3);
     }
-    u128 rk[KCPT], rv[4];
+    u128 rk[2], rv[4];
     auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < KCPT; ++i) {
-            if (KCH % NT == 0 || tid + NT * i < KCH) {
-                int row = kt * KT + kc_row[i];
-                if (ragged && row >= seq) row = seq - 1;
-                rk[i] = *(const u128*)(kbase + (unsigned)(row * ld + kc_col[i] * 8));
-            }
+        {
+            int row = kt * KT + kc_row;
+            if (ragged && row >= seq) row = seq - 1;
+            const T* src = kbase + (unsigned)(row * ld + kc_col * 8);
+            rk[0] = *(const u128*)src;
+            if (kc_two) rk[1] = *(const u128*)(src + 64);
         }
         if (vm_active) {
 #pragma unroll
@@ -452,9 +453,8 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
         (void)kt;
         unsigned char* kl = kring + kbi * K_BYTES;
         unsigned char* vl = vring + vbi * V_BYTES;
-#pragma unroll
-        for (int i = 0; i < KCPT; ++i)
-            if (KCH % NT == 0 || tid + NT * i < KCH) *(u128*)(kl + kc_row[i] * KSTRIDE + kc_col[i] * 16) = rk[i];
+        *(u128*)(kl + kc_row * KSTRIDE + kc_col * 16) = rk[0];
+        if (kc_two) *(u128*)(kl + kc_row * KSTRIDE + kc_col * 16 + 128) = rk[1];
         if (vm_active) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -616,6 +616,48 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
     // ---- finalise: O[q][d] = O^T / l ; lane (q, h) owns d = dm*32 + 8*(r>>2) + 4*h + (r&3)
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
+    if constexpr (OUT_VIA_LDS) {
+        // The lanes hold O^T (a query per lane, 4 consecutive d per register quad): written out directly that is 32 rows x 16
+        // bytes per store instruction, ~10k cycles of a workgroup's ~100k (profiles/r2_attention.md).  Instead every wave lays its
+        // 32 query rows out in LDS (the rings are dead after the barrier) and stores whole 16-byte pieces of full rows.
+        __syncthreads();
+        // the lane id is re-derived HERE from an opaque instruction: nothing of this block's addressing can then be hoisted above
+        // the key loop, whose register budget is full (hoisted, it put a spill reload = a vector-memory load into every iteration)
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const int lq2 = ln & 31, lh2 = ln >> 5;
+        unsigned char* const wl = lds + wid * (32 * OSTRIDE);
+        unsigned char* const rowp = wl + lq2 * OSTRIDE;
+#pragma unroll
+        for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                float v4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v4[j] = oacc[dm][rq * 4 + j] * inv;
+                const int d = dm * 32 + 8 * rq + 4 * lh2;
+                if constexpr (OUTMODE == 3) f16c8_store4((f16c8*)rowp, HD, d, v4);
+                else store_cvt<T, 4>((T*)rowp + d, v4);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int CPR = OROW / 16, HIC = HD / 8;           // 16-byte pieces per row image / of its hi plane
+        static_assert((32 * CPR) % 64 == 0, "pieces per wave");
+        const int64_t row0 = (int64_t)b * q_len + q0;
+        unsigned char* const out_hi = (unsigned char*)p.out;
+        unsigned char* const out_lo = out_hi + 2 * p.out_plane;
+#pragma unroll
+        for (int k = 0; k < 32 * CPR / 64; ++k) {
+            const int c = ln + 64 * k, r = c / CPR, col = c % CPR;
+            if (q0 + r >= q_len) continue;
+            const u128 piece = *(const u128*)(wl + r * OSTRIDE + col * 16);
+            const int64_t e = (row0 + r) * (heads * HD) + head * HD;
+            if (OUTMODE == 3 && col >= HIC) *(u128*)(out_lo + e + (col - HIC) * 16) = piece;
+            else *(u128*)(out_hi + 2 * e + col * 16) = piece;
+        }
+        return;
+    }
     const int q = q0 + lq;
     if (q < q_len) {
         const int64_t e0 = ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
