@@ -1438,7 +1438,31 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
         // of three waves per SIMD with the fragment double-buffering intact) whenever they tile N exactly -- every Linear of
         // both stacks except the head (N = 2304, 3072, 768 are multiples of 192).
         if (uses_pc192(a, NS, ESZ_, kCUs)) {
-            launch_pc<T, NS, BK, 4, 2, 2, 3>(a, s, kCUs);
+            // A ragged last round (DINOv2: M = 50112 = 195.75 row tiles; N = 768 -> 784 tiles = 3 rounds + 16 tiles) costs a whole
+            // tile time on a few CUs.  Row split: the row tiles that make FULL rounds go to the persistent kernel, the remaining
+            // rows to one partial round of small one-tile workgroups (a row's arithmetic does not depend on the tile shape).
+            int64_t rows_pc = a.M;
+#ifdef BD_EXP_PC_HYBRID
+            if (!a.rms_wq && a.rpg_in <= 0 && !a.addtab) {
+                const int ncol = a.N / 192;
+                const int64_t mt = (a.M + 255) / 256, t = mt * ncol, full = t / kCUs, rem = t % kCUs;
+                if (full >= 1 && rem > 0 && rem * BD_EXP_PC_HYBRID < kCUs) {
+                    const int64_t mt_full = full * kCUs / ncol;                 // row tiles inside the full rounds
+                    if (mt_full * 256 < a.M) rows_pc = mt_full * 256;
+                }
+            }
+#endif
+            if (rows_pc < a.M) {
+                launch_pc<T, NS, BK, 4, 2, 2, 3>(row_slice<T>(a, 0, (int)rows_pc), s, kCUs);
+                const bd_gemm_args rest = row_slice<T>(a, rows_pc, (int)(a.M - rows_pc));
+#if defined(BD_EXP_PC_HYBRID_64)
+                launch_glds<T, NS, BK, 2, 2, 1, 1>(rest, s);
+#else
+                launch_glds<T, NS, BK, 2, 2, 2, 2>(rest, s);
+#endif
+            } else {
+                launch_pc<T, NS, BK, 4, 2, 2, 3>(a, s, kCUs);
+            }
             bd_trace_close(s, slot);
             BD_CHECK_LAUNCH();
             return BD_OK;
