@@ -75,6 +75,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * BUF_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#ifdef BD_ATTN_PROBE
+    unsigned probe_ts = 0;
+    AP(60)
+#endif
     const int lq = lane & 31, lh = lane >> 5;
     const int seq = p.seq, heads = p.heads;
     const int q_len = p.q_len;
@@ -181,9 +185,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
     LOAD_TILE(0)
     STORE_TILE(0)
     __syncthreads();
+    AP(61)
     for (int kt = 0; kt < nt; ++kt) {
         if (kt + 1 < nt) { LOAD_TILE(kt + 1) }
         const unsigned char* cur = lds + (NBUF == 2 ? (kt & 1) : 0) * BUF_BYTES;
+        if (kt < 7) AP(kt * 8)
 
         // ---- S^T = K . Q^T  (two 32-key M-tiles)
         f32x16 sacc[2];
@@ -206,6 +212,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
         }
         // ---- online softmax (base-2), per query = per lane pair (l, l^32).  Scores stay raw; the softmax scale
         // (times log2 e) is folded into the exponent:  p = exp2(s*sc - m*sc)  = one FMA + v_exp_f32 per score.
+        if (kt < 7) AP(kt * 8 + 1)
         float tmax = -INFINITY;
         const bool tail = (kt + 1) * KT > seq;
         if (tail) {
@@ -243,6 +250,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
                 psum += pv;
             }
         l_run += psum;
+        if (kt < 7) AP(kt * 8 + 2)
 
         // ---- O^T += V^T . P^T   (four 16-key groups)
 #pragma unroll
@@ -271,14 +279,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
             }
         }
         // the other buffer was last read in iteration kt-1, which every wave left through the barrier below
+        if (kt < 7) AP(kt * 8 + 3)
         if (NBUF == 1) __syncthreads();                      // single buffer: everyone must be done reading first
+        if (kt < 7) AP(kt * 8 + 4)
         if (kt + 1 < nt) { STORE_TILE(NBUF == 2 ? ((kt + 1) & 1) : 0) }
+        if (kt < 7) AP(kt * 8 + 5)
         __syncthreads();
+        if (kt < 7) AP(kt * 8 + 6)
     }
 #undef LOAD_TILE
 #undef STORE_TILE
 
     // ---- finalise: O[q][d] = O^T / l ; lane (q, h) owns d = dm*32 + 8*(r>>2) + 4*h + (r&3)
+    AP(62)
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int q = q0 + lq;
@@ -344,6 +357,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
                 }
         }
     }
+#ifdef BD_ATTN_PROBE
+    AP(63)
+    if (bd_attn_probe_buf && blockIdx.x < 512) bd_attn_probe_buf[((size_t)blockIdx.x * 8 + wid) * 64 + lane] = probe_ts;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
