@@ -18,6 +18,7 @@ DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 PREC_BF16, PREC_F16, PREC_BF16X3, PREC_F16_OUT_BF16X3, PREC_FP8, PREC_BF16_OUT_FP8 = 0, 1, 2, 3, 4, 5
 PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16 = 6, 7      # whole-path only: attention policy of the strict family
 PREC_F16C8 = 8                                         # f16 + e4m3 corrections (include/boxdreamer_hip.h)
+PREC_F16_OUT_F16C8, PREC_BF16X3_OUT_F16C8 = 9, 10      # bd_attention[_q] only: f16 / split-bf16 attention, F16C8 operand out
 PREC_BF16X3_QKV16 = 11                                 # whole-path only: split-bf16, BETR's QKV Linear as one f16 pass
 PREC_F16C8_QKV16 = 12                                  # whole-path only: F16C8 Linears, BETR's QKV Linear as one f16 pass
 F16C8_D = 11                                           # lo planes are scaled 2^D above their q plane

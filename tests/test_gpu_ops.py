@@ -308,6 +308,39 @@ def test_attention_mixed_output_variants(hip, variant, batch, seq, heads, hd):
     assert err < tol, (variant, err)
 
 
+@pytest.mark.parametrize("variant", ["f16_out_f16c8", "bf16x3_out_f16c8"])
+@pytest.mark.parametrize("batch,seq,heads,hd", [(2, 261, 12, 64), (1, 1536, 8, 96), (2, 512, 8, 96), (3, 70, 2, 64)])
+def test_attention_f16c8_output_variants(hip, variant, batch, seq, heads, hd):
+    """The attention variants of the strict mode the bench reports (f16c8_qkv16), against fp64 torch on the operands as stored:
+      BD_PREC_F16_OUT_F16C8     (BETR): f16 qkv (one plane) in, one f16 MFMA pass;
+      BD_PREC_BF16X3_OUT_F16C8  (DINOv2): split-bf16 qkv planes in, three MFMA passes per product;
+    both write the F16C8 operand class (f16 plane + k-permuted e4m3 correction plane) that the proj GEMM reads.  Sequences that are
+    multiples of 256 at head_dim 96 take the pipelined kernel, whose rows leave through its LDS staging block."""
+    from boxdreamer_amd import _lib
+    qkv = _rand("attq", (batch, seq, 3, heads, hd), 1.0)
+    qkv[:, :, 0] *= 1.7
+    if seq >= 200:
+        qkv[:, 150, 1] = qkv[:, 7, 0] * 3.0
+    in_prec = "fp16" if variant == "f16_out_f16c8" else "bf16x3"
+    t = hip_ops.to_operand(qkv.reshape(batch * seq, -1).cuda(), in_prec)
+    src = _q(qkv.reshape(batch * seq, -1), in_prec).reshape(batch, seq, 3, heads, hd).double()
+    q, k, v = (src[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = (((q @ k.transpose(-1, -2)) * hd ** -0.5).softmax(-1) @ v).permute(0, 2, 1, 3).float()
+    out = torch.zeros((2, batch * seq, heads * hd), dtype=torch.float16, device="cuda")
+    pid = _lib.PREC_F16_OUT_F16C8 if variant == "f16_out_f16c8" else _lib.PREC_BF16X3_OUT_F16C8
+    qkv_plane = 0 if variant == "f16_out_f16c8" else t[0].numel()
+    _lib.check(_lib.load().bd_attention(_lib.ptr(t), qkv_plane, _lib.ptr(out), out[0].numel(), batch, seq, heads, hd, hd ** -0.5,
+                                        pid, _lib.stream()), "bd_attention")
+    hi, lo, _ = hip_ops.f16c8_decode(out)
+    got = (hi + lo).cpu().reshape(batch, seq, heads, hd)
+    # f16 variant: P and V carry 11 bits; split-bf16: ~16; the stored class keeps hi + lo to ~2^-15 relative
+    eps = 2.0 ** -11 if variant == "f16_out_f16c8" else 2.0 ** -15
+    err = (got - ref).abs().max().item()
+    assert err < 6 * eps * max(1.0, ref.abs().max().item()) + 2e-5, (variant, err)
+    # the f16 plane alone must be the correctly rounded f16 image of the stored value (the GEMM's first pass reads only it)
+    assert (hi.cpu().reshape(batch, seq, heads, hd) - got).abs().max().item() <= 2.0 ** -11 * max(1.0, got.abs().max().item())
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_im2col_and_patchify(hip, prec):
     data = synth.make_batch(seed=21, B=1, T=2)
