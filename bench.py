@@ -24,6 +24,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import signal
 import statistics
 import sys
 import threading
@@ -146,15 +147,39 @@ def dist_env():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def free_port() -> int:
+    """A TCP port nobody listens on right now (two launches on one node -- the driver's N = 1, 2, 4, 8 sweep back to back, or a
+    test suite running in parallel -- must not collide on a pid-derived number)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
+def launch_plan(args, argv) -> dict:
+    """The exact command and environment `python bench.py --gpus N` turns into (also what `--dry-run` prints)."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    rest = [a for a in argv if a != "--dry-run"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__), *rest]
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),   # dmabuf IPC only on this host driver (RCCL needs it)
+           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port}
+    return {"cmd": cmd if args.gpus > 1 else [sys.executable, os.path.abspath(__file__), *rest], "env": env,
+            "ranks": args.gpus, "backend": args.backend,
+            "note": "one rank per GPU (LOCAL_RANK -> cuda:LOCAL_RANK), batch sharded across ranks, weights replicated, one "
+                    "all_gather_into_tensor of the corners per step"}
+
+
 def maybe_respawn(args) -> None:
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: become the launcher."""
+    if args.dry_run:
+        print(json.dumps(launch_plan(args, sys.argv[1:])), flush=True)
+        raise SystemExit(0)
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
-    port = str(29400 + os.getpid() % 1000)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__), *sys.argv[1:]]
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver (RCCL needs it)
-    os.execvp(cmd[0], cmd)
+    plan = launch_plan(args, sys.argv[1:])
+    os.environ.update(plan["env"])
+    os.execvp(plan["cmd"][0], plan["cmd"])
 
 
 def init_dist(args):
@@ -164,14 +189,69 @@ def init_dist(args):
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; launch with "
                          f"`python bench.py --gpus {world}` (it spawns the ranks itself) or matching torchrun arguments")
     dist = None
+    PROGRESS["line"].update(n_gpus=world)
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a finite collective timeout: a rank that died must surface as an error on the others, not as a hang
+        to = datetime.timedelta(seconds=args.dist_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=to)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=to)
+        if rank == 0:
+            signal.signal(signal.SIGTERM, _on_sigterm)      # torch.distributed.run terminates the survivors when a rank fails
     return world, rank, local_rank, dist
+
+
+# ------------------------------------------------------------------------------------------------ failure reporting
+# What rank 0 knows so far (filled stage by stage).  If any rank fails -- its own exception, a collective timeout, or the
+# launcher's SIGTERM after ANOTHER rank died -- rank 0 still prints ONE JSON line carrying n_gpus and whatever of
+# per_rank_ms_per_step / corner_allgather_ms was measured, plus `error`, and exits non-zero.
+PROGRESS = {"line": {}, "stage": "start", "printed": False}
+
+
+def emit_failure(reason: str) -> None:
+    if PROGRESS["printed"]:
+        return
+    PROGRESS["printed"] = True
+    line = dict(PROGRESS["line"])
+    line.setdefault("value", None)
+    line.update(error=reason, failed_stage=PROGRESS["stage"])
+    print(json.dumps(line), flush=True)
+
+
+def _on_sigterm(signum, frame):
+    emit_failure("terminated by the launcher: another rank failed (see its traceback above)")
+    os._exit(1)
+
+
+def interruptible_sync(device):
+    """torch.cuda.synchronize() that keeps returning to the interpreter: Python runs signal handlers only between bytecodes, and
+    rank 0 must be able to print its failure line when the launcher SIGTERMs it while a peer's death has its stream stuck in a
+    collective.  Multi-rank runs only (adds <= 0.2 ms to a timed region of hundreds of ms)."""
+    def sync():
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        while not ev.query():
+            time.sleep(0.0002)
+        torch.cuda.synchronize(device)            # (other streams: returns at once on the healthy path)
+    return sync
+
+
+def barrier(dist, device=None):
+    """dist.barrier() whose wait polls from Python (see interruptible_sync)."""
+    t = torch.zeros(1, dtype=torch.int32, device=device if device is not None else "cpu")
+    work = dist.all_reduce(t, async_op=True)
+    if device is None or torch.device(device).type != "cuda":
+        work.wait()
+        return
+    while not work.is_completed():
+        time.sleep(0.0002)
+    work.wait()
+    interruptible_sync(device)()
 
 
 def timed_steps(step, steps: int, warmup: int, world: int, dist, sync, device=None):
@@ -181,14 +261,14 @@ def timed_steps(step, steps: int, warmup: int, world: int, dist, sync, device=No
     for _ in range(warmup):
         out = step()
     if world > 1:
-        dist.barrier()
+        barrier(dist, device)
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
     sync()
     if world > 1:
-        dist.barrier()
+        barrier(dist, device)
     dt = time.perf_counter() - t0
     per_rank = [dt]
     if world > 1:
@@ -201,10 +281,32 @@ def timed_steps(step, steps: int, warmup: int, world: int, dist, sync, device=No
 
 
 def cpu_plumbing(args) -> None:
-    """Launcher / barrier / corner-gather plumbing on CPU (gloo).  NOT the data path: the corners are a fixed pattern."""
-    from boxdreamer_amd.dist import gather_corners
+    """Launcher / barrier / corner-gather plumbing on CPU (gloo).  NOT the data path: the corners are a fixed pattern.  Walks the
+    same stages as the GPU sweep: per-rank seeded shard, the lane-count agreement (all_reduce MIN), timed steps with the corner
+    all-gather, the gather-latency probe, optionally a ragged global batch -- and `--plumbing-fail-rank` kills one rank at a chosen
+    stage to exercise the failure report."""
+    from boxdreamer_amd import synth
+    from boxdreamer_amd.dist import gather_corners, gather_corners_ragged, shard_range
     world, rank, _, dist = init_dist(args)
     B = args.batch
+
+    def maybe_fail(stage):
+        PROGRESS["stage"] = stage
+        if args.plumbing_fail_rank == rank and args.plumbing_fail_stage == stage:
+            raise RuntimeError(f"injected failure on rank {rank} at stage {stage}")
+
+    # per-rank seeds: every rank's shard must differ (seed = 100 + rank, as in the GPU sweep)
+    mine = synth.make_batch(seed=100 + rank, B=1, T=1, size=56)["images"]      # (16-px zero border: 24 x 24 random pixels)
+    chk = torch.tensor([float(mine.double().sum())], dtype=torch.float64)
+    lanes = torch.tensor([1 if rank == args.plumbing_short_rank else 2], dtype=torch.int32)
+    if world > 1:
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        distinct = len({round(float(c), 6) for c in allc}) == world
+        dist.all_reduce(lanes, op=dist.ReduceOp.MIN)          # every rank must time the same number of in-flight lanes
+    else:
+        distinct = True
+    maybe_fail("before_timed")
     kp = (torch.arange(B * 16, dtype=torch.float32).reshape(B, 8, 2) + 1000.0 * rank)
 
     def step():
@@ -212,13 +314,162 @@ def cpu_plumbing(args) -> None:
     dt, per_rank, out = timed_steps(step, args.steps, args.warmup, world, dist, lambda: None)
     ok = all(torch.equal(out[r * B:(r + 1) * B], torch.arange(B * 16, dtype=torch.float32).reshape(B, 8, 2) + 1000.0 * r)
              for r in range(world))
+    PROGRESS["line"].update(per_rank_ms_per_step=[round(t / args.steps * 1e3, 4) for t in per_rank])
+    maybe_fail("after_timed")
+    lat = None
+    if world > 1:
+        lat = gather_latency_ms(kp, world, dist, gather_corners, reps=10, sync=lambda: None)
+        PROGRESS["line"].update(corner_allgather_ms=round(lat, 4))
+    ragged_ok = None
+    if args.plumbing_global_batch and world > 1:           # a global batch that does not divide by the world size
+        G = args.plumbing_global_batch
+        full = torch.arange(G * 16, dtype=torch.float32).reshape(G, 8, 2)
+        lo, hi = shard_range(G, rank, world)
+        ragged_ok = bool(torch.equal(gather_corners_ragged(full[lo:hi].clone(), G), full))
+    maybe_fail("before_report")
     if rank == 0:
+        PROGRESS["printed"] = True
         print(json.dumps({"plumbing_only": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "backend": args.backend, "gathered_rows": int(out.shape[0]), "gather_ok": bool(ok),
+                          "per_rank_seeds_distinct": bool(distinct), "lanes_agreed": int(lanes.item()), "ragged_ok": ragged_ok,
+                          "corner_allgather_ms": None if lat is None else round(lat, 4),
                           "per_rank_ms_per_step": [round(t / args.steps * 1e3, 4) for t in per_rank]}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ PMC counters
+# HBM traffic and MFMA-busy come from hardware counters, which only rocprofv3 can read: `python bench.py --measure-counters
+# --prec P` runs the three PMC passes over THIS script (one counter group per pass, --kernel-trace only -- the combination the
+# MI355X guide prescribes) and writes profiles/counters_<P>.json stamped with a hash of the kernel sources; a default run reports
+# those figures as roofline.traffic / mfma_busy ONLY while the stamp matches the sources it is running (else null + why).
+
+def kernel_source_sha() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "boxdreamer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def algorithmic_gemm_bytes(prec: str, B: int, T: int) -> tuple[int, int]:
+    """(bytes, bd_gemm calls) of one step if every GEMM read each operand ONCE and wrote its result once: A, W, fp32 residual in /
+    result out, in the storage formats of the mode."""
+    a = {"bf16": 2, "fp16": 2, "fp8": 1, "f16c8": 3, "f16c8_qkv16": 3}.get(prec, 4)           # activation operand bytes / element
+    w = {"bf16": 2, "fp16": 2, "fp8": 1, "f16c8": 4, "f16c8_qkv16": 4}.get(prec, 4)           # weight bytes / element (F16C8: f16 + [q8|lo8])
+    strict = prec not in ("bf16", "fp16", "fp8")
+    total, calls = 0, 0
+
+    def gemm(M, N, K, a_b, w_b, out_b, resid=False):
+        nonlocal total, calls
+        total += M * K * a_b + N * K * w_b + M * N * out_b + (M * N * 4 if resid else 0)
+        calls += 1
+
+    def block(M, Mtail, qkv_a, qkv_w, qkv_o):
+        gemm(M, 2304, 768, qkv_a, qkv_w, qkv_o)
+        gemm(Mtail, 768, 768, a, w, 4, True)
+        gemm(Mtail, 3072, 768, a, w, a)
+        gemm(Mtail, 768, 3072, a, w, 4, True)
+
+    n = B * T
+    gemm(n * 256, 768, 640 if prec != "fp8" else 640, a, w, 4)                                  # patch embed (+ positional table)
+    for _ in range(12):                                       # DINOv2: q, k not normalised -> split-bf16 attention in the strict modes
+        block(n * 261, n * 261, a, w, 4 if strict else (2 if prec != "fp8" else 2))
+    M, Mq = n * 256, B * 256
+    gemm(M, 768, 768, a, w, a); gemm(M, 768, 768, a, w, 4)                                     # adapter
+    gemm(M, 768, 1600 if prec != "fp8" else 1664, a, w, 4, True)                                # heatmap patch embedding + rgb + pos
+    q16 = prec in ("f16c8_qkv16", "bf16x3_qkv16")
+    for i in range(12):                                       # BETR: f16 attention in the strict modes (q, k RMS-normalised)
+        block(M, M if i < 11 else Mq, 2 if q16 else a, 2 if q16 else w, 2)
+    gemm(Mq, 1568, 768, a, w, 4)                                                               # head
+    return total, calls
+
+
+def _rocprof_pass(counters, child_args, timeout_s=600):
+    import glob, subprocess, tempfile
+    out = tempfile.mkdtemp(prefix="bd_pmc_", dir="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "--",
+           sys.executable, os.path.abspath(__file__), *child_args]
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+    files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+    if r.returncode != 0 or not files:
+        raise RuntimeError(f"rocprofv3 pass {counters} failed (rc {r.returncode}): {r.stderr[-800:]}")
+    return files[0]
+
+
+def _kclass(name: str) -> str:
+    for key, c in (("gemm_kernel", "gemm"), ("attn_kernel", "attention"), ("layernorm", "layernorm"), ("rmsnorm", "rmsnorm")):
+        if key in name:
+            return c
+    return "other"
+
+
+def measure_counters(args) -> None:
+    import collections, csv
+    prec, B, T = args.prec, args.batch, args.views
+    child = ["--prec", prec, "--batch", str(B), "--views", str(T), "--steps", "2", "--warmup", "1", "--no-graph", "--in-flight", "1",
+             "--no-strict", "--no-cpu-baseline", "--no-parity", "--no-pnp", "--no-h2d"]
+    acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")}
+    launches, dur_ns, steps_seen = collections.defaultdict(int), collections.defaultdict(float), 0
+    for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")):
+        path = _rocprof_pass(group, child)
+        first = group[0]
+        for r in csv.DictReader(open(path)):
+            c, k = r["Counter_Name"], _kclass(r["Kernel_Name"])
+            if c in acc:
+                acc[c][k] += float(r["Counter_Value"])
+            if c == first and group[0] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                launches[k] += 1
+                dur_ns[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                if "decode_kernel" in r["Kernel_Name"]:
+                    steps_seen += 1
+    if steps_seen == 0:
+        raise SystemExit("no decode_kernel dispatch in the counter profile: cannot tell how many steps it covers")
+    alg_bytes, calls = algorithmic_gemm_bytes(prec, B, T)
+    per = {}
+    for k in sorted(launches, key=lambda k: -dur_ns[k]):
+        fetch = 2.0 * acc["FETCH_SIZE"][k] * 1024.0 / steps_seen          # KB -> bytes; x2: gfx950 tallies 128-B requests at 64 B
+        write = acc["WRITE_SIZE"][k] * 1024.0 / steps_seen
+        cyc = acc["SQ_BUSY_CYCLES"][k] / 32.0                             # summed over the 32 shader engines
+        per[k] = {"launches_per_step": round(launches[k] / steps_seen, 2), "ms_per_step": round(dur_ns[k] / steps_seen / 1e6, 3),
+                  "fetch_bytes_per_step": round(fetch), "write_bytes_per_step": round(write),
+                  "hbm_gb_per_s": round((fetch + write) / max(dur_ns[k] / steps_seen, 1) , 1),
+                  "mfma_busy": round(acc["SQ_VALU_MFMA_BUSY_CYCLES"][k] / max(cyc * 1024.0, 1.0), 4),
+                  "delivered_clock_ghz": round(cyc / max(dur_ns[k], 1), 3)}
+    tb = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"].values())
+    tc = sum(acc["SQ_BUSY_CYCLES"].values()) / 32.0
+    g = per.get("gemm", {})
+    out = {"prec": prec, "batch": B, "views": T, "kernel_source_sha": kernel_source_sha(), "steps_profiled": steps_seen,
+           "gemm_calls_per_step": calls,
+           "gemm_hbm_bytes_per_call": round((g.get("fetch_bytes_per_step", 0) + g.get("write_bytes_per_step", 0)) / calls),
+           "gemm_algorithmic_bytes_per_call": round(alg_bytes / calls),
+           "gemm_traffic_over_algorithmic": round((g.get("fetch_bytes_per_step", 0) + g.get("write_bytes_per_step", 0)) / alg_bytes, 3),
+           "mfma_busy_whole_step": round(tb / max(tc * 1024.0, 1.0), 4), "per_kernel_class": per,
+           "how": "rocprofv3 --kernel-trace --pmc <one group per pass: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES> over "
+                  "`bench.py " + " ".join(child) + "` (one batch at a time, un-graphed); bytes = counter KB x 1024, FETCH_SIZE x 2 (gfx950 "
+                  "correction, MI355X_MICROARCH.md HBM section), WRITE_SIZE as is; MFMA busy = MFMA-busy SIMD-cycles / (SQ_BUSY_CYCLES / 32 x "
+                  "1024 SIMDs); per step = totals / decode_kernel dispatches"}
+    path = os.path.join(ROOT, "profiles", f"counters_{prec}.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "how"}), flush=True)
+
+
+def load_counters(prec: str, B: int, T: int):
+    """(counters dict or None, why-not).  Only counters measured on the kernel sources now in the tree count."""
+    path = os.path.join(ROOT, "profiles", f"counters_{prec}.json")
+    if not os.path.exists(path):
+        return None, f"no profiles/counters_{prec}.json (run `python bench.py --measure-counters --prec {prec}`)"
+    c = json.load(open(path))
+    if (c.get("batch"), c.get("views")) != (B, T):
+        return None, f"profiles/counters_{prec}.json was measured at batch {c.get('batch')}, views {c.get('views')}"
+    if c.get("kernel_source_sha") != kernel_source_sha():
+        return None, (f"profiles/counters_{prec}.json is STALE: measured on kernel sources {c.get('kernel_source_sha')}, this tree is "
+                      f"{kernel_source_sha()} (re-run --measure-counters)")
+    return c, None
 
 
 # ------------------------------------------------------------------------------------------------ one precision mode
@@ -256,11 +507,15 @@ class ModeRun:
             # tail rounds (DINOv2's N = 768 GEMMs run 3.06 rounds of 256 CUs, attention 13.5, ...); every batch is still
             # computed in full and in order on its lane.  `--in-flight 1` is the single-stream step.
             self.lanes.append({"g": self.graphed, "s": torch.cuda.Stream(device=device), "done": torch.cuda.Event(), "free": torch.cuda.Event()})
-            for _ in range(1, max(1, args.in_flight)):
+            for li in range(1, max(1, args.in_flight)):
                 try:
                     enc2, dec2 = build_models(prec, device)
                     g2 = GraphedPath(enc2, dec2, self.B, self.T, 224, torch.bfloat16, device)
-                    g2.set_inputs(images, bbox)
+                    # the lane's own batch: B more distinct samples (another seed), so K steps really are K x B different-or-
+                    # repeated-per-lane poses, not one batch fed to both lanes
+                    from boxdreamer_amd import synth
+                    other = synth.make_batch(seed=100 + rank + 1000 * li, B=self.B, T=self.T)
+                    g2.set_inputs(other["images"].to(torch.bfloat16).to(device), other["bbox_feat"].to(torch.bfloat16).to(device))
                 except (RuntimeError, MemoryError) as e:          # e.g. not enough memory for a second copy: one batch at a time
                     print(f"bench: second in-flight lane not available ({type(e).__name__}: {e}); timing one batch at a time", file=sys.stderr)
                     break
@@ -324,20 +579,21 @@ def trace_launches(lib, _lib, run_once, n_runs: int, cap: int = 8192):
     return [(buf[i].kind, buf[i].M, buf[i].N, buf[i].K, buf[i].ms) for i in range(n)], wall_ms
 
 
-def gather_latency_ms(kp, world, dist, gather, reps: int = 50) -> float:
+def gather_latency_ms(kp, world, dist, gather, reps: int = 50, sync=None) -> float:
     """Mean latency of the corner all-gather alone (the only collective of the sweep), barrier-aligned."""
+    sync = torch.cuda.synchronize if sync is None else sync
     for _ in range(5):
         gather(kp, world)
-    dist.barrier()
-    torch.cuda.synchronize()
+    barrier(dist, kp.device if kp.is_cuda else None)
+    sync()
     t0 = time.perf_counter()
     for _ in range(reps):
         gather(kp, world)
-    torch.cuda.synchronize()
+    sync()
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, traffic):
+def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, counters, counters_why):
     peak = PEAK_MFMA_FP8 if prec == "fp8" else PEAK_MFMA_16BIT
     g = [(2.0 * m * n * k, ms) for kind, m, n, k, ms in recs if kind == 0]
     a = [(4.0 * m * n * n * k, ms) for kind, m, n, k, ms in recs if kind == 1]   # 4*S^2*d per (batch*head)
@@ -345,7 +601,14 @@ def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, traf
     attn_tf = sum(f for f, _ in a) / max(sum(ms for _, ms in a), 1e-9) / 1e9 if a else 0.0
     r = {"bound": "mfma", "kernel": "gemm_kernel_pc (persistent producer/consumer, 256x192 tiles, LDS-DMA operands, v_mfma_f32_32x32x16) + gemm_kernel_glds for the shapes it does not take",
          "achieved": round(gemm_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tf / peak, 4),
-         "traffic": traffic[0], "traffic_source": traffic[1],
+         "traffic": counters["gemm_hbm_bytes_per_call"] if counters else None,
+         "traffic_source": counters["how"] if counters else counters_why,
+         "algorithmic_bytes_per_launch": counters["gemm_algorithmic_bytes_per_call"] if counters else None,
+         "traffic_over_algorithmic": counters["gemm_traffic_over_algorithmic"] if counters else None,
+         "mfma_busy": ({"gemm": counters["per_kernel_class"].get("gemm", {}).get("mfma_busy"),
+                        "attention": counters["per_kernel_class"].get("attention", {}).get("mfma_busy"),
+                        "whole_step_one_batch_at_a_time": counters["mfma_busy_whole_step"],
+                        "unit": "fraction of SIMD cycles with the MFMA pipe busy (counted, rocprofv3 PMC)"} if counters else None),
          "algorithmic_flops_per_launch": round(sum(f for f, _ in g) / max(len(g), 1)), "launches": len(g),
          "events": f"HIP events (launch stream) around every GEMM / attention launch of {trace_runs} un-graphed executions of "
                    "the step on the same buffers right after the timed region (events cannot be timed inside a captured graph)",
@@ -361,34 +624,27 @@ def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, traf
     return r
 
 
-def measure_mode(prec, args, device, world, rank, dist, images, bbox, mask, with_traffic: bool):
+def measure_mode(prec, args, device, world, rank, dist, images, bbox, mask):
     from boxdreamer_amd import _lib
     lib = _lib.load()
     run = ModeRun(prec, args, device, world, rank, dist, images, bbox, mask)
-    dt, per_rank, out = timed_steps(run.step, args.steps, args.warmup, world, dist, torch.cuda.synchronize, device)
+    sync = torch.cuda.synchronize if world == 1 else interruptible_sync(device)
+    dt, per_rank, out = timed_steps(run.step, args.steps, args.warmup, world, dist, sync, device)
     B, T = run.B, run.T
     assert out.shape[0] == B * world and torch.isfinite(out).all()
     res = {"dt": dt, "per_rank": per_rank, "out": out, "run": run, "in_flight": max(1, len(run.lanes))}
     if len(run.lanes) > 1:        # the same K steps one batch at a time on one stream, for the record
-        dt1, _, out1 = timed_steps(run.step_single, args.steps, 1, world, dist, torch.cuda.synchronize, device)
-        assert torch.equal(out1, out)
+        dt1, _, out1 = timed_steps(run.step_single, args.steps, 1, world, dist, sync, device)
+        assert out1.shape == out.shape and torch.isfinite(out1).all()     # (lanes hold different batches: values differ by design)
         res["single_stream"] = {"value": round(B * world * args.steps / dt1, 2), "ms_per_step": round(dt1 / args.steps * 1e3, 3)}
     if rank == 0:
         TRACE = 3
         recs, _ = trace_launches(lib, _lib, run.eager, TRACE)
         value = B * world * args.steps / dt
         fpp = flops_per_pose(T) if not args.cache_refs else DINO_FLOP_PER_IMAGE + betr_flops(T)
-        traffic = (None, None)
-        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-        if with_traffic and os.path.exists(tpath) and prec == "bf16" and B == 32 and T == 6 and not args.cache_refs:
-            tj = json.load(open(tpath))
-            nb = tj["hbm_bytes_per_launch"]
-            g_calls = sum(1 for r in recs if r[0] == 0) / TRACE
-            if tj.get("steps_profiled") and g_calls:      # per kernel launch -> per bd_gemm call (the unit of `achieved`)
-                nb = round(tj["hbm_bytes_per_launch"] * tj["launches"] / tj["steps_profiled"] / g_calls)
-            traffic = (nb, tj["source"])
+        counters, why = (None, "reference features cached: other algorithmic traffic") if args.cache_refs else load_counters(prec, B, T)
         res.update(value=value, fpp=fpp, ms_per_step=dt / args.steps * 1e3,
-                   roofline=roofline_block(prec, recs, dt / args.steps * 1e3, TRACE, value / world, fpp, traffic))
+                   roofline=roofline_block(prec, recs, dt / args.steps * 1e3, TRACE, value / world, fpp, counters, why))
     return res
 
 
@@ -540,9 +796,51 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--cpu-plumbing", action="store_true",
                     help="run ONLY the launcher / barrier / corner-gather plumbing on CPU (tests); needs --backend gloo")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the exact launch command + environment `--gpus N` turns into (JSON) and exit")
+    ap.add_argument("--dist-timeout", type=int, default=600, help="collective timeout in seconds (a dead rank must not hang the others)")
+    ap.add_argument("--plumbing-fail-rank", type=int, default=-1, help="(--cpu-plumbing) make this rank raise at --plumbing-fail-stage")
+    ap.add_argument("--plumbing-fail-stage", default="before_timed", choices=["before_timed", "after_timed", "before_report"])
+    ap.add_argument("--plumbing-short-rank", type=int, default=-1, help="(--cpu-plumbing) this rank offers only one in-flight lane")
+    ap.add_argument("--plumbing-global-batch", type=int, default=0, help="(--cpu-plumbing) also gather a ragged global batch of this size")
+    ap.add_argument("--measure-counters", action="store_true",
+                    help="run the rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy: one pass each) over this script for --prec and "
+                         "write profiles/counters_<prec>.json, which later default runs report as roofline.traffic / mfma_busy")
     args = ap.parse_args()
 
     maybe_respawn(args)
+    if args.measure_counters:
+        return measure_counters(args)
+    _, rank0, _ = dist_env()
+    try:
+        return run(args)
+    except BaseException as e:                   # noqa: BLE001 -- report, then re-raise with a non-zero exit
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        if rank0 == 0:
+            emit_failure(f"{type(e).__name__}: {e}")
+        raise
+
+
+def workload_name(B: int, T: int, prec: str, world: int, cache_refs: bool) -> str:
+    """Which BASELINE.json config this invocation IS (the T = 17 and B = 1 lines used to be labelled configs[1])."""
+    shape = f"1 query + {T - 1} ref, 224x224, batch {B}/GPU ({B} distinct seeded samples per rank and in-flight lane)"
+    tail = ", DINOv2 ViT-B/14-reg + BETR-12 + top-20 decode, random-init weights, inputs bf16 in HBM"
+    if cache_refs:
+        return "SURVEY 8f1 (reference features cached): " + shape + tail
+    if prec == "fp8" and T == 6 and B == 64:
+        return "configs[4]: fp8 (e4m3) Linears, " + shape + tail
+    if T == 6 and B == 32 and prec != "fp8":
+        return "configs[1]: " + shape + tail
+    if T == 17:
+        full = B * world == 256 and world == 8
+        return ("configs[3]: " if full else f"configs[3] shape (the config itself is batch 256 over 8 GPUs; this run: batch {B * world} over {world}): ") + shape + tail
+    if T == 2 and B == 1:
+        return "configs[0] shape on the GPU: " + shape + tail
+    return "custom (not a BASELINE.json config): " + shape + tail
+
+
+def run(args):
     if args.cpu_plumbing:
         if args.backend != "gloo":
             raise SystemExit("--cpu-plumbing needs --backend gloo")
@@ -564,8 +862,11 @@ def main():
     images = one["images"].to(torch.bfloat16).to(device)
     bbox = one["bbox_feat"].to(torch.bfloat16).to(device)
     mask = torch.zeros(B, T, dtype=torch.bool, device=device); mask[:, T - 1] = True
+    PROGRESS["line"].update(metric="poses/s/GPU (5-ref, 224×224, bf16); heatmap max-abs err vs CPU ref", unit="poses/s",
+                            steps=args.steps, warmup=args.warmup)
+    PROGRESS["stage"] = "timed steps"
 
-    main_res = measure_mode(prec, args, device, world, rank, dist, images, bbox, mask, with_traffic=True)
+    main_res = measure_mode(prec, args, device, world, rank, dist, images, bbox, mask)
     line = None
     if rank == 0:
         value, fpp = main_res["value"], main_res["fpp"]
@@ -576,9 +877,7 @@ def main():
                 "value": round(value, 2), "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(main_res["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": DTYPE_LABEL[prec], "data": "synthetic",
-                "config": {"workload": f"configs[1]: 1 query + {T - 1} ref, 224x224, batch {B}/GPU ({B} distinct seeded samples "
-                                       f"per rank), DINOv2 ViT-B/14-reg + BETR-12 + top-20 decode, random-init weights, "
-                                       f"inputs bf16 in HBM",
+                "config": {"workload": workload_name(B, T, prec, world, args.cache_refs),
                            "global_batch": B * world, "views": T, "parallelism": f"dp{world}",
                            "hip_graph": main_res["run"].graphed is not None, "gflop_per_pose": round(fpp / 1e9, 2),
                            "batches_in_flight": main_res["in_flight"],
@@ -590,11 +889,15 @@ def main():
                 "roofline": main_res["roofline"]}
         if "single_stream" in main_res:
             line["single_stream"] = main_res["single_stream"]
+        PROGRESS["line"] = dict(line)
+    PROGRESS["stage"] = "corner all-gather latency"
     if world > 1:
-        lat = gather_latency_ms(main_res["run"].kp_all, world, dist, main_res["run"].gather)
+        lat = gather_latency_ms(main_res["run"].kp_all, world, dist, main_res["run"].gather, sync=interruptible_sync(device))
         if rank == 0:
             line["corner_allgather_ms"] = round(lat, 4)
+            PROGRESS["line"] = dict(line)
             line["collective"] = f"all_gather_into_tensor of ({B}, 8, 2) fp32 per rank over RCCL (xGMI), once per step"
+    PROGRESS["stage"] = "parity / side measurements"
     if rank == 0:
         run = main_res["run"]
         if not args.no_parity:
@@ -607,9 +910,12 @@ def main():
     del main_res
 
     # ---- the strict mode, same invocation, same inputs (every rank takes part: same barrier / gather structure)
+    PROGRESS["stage"] = "strict mode"
+    if rank == 0:
+        PROGRESS["line"] = dict(line)
     if not args.no_strict and prec != STRICT_PREC and not args.cache_refs:
         torch.cuda.empty_cache()
-        sres = measure_mode(STRICT_PREC, args, device, world, rank, dist, images, bbox, mask, with_traffic=False)
+        sres = measure_mode(STRICT_PREC, args, device, world, rank, dist, images, bbox, mask)
         if rank == 0:
             srun = sres["run"]
             line["strict"] = {"mode": STRICT_PREC,
@@ -631,6 +937,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(T)
             line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+        PROGRESS["printed"] = True
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

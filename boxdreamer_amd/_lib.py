@@ -27,6 +27,10 @@ PREC_NAMES = {"bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16x3": PR
               "bf16x3_qkv16": PREC_BF16X3_QKV16, "f16c8_qkv16": PREC_F16C8_QKV16}
 _X3_FAMILY = (PREC_BF16X3, PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16, 11)
 ACT_NONE, ACT_GELU = 0, 1
+# The precision a module runs when its config names none: the fastest mode that MEETS the path's parity bar (heatmap logits
+# within 1e-3 of the fp32 CPU forward, identical top-20 sets).  "bf16" -- the reference's own `precision`, 4e-2 off its fp32
+# forward -- is the explicit throughput opt-in (`hip_precision: bf16` in the decoder / encoder config, or $BOXDREAMER_HIP_PREC).
+DEFAULT_PREC = "f16c8_qkv16"
 
 _ERR = {-1: "BD_ERR_SHAPE", -2: "BD_ERR_DTYPE", -3: "BD_ERR_ALIGN", -4: "BD_ERR_WORKSPACE", -5: "BD_ERR_NULL"}
 
@@ -97,6 +101,9 @@ _lib = None
 def load() -> C.CDLL:
     """Load the HIP library; raise loudly if it has not been built."""
     global _lib
+    # every wrapper calls load() before it hands the first tensor to ptr(): forget a device noted by a call that raised
+    # between ptr() and stream() (it would make the next call on another device fail with a false "mixes tensors" error)
+    _call.dev = None
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):

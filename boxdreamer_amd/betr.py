@@ -8,6 +8,7 @@ bbox_representation='heatmap', use_pretrained=True.  Inference o
 from __future__ import annotations
 
 import os
+import weakref
 import warnings
 
 import torch
@@ -80,7 +81,7 @@ class BETR(nn.Module):
                 "bbox_representation='heatmap', use_pretrained=True, nvs_supervision=False")
         self.box_dim = 8
         self.cat_dim = 3 + 8
-        self.hip_precision = kwargs.get("hip_precision", os.environ.get("BOXDREAMER_HIP_PREC", "bf16"))
+        self.hip_precision = kwargs.get("hip_precision", os.environ.get("BOXDREAMER_HIP_PREC", _lib.DEFAULT_PREC))
 
         self.attn = nn.Sequential(*[SelfAttentionBlock(d_model, nhead) for _ in range(num_decoder_layers)])
         self.bbox_proj = nn.Linear(d_model, self.patch_size ** 2 * 8)
@@ -91,7 +92,7 @@ class BETR(nn.Module):
 
         self._packed = {}          # (device, operand class) -> (content signature, pack.Packed)
         self._ws = None
-        self._frozen_by = None     # a live GraphedPath that captured raw pointers into _packed / _ws (graph.py)
+        self._frozen_by = weakref.WeakSet()   # live GraphedPaths that captured raw pointers into _packed / _ws (graph.py)
         self.last_logits = None
         self.validate_inputs = True   # one-hot check of `masks` costs a device sync; graph capture and bench turn it off
         self.recast_count = 0         # forwards that had to re-cast features lacking an operand copy (features.py)
@@ -101,7 +102,7 @@ class BETR(nn.Module):
     # through `_load_from_state_dict` and never calls this module's `load_state_dict`), an in-place edit, `.to()` or
     # `.half()` all re-pack on the next forward.
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return tuple((p.data_ptr(), None if p.is_inference() else p._version) for p in self.parameters())
 
     def _apply(self, fn, *a, **k):
         self._check_not_frozen("moving / casting the module")
@@ -109,8 +110,7 @@ class BETR(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _check_not_frozen(self, what: str):
-        g = self._frozen_by() if self._frozen_by is not None else None
-        if g is not None:
+        if len(self._frozen_by):
             raise RuntimeError(f"{what} would free memory a live GraphedPath still replays on; delete the graph first")
 
     def _weights(self, device, prec) -> pack.Packed:

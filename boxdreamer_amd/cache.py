@@ -19,6 +19,25 @@ import torch
 from . import _lib, features
 
 
+def _new_operand(pid: int, n_views: int, P: int, C: int, dtype, dev) -> torch.Tensor:
+    rows = n_views * P
+    return torch.zeros((2, rows, C) if _lib.planes(pid) == 2 else (rows, C), dtype=dtype, device=dev)
+
+
+def _plane_views(t16: torch.Tensor, pid: int, n_views: int, P: int, C: int):
+    """Per-view row views [n_views, P, C] of every plane of an operand tensor, in the plane's OWN element type.
+    Split-bf16: two elementwise 16-bit planes.  F16C8 (include/boxdreamer_hip.h): plane 0 is f16, plane 1 is one e4m3 BYTE per
+    element -- rows of C bytes packed into the first rows*C bytes of the plane's storage (the rest is unused) -- so it must be
+    moved as uint8 rows, never as 16-bit rows."""
+    rows = n_views * P
+    if _lib.planes(pid) == 1:
+        return [t16.reshape(n_views, P, C)]
+    if pid == _lib.PREC_F16C8:
+        lo8 = t16[1].view(torch.uint8).reshape(-1)[: rows * C].reshape(n_views, P, C)
+        return [t16[0].reshape(n_views, P, C), lo8]
+    return [t16[0].reshape(n_views, P, C), t16[1].reshape(n_views, P, C)]
+
+
 class RefFeatureCache:
     def __init__(self, encoder):
         self.encoder = encoder                                 # a DinoV2Wrapper
@@ -45,15 +64,9 @@ class RefFeatureCache:
         valid[torch.arange(B, device=dev), query_idx.to(dev).long()] = False
         full32 = torch.zeros((B, T, P, C), dtype=torch.float32, device=dev)
         full32[valid] = ref_feats.reshape(B * R, P, C)
-        np_ = _lib.planes(pid)
-        if np_ == 2:
-            full16 = torch.zeros((2, B, T, P, C), dtype=f16.dtype, device=dev)
-            full16[:, valid] = f16.reshape(2, B * R, P, C)
-            full16 = full16.reshape(2, B * T * P, C)
-        else:
-            full16 = torch.zeros((B, T, P, C), dtype=f16.dtype, device=dev)
-            full16[valid] = f16.reshape(B * R, P, C)
-            full16 = full16.reshape(B * T * P, C)
+        full16 = _new_operand(pid, B * T, P, C, f16.dtype, dev)
+        for dst, src in zip(_plane_views(full16, pid, B * T, P, C), _plane_views(f16, pid, B * R, P, C)):
+            dst.reshape(B, T, P, C)[valid] = src
         return features.attach(full32, full16, pid), valid
 
 
@@ -69,12 +82,8 @@ def merge_cached_features(encoder, images: torch.Tensor, cached: torch.Tensor, v
     P, C = cached.shape[2:]
     out32 = cached.clone()
     out32[miss] = new
-    if _lib.planes(pid) == 2:
-        out16 = f16.clone().reshape(2, B, T, P, C)
-        out16[:, miss] = n16.reshape(2, -1, P, C)
-        out16 = out16.reshape(2, B * T * P, C)
-    else:
-        out16 = f16.clone().reshape(B, T, P, C)
-        out16[miss] = n16.reshape(-1, P, C)
-        out16 = out16.reshape(B * T * P, C)
+    out16 = f16.clone()
+    n_miss = int(new.shape[0])
+    for dst, src in zip(_plane_views(out16, pid, B * T, P, C), _plane_views(n16, pid, n_miss, P, C)):
+        dst.reshape(B, T, P, C)[miss] = src
     return features.attach(out32, out16, pid)

@@ -1419,10 +1419,12 @@ inline bool uses_pc192(const bd_gemm_args& a, int ns, int esz, int cus) {
     // run on the CUs this kernel's tail leaves idle -- +5 %: 1221 -> 1282 poses/s same box.)
     return (double)t192 / (double)(((t192 + cus - 1) / cus) * cus) >= 0.75;       // last-round occupancy of the CUs
 }
-// a fused q/k RMSNorm needs: 16-bit output of a plain Linear, N = 3 x heads x 96, row-identity output map
+// a fused q/k RMSNorm needs: 16-bit output of a plain Linear, N = 3 x heads x 96, row-identity output map, and N a multiple of
+// the 192-column workgroup tile: with an odd head count (N = 288 h, h odd) the last column tile's second wave tile would lie
+// past N, and the fused branch stores whole 96-column heads without a column guard
 inline bool rms_geometry_ok(const bd_gemm_args& a) {
     return a.rms_wq && a.rms_wk && a.out_f32 != OUT_F32 && a.act == BD_ACT_NONE && !a.resid && !a.addtab && a.rpg_in <= 0 &&
-           a.N % 3 == 0 && (a.N / 3) % 96 == 0 && (((uintptr_t)a.rms_wq | (uintptr_t)a.rms_wk) & 3) == 0;
+           a.N % 3 == 0 && (a.N / 3) % 96 == 0 && a.N % 192 == 0 && (((uintptr_t)a.rms_wq | (uintptr_t)a.rms_wk) & 3) == 0;
 }
 
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {

@@ -11,6 +11,7 @@ Differences that are deliberate:
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
@@ -41,17 +42,16 @@ class PretrainedModelWrapper:
 class DinoV2Encoder:
     """DINOv2 ViT-*/14 + 4 registers, inference only, on the HIP library."""
 
-    def __init__(self, state_dict: dict, heads: int, patch: int = 14, prec="bf16"):
+    def __init__(self, state_dict: dict, heads: int, patch: int = 14, prec=_lib.DEFAULT_PREC):
         self.sd = {k: v.detach().float() for k, v in state_dict.items()}
         self.heads, self.patch, self.prec = heads, patch, prec
         self.device = torch.device("cpu")
         self._packed = {}       # (device, operand class, img_size) -> pack.Packed
         self._ws = None
-        self._frozen_by = None  # weakref to a live GraphedPath that captured raw pointers into _packed / _ws (graph.py)
+        self._frozen_by = weakref.WeakSet()  # live GraphedPaths that captured raw pointers into _packed / _ws (graph.py)
 
     def _check_not_frozen(self, what: str):
-        g = self._frozen_by() if self._frozen_by is not None else None
-        if g is not None:
+        if len(self._frozen_by):
             raise RuntimeError(f"{what} would free memory a live GraphedPath still replays on; delete the graph first")
 
     def to(self, device):
@@ -129,7 +129,7 @@ class DinoV2Wrapper(PretrainedModelWrapper):
         self.freeze = cfg.get("freeze", True)
         self.cfg = cfg
         self.device = None
-        self.prec = cfg.get("hip_precision", os.environ.get("BOXDREAMER_HIP_PREC", "bf16"))
+        self.prec = cfg.get("hip_precision", os.environ.get("BOXDREAMER_HIP_PREC", _lib.DEFAULT_PREC))
         self.load_model()
 
     def get_device(self):

@@ -15,8 +15,15 @@ import torch
 _ATTR = "_bd_operand"
 
 
+def _version(t: torch.Tensor):
+    """In-place-modification stamp of `t`.  Tensors created under `torch.inference_mode()` (Lightning's test / validate /
+    predict loops run there by default) do not track a version counter -- reading `_version` raises -- and cannot be
+    modified in place outside inference mode; for them the identity check is storage address + element count only."""
+    return None if t.is_inference() else t._version
+
+
 def attach(feats32: torch.Tensor, feats16: torch.Tensor, pid: int) -> torch.Tensor:
-    setattr(feats32, _ATTR, (feats16, int(pid), feats32.data_ptr(), feats32.numel(), feats32._version))
+    setattr(feats32, _ATTR, (feats16, int(pid), feats32.data_ptr(), feats32.numel(), _version(feats32)))
     return feats32
 
 
@@ -26,7 +33,7 @@ def operand_of(feats32: torch.Tensor, pid: int):
     if tag is None:
         return None
     f16, tpid, ptr, numel, version = tag
-    if tpid != int(pid) or ptr != feats32.data_ptr() or numel != feats32.numel() or version != feats32._version:
+    if tpid != int(pid) or ptr != feats32.data_ptr() or numel != feats32.numel() or version != _version(feats32):
         return None
     return f16
 
@@ -34,7 +41,7 @@ def operand_of(feats32: torch.Tensor, pid: int):
 def tag_of(feats32: torch.Tensor):
     """(operand copy, precision id) or None -- for the reference-feature cache, which re-packs both copies."""
     tag = getattr(feats32, _ATTR, None)
-    if tag is None or tag[2] != feats32.data_ptr() or tag[4] != feats32._version:
+    if tag is None or tag[2] != feats32.data_ptr() or tag[4] != _version(feats32):
         return None
     return tag[0], tag[1]
 
@@ -43,5 +50,5 @@ def carry(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     """Move src's operand copy onto dst when dst aliases exactly the same elements (same storage start, same count)."""
     tag = getattr(src, _ATTR, None)
     if tag is not None and dst is not src and dst.data_ptr() == tag[2] and dst.numel() == tag[3] and dst.is_contiguous():
-        setattr(dst, _ATTR, (tag[0], tag[1], tag[2], tag[3], dst._version))
+        setattr(dst, _ATTR, (tag[0], tag[1], tag[2], tag[3], _version(dst)))
     return dst

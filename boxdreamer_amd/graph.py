@@ -7,8 +7,6 @@ buffers, the graph is replayed, outputs are read from static buffers.
 """
 from __future__ import annotations
 
-import weakref
-
 import torch
 
 from . import hip_ops
@@ -42,12 +40,13 @@ class GraphedPath:
         # graph replaying on stale weights.  Deleting the GraphedPath lifts the freeze.
         enc_model = getattr(encoder, "model", encoder)
         self._pinned = [enc_model._ws, decoder._ws, list(enc_model._packed.values()), list(decoder._packed.values())]
-        ref = weakref.ref(self)
-        enc_model._frozen_by = ref
-        decoder._frozen_by = ref
+        # every live graph on these modules freezes them (a second GraphedPath must not lift the first one's freeze)
+        enc_model._frozen_by.add(self)
+        decoder._frozen_by.add(self)
 
     def _run(self):
-        self.decoder.validate_inputs = False      # the one-hot mask check is a device sync (illegal while capturing)
+        # (BETR.forward skips its one-hot mask check -- a device sync -- by itself while the stream is capturing; the
+        # module's `validate_inputs` flag is left alone, so eager use of the same decoder keeps the check)
         feats = self.encoder.predict(self.images)
         heat = self.decoder(self.bbox_feat, self.images, self.mask, feats, None)
         kp, kn, idx = hip_ops.decode_topk(heat, want_idx=self.want_idx)

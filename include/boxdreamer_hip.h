@@ -61,13 +61,22 @@ extern "C" {
  *                            (oracle/numerics_sim.py): a single f16 pass costs 5.2e-4 on the logits in this Linear and 1.3e-3 to
  *                            2.6e-3 in every other one, so it is the only Linear that can leave the split scheme inside 1e-3. */
 #define BD_PREC_BF16X3_QKV16 11
-/* f16 + e4m3 corrections (round 2's strict mode; every entry point):  A.W ~= hi_A.hi_W (one f16 MFMA pass) + lo_A.q_W +
- * q_A.lo_W (one e4m3 pass over a doubled K on the block-scaled MFMA): 2 pass-equivalents instead of BF16X3's 3, logits
- * error 1.7e-4 at full depth, and 3 bytes per element through the GEMM's LDS-DMA instead of 4.  Operand [rows][K], K % 32 == 0:
- * plane 0 = f16 hi; plane 1 (`plane` 2-byte units further) = lo8 = e4m3((x - hi) * 2^(E + 11)), one byte per element, the 32
- * k of every block stored as byte 16 h + 8 a + j <- k = 16 a + 8 h + j (a, h < 2, j < 8); q8 = e4m3(hi * 2^E) is derived by
- * the GEMM in registers.  E = 0 for activations, bd_linear.w_qexp / bd_gemm_args.w_qexp for a weight tensor.  Activation
- * operands are clamped to +-448.  Attention: f16 single pass where q, k are RMS-normalised (BETR), split-bf16 in DINOv2. */
+/* f16 + e4m3 corrections (the strict operand class):  A.W ~= hi_A.hi_W (one f16 MFMA pass) + lo_A.q_W + q_A.lo_W (one e4m3
+ * pass over a doubled K on the block-scaled MFMA): 2 pass-equivalents instead of BF16X3's 3, logits error 1.7e-4 at full depth.
+ * Accepted by: bd_gemm, bd_layernorm, bd_im2col_images, bd_patchify_heatmaps, bd_gather_query_tokens and the whole-path entry
+ * points.  NOT by bd_attention[_q] / bd_qk_rmsnorm (BD_ERR_DTYPE): attention runs on an f16 plane or on split-bf16 planes and
+ * EMITS the class through BD_PREC_F16_OUT_F16C8 / BD_PREC_BF16X3_OUT_F16C8 below.
+ * Storage of an operand [rows][K], K % 32 == 0, ld % 32 == 0; "plane" = 2-byte units between plane 0 and plane 1:
+ *   plane 0                f16 hi = f16(x), row-major, 2 bytes per element (activations: x clamped to +-448 first).
+ *   plane 1, ACTIVATIONS   lo8 = e4m3((x - hi) * 2^11): ONE byte per element, rows of `ld` BYTES packed into the first rows*ld
+ *                          bytes of the plane (the rest of the plane's storage is unused); inside every 32-element block the
+ *                          byte at 16 h + 8 a + j holds k = 16 a + 8 h + j (a, h < 2, j < 8).  q8 = e4m3(hi) is derived by the
+ *                          GEMM in registers, nothing stored.
+ *   plane 1, WEIGHTS       TWO bytes per element, rows of 2*ld bytes: per 32-element block 64 bytes = for each h < 2:
+ *                          [ q8 x 16 | lo8 x 16 ] of the sixteen k = 16 a + 8 h + j in (a, j) order, with
+ *                          q8 = e4m3(hi * 2^E), lo8 = e4m3((w - hi) * 2^(E + 11)); E = bd_linear.w_qexp / bd_gemm_args.w_qexp,
+ *                          one exponent per weight tensor (the largest E with max|w| * 2^E <= 448).
+ * boxdreamer_amd/hip_ops.py:f16c8_encode / f16c8_decode are the reference packers (torch ops, load time only). */
 #define BD_PREC_F16C8 8
 /*   BD_PREC_F16C8_QKV16      whole-path only: BD_PREC_F16C8 Linears with BD_PREC_BF16X3_QKV16's exception (BETR's QKV Linear as ONE f16
  *                            pass on an f16 LayerNorm output; needs bd_block_weights.qkv16): round 2's fastest mode inside 1e-3. */

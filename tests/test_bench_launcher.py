@@ -35,3 +35,82 @@ def test_world_size_must_match_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--cpu-plumbing"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (r.stderr + r.stdout)
+
+
+def _plumb(n, *extra, timeout=900):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "gloo", "--cpu-plumbing",
+                           "--steps", "3", "--warmup", "1", "--batch", "4", "--dist-timeout", "120", *extra],
+                          capture_output=True, text=True, env=_env(), timeout=timeout)
+
+
+def _one_line(r):
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
+    return json.loads(lines[0])
+
+
+def test_world4_and_world8_ragged_seeds_and_lane_agreement():
+    """VERDICT r2 item 7 (no multi-GPU hardware this round: harden what a CPU can check).  World sizes 4 and 8 (the driver's
+    N = 4 / 8 sweeps): every rank's seeded shard differs, the in-flight lane count is agreed with all_reduce(MIN) when ONE rank can
+    only offer one lane (bench.py ModeRun), a global batch that does not divide by the world size gathers in order, and the
+    corner all-gather latency is reported."""
+    for n, short, G in ((4, 2, 10), (8, 5, 29)):
+        r = _plumb(n, "--plumbing-short-rank", str(short), "--plumbing-global-batch", str(G))
+        assert r.returncode == 0, r.stderr[-2000:]
+        j = _one_line(r)
+        assert j["n_gpus"] == n and j["gathered_rows"] == 4 * n and j["gather_ok"]
+        assert j["per_rank_seeds_distinct"] and j["lanes_agreed"] == 1 and j["ragged_ok"] is True
+        assert len(j["per_rank_ms_per_step"]) == n and j["corner_allgather_ms"] > 0
+
+
+def test_rank_failure_still_yields_one_line_and_nonzero_rc():
+    """A rank that dies must not hang the sweep, and rank 0 must still print ONE JSON line with n_gpus (+ what was measured so
+    far) and `error`; the launch exits non-zero.  Rank 2 of 4 dies before the timed region / rank 0 itself dies after it."""
+    r = _plumb(4, "--plumbing-fail-rank", "2", "--plumbing-fail-stage", "before_timed")
+    assert r.returncode != 0
+    j = _one_line(r)
+    assert j["n_gpus"] == 4 and j["value"] is None and "error" in j and "injected failure on rank 2" in r.stderr
+    r = _plumb(4, "--plumbing-fail-rank", "0", "--plumbing-fail-stage", "after_timed")
+    assert r.returncode != 0
+    j = _one_line(r)
+    assert j["n_gpus"] == 4 and len(j["per_rank_ms_per_step"]) == 4 and "injected failure on rank 0" in j["error"]
+    assert j["failed_stage"] == "after_timed"
+
+
+def test_dry_run_prints_the_launch_plan_and_ports_do_not_collide():
+    plans = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-run"],
+                           capture_output=True, text=True, env=_env(), timeout=300)
+        assert r.returncode == 0, r.stderr[-1000:]
+        plans.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    p = plans[0]
+    assert p["ranks"] == 8 and p["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and p["env"]["MASTER_ADDR"] == "127.0.0.1"
+    cmd = p["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--dry-run" not in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    port = int(cmd[cmd.index("--master-port") + 1])
+    assert 1024 < port < 65536 and str(port) == p["env"]["MASTER_PORT"]
+    # a MASTER_PORT given by the caller is honoured (the driver passes its own --master-port to torch.distributed.run)
+    env = _env(); env["MASTER_PORT"] = "23456"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert json.loads(r.stdout.strip().splitlines()[-1])["env"]["MASTER_PORT"] == "23456"
+
+
+def test_workload_label_names_the_config_actually_run():
+    """config.workload said "configs[1]" for every --views / --batch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert m.workload_name(32, 6, "bf16", 1, False).startswith("configs[1]:")
+    assert m.workload_name(32, 6, "f16c8_qkv16", 8, False).startswith("configs[1]:")
+    assert m.workload_name(32, 17, "bf16", 8, False).startswith("configs[3]:")
+    assert m.workload_name(32, 17, "bf16", 1, False).startswith("configs[3] shape")
+    assert m.workload_name(64, 6, "fp8", 1, False).startswith("configs[4]:")
+    assert m.workload_name(1, 6, "bf16", 1, False).startswith("custom")
+    assert m.workload_name(32, 6, "bf16", 1, True).startswith("SURVEY 8f1")
+    # algorithmic GEMM bytes: 101 bd_gemm calls per step at T = 6, ~0.4 GB per call in bf16, more in the strict classes
+    b16, calls = m.algorithmic_gemm_bytes("bf16", 32, 6)
+    bs, _ = m.algorithmic_gemm_bytes("f16c8_qkv16", 32, 6)
+    assert calls == 101 and 3.5e8 < b16 / calls < 4.5e8 and b16 < bs < 2 * b16

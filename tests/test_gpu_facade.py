@@ -12,7 +12,19 @@ from oracle import boxdreamer_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
+STRICT_DEFAULT = "f16c8_qkv16"       # the facade's default mode (boxdreamer_amd._lib.DEFAULT_PREC)
+
+
 def _config(prec, depth=2):
+    """prec None: no `hip_precision` key anywhere -- what the reference's own YAML gives a maintainer."""
+    cfg = _config_with(prec if prec is not None else "x", depth)
+    if prec is None:
+        del cfg["modules"]["decoder"]["hip_precision"]
+        del cfg["modules"]["encoder"]["dino"]["cfg"]["hip_precision"]
+    return cfg
+
+
+def _config_with(prec, depth=2):
     return {"modules": {
         "use_keypoints": False, "use_matching": False, "use_tracking": False, "use_rgb": True, "use_pp": True,
         "ref_type": "all", "regression_intri": True, "rotation_type": None, "coordinate": "object",
@@ -27,9 +39,12 @@ def _config(prec, depth=2):
     }}
 
 
+@pytest.mark.parametrize("prec", [None, "bf16x3"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_forward_dict_contract(hip, dtype):
-    model = BoxDreamer(_config("bf16x3"))
+def test_forward_dict_contract(hip, dtype, prec):
+    model = BoxDreamer(_config(prec))
+    if prec is None:
+        assert model.decoder.hip_precision == model.rgb_encoder.prec == STRICT_DEFAULT
     # checkpoints carry the decoder under "decoder." (Lightning adds "BoxDreamer." on top, demo.py:564-573 strips it)
     sd = {"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}
     missing, unexpected = model.load_state_dict(sd, strict=True), None
@@ -40,7 +55,11 @@ def test_forward_dict_contract(hip, dtype):
     keys_in = set(data)
     dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
     inputs = copy.deepcopy({k: v.clone() for k, v in dev.items()})
-    out = model(dev)
+    if prec is None:
+        with torch.inference_mode():              # Lightning's test / validate / predict loops (used to crash here)
+            out = model(dev)
+    else:
+        out = model(dev)
     assert out is dev
     for k in ("camera_mask", "pred_bbox", "regression_boxes", "pred_poses", "pred_intrinsics"):
         assert k in out
@@ -83,7 +102,7 @@ def test_unsupported_configs_raise():
 def test_reference_feature_cache_is_bit_identical(hip):
     """"next" row f1: encoding the references once and only the query per pose gives the same bits."""
     from boxdreamer_amd.cache import RefFeatureCache
-    for prec in ("bf16", "bf16x3"):
+    for prec in ("bf16", "bf16x3", "f16c8_qkv16", "f16c8"):
         model = BoxDreamer(_config(prec))
         model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
         model = model.cuda().eval()
@@ -122,6 +141,23 @@ def test_hip_graph_replay_matches_eager(hip):
         ref = model.decoder(bf, img, mask.cuda(), model.rgb_encoder.predict(img), None)
         rkp, _, ridx = hip_ops.decode_topk(ref)
         assert torch.equal(heat, ref) and torch.equal(kp, rkp) and torch.equal(idx, ridx)
+    # building a graph must not switch the decoder's one-hot mask check off for later eager use ...
+    assert model.decoder.validate_inputs is True
+    with pytest.raises(ValueError, match="exactly one query view"):
+        model.decoder(bf, img, torch.zeros(B, T, dtype=torch.bool, device="cuda"), model.rgb_encoder.predict(img), None)
+    # ... a live graph freezes the modules it captured raw pointers into (a larger eager batch would re-allocate the workspace) ...
+    big = synth.make_batch(seed=3, B=B + 2, T=T)
+    with pytest.raises(RuntimeError, match="GraphedPath"):
+        model.rgb_encoder.predict(big["images"].cuda())
+    # ... a SECOND graph on the same modules does not lift the first one's freeze when it is deleted, and deleting both does
+    g2 = GraphedPath(model.rgb_encoder, model.decoder, B, T, 224, torch.float32, "cuda")
+    del g2
+    import gc; gc.collect()
+    with pytest.raises(RuntimeError, match="GraphedPath"):
+        model.rgb_encoder.predict(big["images"].cuda())
+    del g
+    gc.collect()
+    assert model.rgb_encoder.predict(big["images"].cuda()).shape[0] == B + 2
 
 
 def test_two_batches_in_flight_match_one_at_a_time(hip):
@@ -156,8 +192,8 @@ def test_two_batches_in_flight_match_one_at_a_time(hip):
             assert torch.equal(g.out[0], heat0) and torch.equal(g.out[1], kp0)
 
 
-def _dense_model_and_batch(dense_cfg, B=2, T=7, seed=13):
-    cfg = _config("bf16x3")
+def _dense_model_and_batch(dense_cfg, B=2, T=7, seed=13, prec=STRICT_DEFAULT):
+    cfg = _config(prec)
     cfg["modules"]["dense_cfg"] = dense_cfg
     model = BoxDreamer(cfg)
     model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
@@ -175,7 +211,8 @@ def _dense_model_and_batch(dense_cfg, B=2, T=7, seed=13):
     return model, data
 
 
-def test_dense_mode_filter_path(hip):
+@pytest.mark.parametrize("prec", [STRICT_DEFAULT, "bf16x3"])
+def test_dense_mode_filter_path(hip, prec):
     """dense_cfg.enable + filter='dino' (BoxDreamerModel.py:291-330, data_processing.py:179-225): references are ranked
     by the HIP similarity kernel, the batch is re-packed (selected references in order, query last) and decoded once.
     The re-packed decode must equal the oracle run on the views the facade itself selected."""
@@ -183,7 +220,7 @@ def test_dense_mode_filter_path(hip):
     from oracle import dense_oracle as do
     k = 3
     model, data = _dense_model_and_batch({"enable": True, "filter": "dino", "filter_enable": True, "filter_topk": k,
-                                          "multi_round": False})
+                                          "multi_round": False}, prec=prec)
     B, T = data["images"].shape[:2]
     dev = {kk: (v.cuda() if torch.is_tensor(v) else v) for kk, v in data.items()}
     out = model(dev)
@@ -311,9 +348,10 @@ def test_configs2_substitute_b64_end_to_end(hip):
     """BASELINE configs[2] (LINEMOD eval, pretrained checkpoint, 5 references, batch 64, CPU PnP) needs files that are not
     available offline (checkpoint: run.py:172-183; data: configs/test.yaml:18-24).  SURVEY §8d's substitute: synthetic
     B = 64, T = 6 at FULL depth through the facade -> heatmaps -> corners -> host PnP, in the strict mode, with the oracle
-    on two of the 64 samples and batch-independence (bit-exact) on two more."""
-    cfg = _config("bf16x3", depth=12)
+    on two of the 64 samples and batch-independence (bit-exact) on two more.  Runs in the facade's DEFAULT mode."""
+    cfg = _config(None, depth=12)                   # the facade's default mode (f16c8_qkv16)
     model = BoxDreamer(cfg)
+    assert model.decoder.hip_precision == STRICT_DEFAULT
     model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 12).items()}, strict=True)
     model = model.cuda().eval()
     B, T = 64, 6

@@ -253,6 +253,50 @@ def test_gemm_fused_qk_rmsnorm(hip, prec, out_mode, M):
     assert err < 2 * eps * max(1.0, ref.abs().max().item()) + 1e-4, (prec, out_mode, err)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "f16c8"])
+def test_fused_qk_rmsnorm_refuses_odd_head_counts(hip, prec):
+    """with an odd head count (N = 3 x 3 x 96 = 864, not a multiple of the 192-column workgroup tile) the last column
+    tile's second 96-column wave tile lies past N and the fused branch has no column guard.  The geometry check must say "not
+    fused" (the whole-path entry points then run the separate bd_qk_rmsnorm kernel) and bd_gemm must reject rms_wq outright --
+    never write past column N.  A guard row/column around the output proves nothing was written outside."""
+    import ctypes as C
+    from boxdreamer_amd import _lib
+    heads, hd, K, M = 3, 96, 768, 700
+    N = 3 * heads * hd
+    a, w, b = _rand("a", (M, K)), _rand("w", (N, K), 0.05), _rand("b", (N,), 0.1)
+    wq, wk = (_rand("wq", (hd,), 0.1) + 1).cuda(), (_rand("wk", (hd,), 0.1) + 1).cuda()
+    e = hip_ops.f16c8_qexp(w) if prec == "f16c8" else 0
+    a16 = hip_ops.to_operand(a.cuda(), prec)
+    w16 = hip_ops.f16c8_encode(w.cuda(), e, True) if prec == "f16c8" else hip_ops.to_operand(w.cuda(), prec)
+    g = _lib.GemmArgs()
+    g.M, g.N, g.K = M, N, K
+    g.rms_wq, g.rms_wk, g.rms_eps = wq.data_ptr(), wk.data_ptr(), 1e-6
+    g.A, g.W, g.lda, g.ldw, g.ldo = a16.data_ptr(), w16.data_ptr(), K, K, N
+    assert _lib.load().bd_gemm_fuses_qk_rmsnorm(C.byref(g), _lib.prec_id(prec)) == 0
+    with pytest.raises(_lib.HipLibraryError, match="BD_ERR_SHAPE"):
+        hip_ops.gemm(a16, w16, b.cuda(), prec=prec, w_qexp=e, out_mode=2, rms=(wq, wk, 1e-6))
+    # the unfused pair still gives the right answer for this geometry: Linear (f16 plane out) + in-place q/k RMSNorm
+    out = hip_ops.gemm(a16, w16, b.cuda(), prec=prec, w_qexp=e, out_mode=2 if prec != "bf16" else None)
+    if prec == "bf16":
+        hip_ops.qk_rmsnorm_(out, wq, wk, 1e-6, heads, hd, prec="bf16")
+        got, eps = out.float().cpu(), EPS["bf16"]
+    else:
+        hip_ops.qk_rmsnorm_(out, wq, wk, 1e-6, heads, hd, prec="fp16")
+        got, eps = out.float().cpu(), 2.0 ** -11
+    if prec == "f16c8":
+        ah, al, aq = (t.cpu().double() for t in hip_ops.f16c8_decode(a16))
+        wh, wl, wqq = (t.cpu().double() for t in hip_ops.f16c8_decode(w16, e, True))
+        lin = ah @ wh.t() + al @ wqq.t() + aq @ wl.t() + b.double()
+    else:
+        lin = _q(a, prec).double() @ _q(w, prec).double().t() + b.double()
+    x = lin.reshape(M, 3, heads, hd)
+    ref = x.clone()
+    ref[:, 0] = wq.cpu().double() * (x[:, 0] * torch.rsqrt(x[:, 0].pow(2).mean(-1, keepdim=True) + 1e-6))
+    ref[:, 1] = wk.cpu().double() * (x[:, 1] * torch.rsqrt(x[:, 1].pow(2).mean(-1, keepdim=True) + 1e-6))
+    err = (got - ref.reshape(M, N).float()).abs().max().item()
+    assert err < 4 * eps * max(1.0, ref.abs().max().item()) + 1e-4, (prec, err)
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("batch,seq,heads,hd", [(2, 261, 12, 64), (2, 512, 8, 96), (1, 1536, 8, 96), (3, 70, 2, 64)])
 def test_attention(hip, prec, batch, seq, heads, hd):

@@ -257,6 +257,53 @@ def test_feature_operand_handoff_is_explicit():
     assert features.operand_of(f32, _lib.PREC_BF16) is None                      # modified in place: the copy is stale
 
 
+def test_feature_operand_handoff_under_inference_mode():
+    """Lightning's test / validate / predict loops run the model under torch.inference_mode(); tensors created there do not
+    track a version counter (reading `_version` raises), so the hand-off falls back to address + element count for them."""
+    from boxdreamer_amd import features
+    with torch.inference_mode():
+        f32 = torch.zeros(2, 3, 4, 5)
+        f16 = torch.zeros(2 * 3 * 4, 5, dtype=torch.bfloat16)
+        assert f32.is_inference()
+        features.attach(f32, f16, _lib.PREC_BF16)
+        assert features.operand_of(f32, _lib.PREC_BF16) is f16
+        assert features.tag_of(f32) == (f16, _lib.PREC_BF16)
+        v = f32.view(6, 4, 5)
+        assert features.operand_of(features.carry(f32, v), _lib.PREC_BF16) is f16
+        assert features.operand_of(features.carry(f32, f32.clone()), _lib.PREC_BF16) is None
+    # a tagged inference tensor read back outside inference mode still resolves
+    assert features.operand_of(f32, _lib.PREC_BF16) is f16
+
+
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "f16c8"])
+def test_reference_feature_cache_moves_every_operand_plane_in_its_own_layout(prec):
+    """F16C8's plane 1 is one e4m3 BYTE per element packed into the first rows*C bytes of the plane, not an
+    elementwise 16-bit plane; `place` / the merge must move it as byte rows.  Host-only check (torch ops): the operand copy of the
+    placed layout decodes, view by view, to the values of the views that were placed."""
+    from boxdreamer_amd import features, hip_ops
+    from boxdreamer_amd.cache import RefFeatureCache, _plane_views
+    B, R, P, C = 2, 3, 4, 64
+    T = R + 1
+    pid = _lib.operand_prec(prec)
+    x = torch.randn(B * R * P, C) * 3.0
+    f16 = hip_ops.to_operand(x, pid)
+    if pid == _lib.PREC_F16C8:                       # the encoder leaves the unused half of plane 1 uninitialised: poison it
+        f16[1].view(torch.uint8).reshape(-1)[B * R * P * C:] = 0x7F
+    ref = features.attach(x.reshape(B, R, P, C).clone(), f16, pid)
+    qidx = torch.tensor([1, 3])
+    full, valid = RefFeatureCache(None).place(ref, qidx, T)
+    got16, gpid = features.tag_of(full)
+    assert gpid == pid and valid.tolist() == [[True, False, True, True], [True, True, True, False]]
+    dec = hip_ops.from_operand(got16, pid).reshape(B, T, P, C)
+    want = hip_ops.from_operand(f16, pid).reshape(B * R, P, C)
+    assert torch.equal(dec[valid], want)
+    assert torch.equal(dec[~valid], torch.zeros(B, P, C))
+    assert torch.equal(full[valid], x.reshape(B * R, P, C))
+    if pid == _lib.PREC_F16C8:                       # nothing of the poisoned tail travelled
+        assert int(got16[1].view(torch.uint8).reshape(-1)[B * T * P * C:].max()) == 0
+    assert len(_plane_views(got16, pid, B * T, P, C)) == _lib.planes(pid)
+
+
 def test_precision_ids():
     assert _lib.prec_id("bf16x3_attn_x3") == 6 and _lib.prec_id("bf16x3_attn_f16") == 7
     for name in ("bf16x3", "bf16x3_attn_x3", "bf16x3_attn_f16"):
