@@ -42,8 +42,8 @@ DINO_FLOP_PER_IMAGE = 47_078_313_984          # BASELINE.md §4 / SURVEY.md §8(
 STRICT_PREC = "f16c8_qkv16"                     # the fastest mode whose logits meet the 1e-3 bar
 DTYPE_LABEL = {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3", "bf16x3_attn_x3": "bf16x3", "bf16x3_attn_f16": "bf16x3 (attention: f16)",
                "bf16x3_qkv16": "bf16x3 (BETR QKV: f16)", "f16c8": "f16 + e4m3 corrections",
-               "f16c8_qkv16": "f16 + e4m3 corrections (BETR QKV: f16)", "fp8": "fp8-e4m3 (Linears) + bf16 (attention)"}
-MFMA_PASSES = {"bf16x3": 3.0, "bf16x3_attn_x3": 3.0, "bf16x3_attn_f16": 3.0, "bf16x3_qkv16": 2.75, "f16c8": 2.0, "f16c8_qkv16": 1.9}
+               "f16c8_qkv16": "f16 + e4m3 corrections (BETR QKV: f16)", "f16c8_qk16": "f16 + e4m3 corrections (BETR q, k columns: f16)", "fp8": "fp8-e4m3 (Linears) + bf16 (attention)"}
+MFMA_PASSES = {"bf16x3": 3.0, "bf16x3_attn_x3": 3.0, "bf16x3_attn_f16": 3.0, "bf16x3_qkv16": 2.75, "f16c8": 2.0, "f16c8_qkv16": 1.9, "f16c8_qk16": 1.93}
 _PRECS = tuple(DTYPE_LABEL)
 
 
@@ -358,8 +358,8 @@ def kernel_source_sha() -> str:
 def algorithmic_gemm_bytes(prec: str, B: int, T: int) -> tuple[int, int]:
     """(bytes, bd_gemm calls) of one step if every GEMM read each operand ONCE and wrote its result once: A, W, fp32 residual in /
     result out, in the storage formats of the mode."""
-    a = {"bf16": 2, "fp16": 2, "fp8": 1, "f16c8": 3, "f16c8_qkv16": 3}.get(prec, 4)           # activation operand bytes / element
-    w = {"bf16": 2, "fp16": 2, "fp8": 1, "f16c8": 4, "f16c8_qkv16": 4}.get(prec, 4)           # weight bytes / element (F16C8: f16 + [q8|lo8])
+    a = {"bf16": 2, "fp16": 2, "fp8": 1, "f16c8": 3, "f16c8_qkv16": 3, "f16c8_qk16": 3}.get(prec, 4)           # activation operand bytes / element
+    w = {"bf16": 2, "fp16": 2, "fp8": 1, "f16c8": 4, "f16c8_qkv16": 4, "f16c8_qk16": 4}.get(prec, 4)           # weight bytes / element (F16C8: f16 + [q8|lo8])
     strict = prec not in ("bf16", "fp16", "fp8")
     total, calls = 0, 0
 

@@ -21,10 +21,11 @@ PREC_F16C8 = 8                                         # f16 + e4m3 corrections 
 PREC_F16_OUT_F16C8, PREC_BF16X3_OUT_F16C8 = 9, 10      # bd_attention[_q] only: f16 / split-bf16 attention, F16C8 operand out
 PREC_BF16X3_QKV16 = 11                                 # whole-path only: split-bf16, BETR's QKV Linear as one f16 pass
 PREC_F16C8_QKV16 = 12                                  # whole-path only: F16C8 Linears, BETR's QKV Linear as one f16 pass
+PREC_F16C8_QK16 = 13                                   # whole-path only: F16C8 Linears, BETR's QKV split: q, k one f16 pass, v F16C8
 F16C8_D = 11                                           # lo planes are scaled 2^D above their q plane
 PREC_NAMES = {"bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8,
               "bf16x3_attn_x3": PREC_BF16X3_ATTN_X3, "bf16x3_attn_f16": PREC_BF16X3_ATTN_F16, "f16c8": PREC_F16C8,
-              "bf16x3_qkv16": PREC_BF16X3_QKV16, "f16c8_qkv16": PREC_F16C8_QKV16}
+              "bf16x3_qkv16": PREC_BF16X3_QKV16, "f16c8_qkv16": PREC_F16C8_QKV16, "f16c8_qk16": PREC_F16C8_QK16}
 _X3_FAMILY = (PREC_BF16X3, PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16, 11)
 ACT_NONE, ACT_GELU = 0, 1
 # The precision a module runs when its config names none: the fastest mode that MEETS the path's parity bar (heatmap logits
@@ -50,7 +51,7 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("act", C.c_int),
                 ("rpg_in", C.c_int), ("rpg_out", C.c_int), ("row_off", C.c_int), ("w_qexp", C.c_int),
-                ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float)]
+                ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("rms_parts", C.c_int)]
 
 
 class Linear(C.Structure):
@@ -143,7 +144,7 @@ def load() -> C.CDLL:
     lib.bd_solve_pnp.argtypes = [vp, vp, vp, i, i, i, vp, vp]
     lib.bd_trace_begin.argtypes = [i]
     lib.bd_trace_end.argtypes = [C.POINTER(TraceRecord), i]
-    if lib.bd_abi_version() != 3:
+    if lib.bd_abi_version() != 4:
         raise HipLibraryError("libboxdreamer_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -181,7 +182,7 @@ def prec_id(prec) -> int:
 def operand_prec(prec) -> int:
     """Operand class of a (possibly whole-path) precision id: the value the unit operators and the weight packer take."""
     pid = prec_id(prec)
-    if pid == PREC_F16C8_QKV16:
+    if pid in (PREC_F16C8_QKV16, PREC_F16C8_QK16):
         return PREC_F16C8
     return PREC_BF16X3 if pid in _X3_FAMILY else pid
 
@@ -190,7 +191,7 @@ def op_dtype(prec) -> torch.dtype:
     pid = prec_id(prec)
     if pid == PREC_FP8:
         return torch.float8_e4m3fn          # OCP e4m3 (gfx950), not MI300's fnuz
-    return torch.float16 if pid in (PREC_F16, PREC_F16C8, PREC_F16C8_QKV16) else torch.bfloat16     # F16C8: plane 1 holds raw e4m3 bytes
+    return torch.float16 if pid in (PREC_F16, PREC_F16C8, PREC_F16C8_QKV16, PREC_F16C8_QK16) else torch.bfloat16     # F16C8: plane 1 holds raw e4m3 bytes
 
 
 def k_multiple(prec) -> int:
@@ -199,7 +200,7 @@ def k_multiple(prec) -> int:
 
 
 def planes(prec) -> int:
-    return 2 if prec_id(prec) in _X3_FAMILY or prec_id(prec) in (PREC_F16C8, PREC_F16C8_QKV16) else 1
+    return 2 if prec_id(prec) in _X3_FAMILY or prec_id(prec) in (PREC_F16C8, PREC_F16C8_QKV16, PREC_F16C8_QK16) else 1
 
 
 def dtype_id(t: torch.Tensor) -> int:

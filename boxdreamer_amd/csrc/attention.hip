@@ -56,6 +56,7 @@ __device__ __forceinline__ int vswz(int d) { return ((d >> 1) ^ (d >> 4)) & 7; }
 // the logits while the x3 attention kernel is register-bound at one wave per SIMD.
 template <class T, int NS, int HD, int NW, int OUTMODE = 0>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
+    bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 vec8;
     constexpr int NT = NW * 64;
     constexpr int DCH = HD / 8;                  // 16-byte chunks per K/V row
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnArgs p) {
 // attn_kernel's LDS images) at its end; K ring 2 tiles, V^T ring 4 tiles, ONE barrier per tile.
 template <class T, int HD, int OUTMODE>
 __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
+    bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 vec8;
     constexpr int NT = 512;
     constexpr int DCH = HD / 8;

@@ -110,9 +110,22 @@ template <> __device__ __forceinline__ void store_cvt<fp8e4, 4>(fp8e4* dst, cons
 //            ds_read_b128 and in the same order as the sixteen q8 bytes it derives from its own two f16 fragments
 //            (v_cvt_scalef32_pk_fp8_f16: q8 = e4m3(hi * 2^E), nothing stored).
 // Scales are fixed powers of two: E = 0 for activations, one exponent per weight tensor (bd_linear.w_qexp: max|w| 2^E <= 448),
-// D = 11; both cross terms carry 2^(E_w + D), undone by the MFMA's E8M0 block scales.  The scaled f16 -> e4m3 conversion does
-// NOT saturate (|hi| > 448 -> NaN), so producers clamp A-operand values to +-448 before splitting (far outside anything
-// LayerNorm, GELU or softmax-weighted sums produce here; split-bf16 remains for wider ranges).
+// D = 11; both cross terms carry 2^(E_w + D), undone by the MFMA's E8M0 block scales.
+// RANGE (round 3; round 2 clamped the whole activation to +-448, which is catastrophic on trained-like statistics -- LayerNorm
+// gains and massive-activation channels push single A-operand elements past 448, oracle/numerics_sim.py --outliers): the hi
+// plane keeps the full f16 range (producers clamp to +-65504 only), and the two e4m3 images SATURATE instead:
+//   q8 of A (derived in the GEMM's registers) = e4m3(clamp(hi, +-448)): an element beyond 448 loses accuracy only in its
+//       q_A . lo_W term, i.e. degrades to what a single f16 pass gives for that one element;
+//   lo8 = e4m3(clamp((x - hi) 2^D, +-448)): exact for |x| < 512, partially saturated beyond (f16's ulp there exceeds 448 / 2^D).
+// Saturation costs nothing: with MODE.FP16_OVFL set, gfx950's fp8 conversions (v_cvt_scalef32_pk_fp8_f16, v_cvt_pk_fp8_f32) clamp
+// to +-448 and f32 -> f16 conversions to +-65504 instead of producing NaN / inf (measured: tools/fp8_sat_probe.hip; an explicit
+// v_pk_max / v_pk_min pair per f16 pair in the GEMM's K loop cost 3.2 % of the strict step).  Every kernel that produces or consumes
+// the class calls bd_saturating_conversions() first; the mode is per-wave state and dies with the wave.
+__device__ __forceinline__ void bd_saturating_conversions() {
+#ifndef BD_EXP_NO_SAT          // (A/B builds only, tools/ab_build.sh)
+    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);      // hwreg(HW_REG_MODE, 23, 1) = MODE.FP16_OVFL
+#endif
+}
 struct f16c8 { unsigned short v; };              // storage element of either plane (never used arithmetically)
 #define BD_F16C8_D 11
 
@@ -239,7 +252,12 @@ template <int N>
 __device__ __forceinline__ void f16c8_split(const float (&v)[N], _Float16 (&hi)[N], float (&lo_scaled)[N]) {
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        const float c = __builtin_amdgcn_fmed3f(v[j], -448.0f, 448.0f);
+        // (MODE.FP16_OVFL is set by the calling kernel: hi saturates at +-65504, the e4m3 image of lo at +-448.)  The value is made
+        // opaque first, as in store_cvt: hi must be the rounding of the SAME fp32 number lo is taken against -- left alone, hipcc folds
+        // the producer's last multiply into the conversion in some contexts and not into the subtraction (op test: lo planes off by
+        // an f16 ulp in the attention epilogue).
+        float c = v[j];
+        asm("" : "+v"(c));
         hi[j] = (_Float16)c;
         lo_scaled[j] = (c - (float)hi[j]) * (float)(1 << BD_F16C8_D);
     }

@@ -19,7 +19,7 @@ struct Carver {
 
 inline int planes_of(int prec) {      // 2-byte units per element of a 16-bit operand buffer (F16C8: f16 plane + e4m3 plane)
     return (prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_BF16X3_ATTN_F16 ||
-            prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16C8 || prec == BD_PREC_F16C8_QKV16) ? 2 : 1;
+            prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16C8 || prec == BD_PREC_F16C8_QKV16 || prec == BD_PREC_F16C8_QK16) ? 2 : 1;
 }
 
 struct BlockBufs {
@@ -55,10 +55,37 @@ inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const
 //   BD_PREC_BF16X3_ATTN_F16  f16 attention everywhere (1.18e-3: the f16 Q.K^T on DINOv2's un-normalised q/k eats the whole
 //                            1e-3 budget -- kept for measurement, misses the bar)
 inline int gemm_prec(int prec) {
-    if (prec == BD_PREC_F16C8_QKV16) return BD_PREC_F16C8;
+    if (prec == BD_PREC_F16C8_QKV16 || prec == BD_PREC_F16C8_QK16) return BD_PREC_F16C8;
     return (prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_BF16X3_ATTN_F16 || prec == BD_PREC_BF16X3_QKV16) ? BD_PREC_BF16X3 : prec;
 }
 inline bool qkv_single_f16(int prec) { return prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16C8_QKV16; }
+inline bool qk_single_f16(int prec) { return prec == BD_PREC_F16C8_QK16; }
+
+// BD_PREC_F16C8_QK16: the QKV Linear of a block whose q, k are RMS-normalised, split by output column (include/boxdreamer_hip.h).
+// LayerNorm 1 emits the F16C8 operand; launch 1 multiplies its f16 plane with the f16 copy of the q, k weight rows (one MFMA pass,
+// q/k RMSNorm fused where the launch allows it), launch 2 is the full F16C8 product for the v rows.  q, k, v land in one f16
+// [M, 3D] buffer exactly as the single-launch forms lay them out.  Returns through *rms_fused whether q, k still need bd_qk_rmsnorm.
+int qkv_split_qk16(const bd_block_weights& w, const float* x, void* xn, void* qkv, int M, int D, int hd, float ln_eps, float rms_eps,
+                   bool* rms_fused, void* stream) {
+    const int64_t pD = (int64_t)M * D;
+    BD_TRY(bd_layernorm(x, D, w.ln1_w, w.ln1_b, ln_eps, xn, pD, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16C8, stream));
+    {
+        bd_gemm_args g = gemm_args(xn, D, 0, w.qkv16, D, 2 * D, qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);      // rows [0, 2D) of the f16 copy
+        g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps; g.rms_parts = 2;
+        *rms_fused = hd == 96 && bd_gemm_fuses_qk_rmsnorm(&g, BD_PREC_F16);
+        if (!*rms_fused) { g.rms_wq = g.rms_wk = nullptr; g.rms_parts = 0; }
+        BD_TRY(bd_gemm(&g, BD_PREC_F16, stream));
+    }
+    {
+        bd_linear v = w.qkv;                                      // rows [2D, 3D) of the F16C8 weight: both planes advance by 2D rows
+        v.w = (const unsigned short*)w.qkv.w + (int64_t)2 * D * D;
+        v.b = w.qkv.b + 2 * D;
+        bd_gemm_args g = gemm_args(xn, D, pD, v, D, D, (unsigned short*)qkv + 2 * D, 3 * D, 0, 2 /* f16 plane */, M, D, BD_ACT_NONE);
+        g.w_plane = (int64_t)3 * D * D;                           // plane 1 still lies one FULL weight plane behind plane 0
+        BD_TRY(bd_gemm(&g, BD_PREC_F16C8, stream));
+    }
+    return BD_OK;
+}
 inline bool x3_f16_attention(int prec, bool qk_normed) {
     return prec == BD_PREC_BF16X3_ATTN_F16 || ((prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_QKV16) && qk_normed);
 }
@@ -79,7 +106,9 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
     const int qkv_out = hyb ? 2 : (f8 ? 3 : (c8 ? 4 : 0));          // f16 plane / bf16 plane / split-bf16 planes / operand class
     bool rms_fused = false;
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D, p4D = (int64_t)M * 4 * D;
-    if (qkv_single_f16(wprec) && hyb && w.qkv16.w) {
+    if (qk_single_f16(wprec) && hyb && w.qkv16.w) {
+        BD_TRY(qkv_split_qk16(w, b.x, b.xn, b.qkv, M, D, hd, ln_eps, rms_eps, &rms_fused, stream));
+    } else if (qkv_single_f16(wprec) && hyb && w.qkv16.w) {
         // the one Linear that may leave the split scheme: f16 LayerNorm output x f16 weights, one pass, f16 q, k, v out
         BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, 0, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16, stream));
         bd_gemm_args g = gemm_args(b.xn, D, 0, w.qkv16, D, 3 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);
@@ -136,7 +165,9 @@ int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, flo
     bool rms_fused = false;
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D;
     const int64_t qD = (int64_t)Mq * D, q4D = (int64_t)Mq * 4 * D;
-    if (qkv_single_f16(wprec) && hyb && w.qkv16.w) {
+    if (qk_single_f16(wprec) && hyb && w.qkv16.w) {
+        BD_TRY(qkv_split_qk16(w, b.x, b.xn, b.qkv, M, D, hd, ln_eps, rms_eps, &rms_fused, stream));
+    } else if (qkv_single_f16(wprec) && hyb && w.qkv16.w) {
         // the one Linear that may leave the split scheme: f16 LayerNorm output x f16 weights, one pass, f16 q, k, v out
         BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, 0, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16, stream));
         bd_gemm_args g = gemm_args(b.xn, D, 0, w.qkv16, D, 3 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);
@@ -217,7 +248,7 @@ DecBufs carve_decoder(const bd_betr_weights* w, int B, int T, int prec, void* ws
 inline bool bad_prec(int prec) {
     return prec != BD_PREC_BF16 && prec != BD_PREC_F16 && prec != BD_PREC_BF16X3 && prec != BD_PREC_FP8 &&
            prec != BD_PREC_BF16X3_ATTN_X3 && prec != BD_PREC_BF16X3_ATTN_F16 && prec != BD_PREC_BF16X3_QKV16 &&
-           prec != BD_PREC_F16C8 && prec != BD_PREC_F16C8_QKV16;
+           prec != BD_PREC_F16C8 && prec != BD_PREC_F16C8_QKV16 && prec != BD_PREC_F16C8_QK16;
 }
 
 }  // namespace

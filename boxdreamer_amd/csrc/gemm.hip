@@ -317,7 +317,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
                 // 16-row pass and the 4 lanes of a row (one quad) combine their sums of squares: fp32 mean / rsqrt on the
                 // accumulators themselves, then the learned weight, then the 16-bit store.  Which third of the output this
                 // wave tile lies in (q: normalise with wq, k: with wk, v: untouched) is wave-uniform.
-                const int part = wn0 / (N / 3);
+                const int part = wn0 / (N / (p.rms_parts == 2 ? 2 : 3));
                 const float* rw = part == 0 ? p.rms_wq : (part == 1 ? p.rms_wk : nullptr);
                 float wv[3][8];
 #pragma unroll
@@ -396,6 +396,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
 // ------------------------------------------------------------------------------------------------
 template <class T, int NS, int BK, int WM, int WN, int MI, int NI>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gemm_args p) {
+    bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 frag_t;
     constexpr int ESZ = OpGeom<T>::ESZ, KSTEP = OpGeom<T>::KSTEP, CPF = OpGeom<T>::CPF;
     constexpr int NWAVE = WM * WN;
@@ -575,8 +576,8 @@ __device__ __forceinline__ float quad_sum(float x) {
 //   rmsw: q weights at [0, 96), k weights at [256, 352)
 //   wcol: first column of the wave tile inside the workgroup tile;  (wm0, wn0): its global origin
 //   next: the wave tile origin of this workgroup's next tile (EP 3 pre-loads its residual), has_next = there is one
-template <class T, int NS, int EP, int OUTK, bool GELU>
-__device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)[2][3], float* sc, const float* colp, const float* colp_next,
+template <class T, int NS, int EP, int OUTK, bool GELU, int MI = 2>
+__device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)[MI][3], float* sc, const float* colp, const float* colp_next,
                                             const float* rmsw, int wcol, int wm0, int wn0, int lane, bool has_next, int nwm0, int nwn0) {
     constexpr int COLS = 96;
     const int lrow = lane & 31, lhalf = lane >> 5;
@@ -609,7 +610,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
             }
         }
 #pragma unroll
-        for (int ih = 0; ih < 4; ++ih) {
+        for (int ih = 0; ih < 2 * MI; ++ih) {
             const int i = ih >> 1, hc = ih & 1;
             to_scratch(i, hc);
             // these accumulator registers are free now: the next tile's residual (or zero) goes in
@@ -649,7 +650,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
         // (192-byte runs).  Same values, same roundings as the fp32 staging (the conversion is the separate step of store_cvt).
         unsigned* sp = (unsigned*)sc;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -704,7 +705,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
         bool norm = false;
         if constexpr (EP == 2) {
             // the 96-column wave tile IS one head (host-checked); which third of the output it lies in is wave-uniform
-            const int part = wn0 / (p.N / 3);
+            const int part = wn0 / (p.N / (p.rms_parts == 2 ? 2 : 3));
             norm = part < 2;
 #pragma unroll
             for (int cb = 0; cb < 3; ++cb) {
@@ -715,7 +716,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
             }
         }
 #pragma unroll
-        for (int ih = 0; ih < 4; ++ih) {
+        for (int ih = 0; ih < 2 * MI; ++ih) {
             const int i = ih >> 1, hc = ih & 1;
             to_scratch(i, hc);
 #pragma unroll
@@ -761,6 +762,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
 
 template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NPW, int EP, int OUTK, bool GELU>
 __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const bd_gemm_args p) {
+    bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 frag_t;
     constexpr int ESZ = OpGeom<T>::ESZ, KSTEP = OpGeom<T>::KSTEP, CPF = OpGeom<T>::CPF;
     constexpr int NCW = WM * WN;                      // consumer waves; waves NCW .. NCW + NPW - 1 are producers
@@ -774,9 +776,9 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
     constexpr int KS = BK / KSTEP;
     static_assert(KS >= 1 && CH * 16 == ROWB && (CH == 4 || CH == 8) && A_BYTES % 1024 == 0 && W_BYTES % 1024 == 0, "slab geometry");
     static_assert(PA % NPW == 0 && PW % NPW == 0, "pieces split evenly over the producer waves");
-    constexpr int SR = (NCW * 32 * NI * 32 * 4 <= STAGE_BYTES) ? 32 : 16;      // LDS-staged epilogue: scratch rows per pass
+    constexpr int SR = (EP == 0 && NCW * 32 * NI * 32 * 4 <= STAGE_BYTES) ? 32 : 16;      // LDS-staged epilogue: scratch rows per pass
     static_assert(NCW * SR * NI * 32 * 4 <= STAGE_BYTES, "the epilogue scratch must fit one stage");
-    static_assert(EP == 0 || (MI == 2 && NI == 3 && SR == 16 && TBN <= 256), "pc_epilogue is written for the 64 x 96 wave tile");
+    static_assert(EP == 0 || ((MI == 2 || MI == 4) && NI == 3 && SR == 16 && TBN <= 256), "pc_epilogue is written for 96-column wave tiles");
     // side buffer behind the ring: per-column vectors of the current / next tile (2 x [bias 1 KiB | weight scale 1 KiB]) and
     // the q / k RMSNorm weights (2 x 1 KiB)
     constexpr int AUX_COLP = 2 * STAGE_BYTES, AUX_RMS = AUX_COLP + 4096, AUX_BYTES = EP == 0 ? 0 : 6144;
@@ -945,7 +947,36 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                \
                     LOAD_ONE(b[slot][s2][j], base + NS * A_BYTES + s2 * W_BYTES, wn * (NI * 32) + j * 32 + lrow, ks) \
             }
-            if constexpr (NS == 1) {
+            if constexpr (NS == 1 && MI == 4) {
+                // 128 x 96 wave tile (ONE consumer wave per SIMD, four per workgroup: the vendor GEMM's shape -- 7 fragment reads feed 12
+                // MFMAs per k-step, 0.58 LDS reads per MFMA against 0.83 for the 64 x 96 tile; profiles/r2_hipblaslt_reference.md).
+                // 192 accumulator registers leave room for ONE set of A fragments and two of W fragments, so MFMAs go row by row
+                // (i outer): after the three MFMAs of row i its A fragment is dead and the NEXT k-step's A fragment of that row is
+                // loaded into the same registers; the next W fragments ride under the first three MFMAs.  Order pinned as below.
+                static_assert(NI == 3, "row-major MFMA order below is written for 3 column tiles");
+                frag_t a1[MI], b2[2][NI];
+                LOAD_ONE(a1[0], base, wm * (MI * 32) + lrow, 0)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) LOAD_ONE(b2[0][j], base + NS * A_BYTES, wn * (NI * 32) + j * 32 + lrow, 0)
+#pragma unroll
+                for (int i = 1; i < MI; ++i) LOAD_ONE(a1[i], base, wm * (MI * 32) + i * 32 + lrow, 0)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int cur = ks & 1;
+                    const bool more = ks + 1 < KS;
+#pragma unroll
+                    for (int q = 0; q < MI * NI; ++q) {
+                        const int i = q / NI, j = q % NI;
+                        acc[i][j] = Op16<T>::mfma(a1[i], b2[cur][j], acc[i][j]);
+                        if (more) {
+                            if (q < NI) LOAD_ONE(b2[cur ^ 1][q], base + NS * A_BYTES, wn * (NI * 32) + q * 32 + lrow, ks + 1)
+                            if (j == NI - 1) LOAD_ONE(a1[i], base, wm * (MI * 32) + i * 32 + lrow, ks + 1)
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else if constexpr (NS == 1) {
                 // Software pipeline inside the slab, order PINNED (sched_barrier(0) after every MFMA / ds_read pair): the
                 // fragment reads of k-step ks+1 are interleaved one-for-one with the MFMAs of k-step ks, so a consumer wave
                 // keeps its matrix pipe fed on its own.  (With producers doing the DMA, both consumer waves of a SIMD leave the
@@ -1050,7 +1081,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 const bool has_next = t + stride < t_end;
                 int nm0 = 0, nn0 = 0;
                 if (has_next) tile_origin(t + stride, nm0, nn0);
-                pc_epilogue<T, NS, EP, OUTK, GELU>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
+                pc_epilogue<T, NS, EP, OUTK, GELU, MI>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
                                                   (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
                                                   lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
             }
@@ -1094,6 +1125,7 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
     constexpr int AUX_COLP = 2 * STAGE + SCRATCH, AUX_RMS = AUX_COLP + 4096, AUX_BYTES = EP == 0 ? 0 : 6144;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE + SCRATCH + AUX_BYTES];   // stages at 0, STAGE, 2*STAGE; scratch at 2*STAGE
 
+    bd_saturating_conversions();      // q8 images (K loop) and F16C8 / f16 results (epilogue) saturate instead of turning NaN / inf
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = p.M, N = p.N;
@@ -1253,18 +1285,21 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
                 const u128 hi_ = *(const u128*)((ptr) + (row) * 64 + (swz_chunk<4>((row), 2 * lhalf + 1) << 4));    \
                 dst = (i32x8){(int)lo_[0], (int)lo_[1], (int)lo_[2], (int)lo_[3], (int)hi_[0], (int)hi_[1], (int)hi_[2], (int)hi_[3]}; \
             }
-            // e4m3 image of one f16 A fragment (8 values of a k-step), 2 dwords; scale 1.0 (activations are clamped to +-448).
+            // e4m3 image of one f16 A fragment (8 values of a k-step), 2 dwords; scale 1.0.  The wave runs with MODE.FP16_OVFL set
+            // (bd_saturating_conversions): the conversion clamps to +-448, so an activation beyond 448 keeps its full value in the f16
+            // pass and only its q_A . lo_W correction term is computed from 448 (bd_common.h, RANGE).
             // (pairs built element-wise: __builtin_bit_cast of a vector ELEMENT to a 2 x f16 vector is miscompiled by hipcc 7.2
             // here -- every conversion then reads the first dword)
+#define Q8P(f, a, b) ((h2_){f[a], f[b]})
 #define Q8H(d0, d1, f)                                                                                        \
             {                                                                                                     \
                 typedef _Float16 h2_ __attribute__((ext_vector_type(2)));                                         \
                 typedef short s2_ __attribute__((ext_vector_type(2)));                                            \
                 s2_ a_ = {0, 0}, b_ = {0, 0};                                                                     \
-                a_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(a_, (h2_){f[0], f[1]}, 1.0f, false);                \
-                a_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(a_, (h2_){f[2], f[3]}, 1.0f, true);                 \
-                b_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b_, (h2_){f[4], f[5]}, 1.0f, false);                \
-                b_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b_, (h2_){f[6], f[7]}, 1.0f, true);                 \
+                a_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(a_, Q8P(f, 0, 1), 1.0f, false);                     \
+                a_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(a_, Q8P(f, 2, 3), 1.0f, true);                      \
+                b_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b_, Q8P(f, 4, 5), 1.0f, false);                     \
+                b_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b_, Q8P(f, 6, 7), 1.0f, true);                      \
                 d0 = __builtin_bit_cast(unsigned, a_);                                                            \
                 d1 = __builtin_bit_cast(unsigned, b_);                                                            \
             }
@@ -1309,6 +1344,7 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
 #undef LD16
 #undef LDLO
 #undef Q8H
+#undef Q8P
         }
         BD_PROBE_IF(g == nk, 60)
         pc_barrier();                                     // X
@@ -1424,7 +1460,8 @@ inline bool uses_pc192(const bd_gemm_args& a, int ns, int esz, int cus) {
 // past N, and the fused branch stores whole 96-column heads without a column guard
 inline bool rms_geometry_ok(const bd_gemm_args& a) {
     return a.rms_wq && a.rms_wk && a.out_f32 != OUT_F32 && a.act == BD_ACT_NONE && !a.resid && !a.addtab && a.rpg_in <= 0 &&
-           a.N % 3 == 0 && (a.N / 3) % 96 == 0 && a.N % 192 == 0 && (((uintptr_t)a.rms_wq | (uintptr_t)a.rms_wk) & 3) == 0;
+           (a.rms_parts == 0 || a.rms_parts == 2 || a.rms_parts == 3) &&
+           a.N % (a.rms_parts == 2 ? 2 : 3) == 0 && (a.N / (a.rms_parts == 2 ? 2 : 3)) % 96 == 0 && a.N % 192 == 0 && (((uintptr_t)a.rms_wq | (uintptr_t)a.rms_wk) & 3) == 0;
 }
 
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {
@@ -1463,7 +1500,12 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
                 launch_glds<T, NS, BK, 2, 2, 2, 2>(rest, s);
 #endif
             } else {
+#if defined(BD_PC_WAVES4)      // A/B build: four consumer waves of 128 x 96 (one per SIMD) instead of eight of 64 x 96
+                if constexpr (NS == 1 && sizeof(T) == 2) launch_pc<T, NS, BK, 2, 2, 4, 3>(a, s, kCUs);
+                else launch_pc<T, NS, BK, 4, 2, 2, 3>(a, s, kCUs);
+#else
                 launch_pc<T, NS, BK, 4, 2, 2, 3>(a, s, kCUs);
+#endif
             }
             bd_trace_close(s, slot);
             BD_CHECK_LAUNCH();

@@ -8,6 +8,7 @@ namespace {
 template <class T, int NS>
 __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ img, int dtype, void* __restrict__ out_,
                                                      int64_t plane, int n_images, int size, int patch, int kpad) {
+    bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     T* out = (T*)out_;
     const int grid = size / patch, pp = patch * patch, kreal = 3 * pp, cpr = kpad / 8;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ im
 template <class T, int NS>
 __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ heat, int dtype, void* __restrict__ out_,
                                                        int64_t plane, int n_images, int size, int patch, int kpad) {
+    bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     T* out = (T*)out_;
     const int grid = size / patch, pp = patch * patch, cpr = kpad / 8;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256) void query_sub_kernel(float* __restrict__ x, c
 template <class T, int NS>
 __global__ __launch_bounds__(256) void gather_query_kernel(const float* __restrict__ x, const int32_t* __restrict__ qidx,
                                                            void* __restrict__ out_, int64_t plane, int B, int T_, int P, int dim) {
+    bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     T* out = (T*)out_;
     const int cpr = dim / 8;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;

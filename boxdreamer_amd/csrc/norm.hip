@@ -12,6 +12,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         T* __restrict__ out16, int64_t out16_plane,
                                                         float* __restrict__ out32, int64_t ldo, int rows,
                                                         int cols, int rpg_in, int rpg_out, int row_off) {
+    bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_kernel(T* __restrict__ qkv, in
                                                          const float* __restrict__ wq,
                                                          const float* __restrict__ wk, float eps,
                                                          int rows, int heads) {
+    bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 vec8;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)rows * 2 * heads;
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_row_kernel(T* __restrict__ qkv
                                                              const float* __restrict__ wq,
                                                              const float* __restrict__ wk, float eps,
                                                              int rows, int heads) {
+    bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 vec8;
     constexpr int NC = EPL / 8, LPV = HD / EPL;
     static_assert(EPL % 8 == 0 && HD % EPL == 0 && (LPV & (LPV - 1)) == 0, "row split");

@@ -42,14 +42,12 @@ def _f16c8_perm(K: int, device) -> torch.Tensor:
 
 def f16c8_encode(x: torch.Tensor, qexp: int = 0, weight: bool = False) -> torch.Tensor:
     """fp32 [rows, K] (K % 32 == 0) -> [2, rows, K] float16 STORAGE of the F16C8 operand class (include/boxdreamer_hip.h):
-    plane 0 = f16(x) (activations clamped to +-448 first); plane 1 = raw bytes:
+    plane 0 = f16(x) (clamped to f16's finite range only); plane 1 = raw bytes (both e4m3 images saturate at +-448):
       activations: the first rows*K bytes are the lo8 plane e4m3((x - hi) 2^D), k-permuted per 32-block (rest unused);
       weights:     per 32-block 64 bytes = for each lane half h: [q8 x 16 | lo8 x 16] of its sixteen k (same k order),
                    q8 = e4m3(hi 2^E), lo8 = e4m3((w - hi) 2^(E + D)).
     Torch ops: weight packing at load time and test helpers (not on the hot path)."""
-    x = x.float()
-    if not weight:
-        x = x.clamp(-E4M3_MAX, E4M3_MAX)
+    x = x.float().clamp(-65504.0, 65504.0)
     rows, K = x.shape
     assert K % 32 == 0, "F16C8 operands are laid out in 32-element blocks"
     hi = x.half()
@@ -80,7 +78,7 @@ def f16c8_decode(t: torch.Tensor, qexp: int = 0, weight: bool = False):
         lo = dec(mix[:, :, 1].reshape(rows, K)) * 2.0 ** -(qexp + _lib.F16C8_D)
     else:
         lo = dec(raw[: rows * K].reshape(rows, K)) * 2.0 ** -(qexp + _lib.F16C8_D)
-        q = (hi * 2.0 ** qexp).to(torch.float8_e4m3fn).float() * 2.0 ** -qexp     # derived by the GEMM in registers
+        q = (hi * 2.0 ** qexp).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).float() * 2.0 ** -qexp     # derived by the GEMM in registers (saturating)
     return hi, lo, q
 
 
@@ -139,8 +137,9 @@ def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, add
     g.out, g.ldo, g.out_f32 = ptr(out), o2.stride(0), mode
     g.out_plane = out[0].numel() if mode == 4 else (0 if mode else _plane(out, prec))
     g.w_qexp = int(w_qexp)
-    if rms is not None:                      # (wq, wk, eps): fused q/k RMSNorm of a QKV Linear
+    if rms is not None:                      # (wq, wk, eps[, parts]): fused q/k RMSNorm of a QKV Linear ([q | k | v] columns, or [q | k])
         g.rms_wq, g.rms_wk, g.rms_eps = ptr(rms[0]), ptr(rms[1]), float(rms[2])
+        g.rms_parts = int(rms[3]) if len(rms) > 3 else 0
     g.M, g.N, g.K, g.act = M, N, K, act
     g.rpg_in, g.rpg_out, g.row_off = rpg
     check(lib.bd_gemm(C.byref(g), prec_id(prec), stream()), "bd_gemm")

@@ -142,6 +142,121 @@ def dino_state_dict(seed: int = 4321, depth: int = 12, dim: int = 768, nheads: i
     return sd
 
 
+# --------------------------------------------------------------------------- "trained-like" statistics
+# Random N(0, 0.02^2) weights keep every activation O(1-10).  Trained DINOv2 / BETR checkpoints do not: ViTs develop a few
+# "massive activation" channels in the residual stream (hundreds, fed by single MLP hidden units with very large
+# pre-activations), LayerNorm gains with outliers, and attention logits with a large dynamic range.  These variants graft
+# such statistics onto the seeded weights (same key names, deterministic) so that the 16-bit / e4m3 operand classes of the
+# strict mode can be checked against the fp32 oracle where their range limits (f16: 65504, e4m3: 448) actually bite.
+# Reference modules whose operands are affected: src/models/sources/DINOv2/layers/block.py:89-114 (norm1 / norm2 -> attn / mlp),
+# layers/mlp.py:34-40 (fc1 -> GELU -> fc2), src/models/modules/backbone/utils/blocks.py:243-302 (q / k RMSNorm gains).
+
+OUTLIER_CHANNELS = (137, 481)          # residual-stream channels that carry the massive activations
+OUTLIER_HIDDEN = (5, 77, 1999, 3000)   # MLP hidden units with very large pre-activations
+
+
+def _scale_rows(sd, key, rows, f):
+    w = sd[key].clone()
+    w[list(rows)] *= f
+    sd[key] = w
+
+
+def dino_state_dict_outliers(seed: int = 4321, depth: int = 12, gain: float = 1.0, **kw) -> dict:
+    """dino_state_dict + trained-like outliers (gain = 1: LayerNorm outputs reach ~800 and GELU outputs several hundred, i.e.
+    beyond e4m3's 448; gain < 1 scales the grafts down)."""
+    sd = dino_state_dict(seed, depth, **kw)
+    g = float(gain)
+    blk = lambda i: f"blocks.{min(i, depth - 1)}"
+    # (1) two massive-activation channels: one early MLP writes hundreds into them
+    _scale_rows(sd, blk(1) + ".mlp.fc2.weight", OUTLIER_CHANNELS, 60.0 * g)
+    b = sd[blk(1) + ".mlp.fc2.bias"].clone(); b[list(OUTLIER_CHANNELS)] += 3.0 * g; sd[blk(1) + ".mlp.fc2.bias"] = b
+    # (2) LayerNorm gains: most later norms damp the massive channels (as trained nets do), one does the opposite, and a few
+    #     ordinary channels carry large gains
+    for i in range(2, depth):
+        for nm in (".norm1.weight", ".norm2.weight"):
+            _scale_rows(sd, blk(i) + nm, OUTLIER_CHANNELS, 0.05)
+    if depth > 4:
+        _scale_rows(sd, blk(4) + ".norm2.weight", OUTLIER_CHANNELS[:1], 20.0 * 30.0 * g)       # undo the damping, then x30
+        _scale_rows(sd, blk(7) + ".norm1.weight", (23, 300, 655), 30.0 * g)
+    # (3) MLP hidden units with huge pre-activations (-> GELU outputs in the hundreds feeding fc2's A operand)
+    _scale_rows(sd, blk(min(6, depth - 1)) + ".mlp.fc1.weight", OUTLIER_HIDDEN, 40.0 * g)
+    _scale_rows(sd, blk(min(9, depth - 1)) + ".mlp.fc1.weight", OUTLIER_HIDDEN[:2], 100.0 * g)
+    # (4) attention logits with a large dynamic range: a few q / k feature rows x8
+    _scale_rows(sd, blk(min(3, depth - 1)) + ".attn.qkv.weight", (0, 1, 70, 768 + 0, 768 + 1, 768 + 70), 8.0 * g)
+    return sd
+
+
+def betr_state_dict_outliers(seed: int = 1234, depth: int = 12, gain: float = 1.0, **kw) -> dict:
+    """betr_state_dict + trained-like outliers: LayerNorm gains, MLP hidden units, q / k RMSNorm gains, one massive channel."""
+    sd = betr_state_dict(seed, depth, **kw)
+    g = float(gain)
+    blk = lambda i: f"attn.{min(i, depth - 1)}"
+    _scale_rows(sd, blk(1) + ".mlp.fc2.weight", OUTLIER_CHANNELS[1:], 60.0 * g)
+    for i in range(2, depth):
+        for nm in (".norm1.weight", ".norm2.weight"):
+            _scale_rows(sd, blk(i) + nm, OUTLIER_CHANNELS[1:], 0.05)
+    if depth > 3:
+        _scale_rows(sd, blk(3) + ".norm2.weight", OUTLIER_CHANNELS[1:], 20.0 * 30.0 * g)
+        _scale_rows(sd, blk(min(5, depth - 1)) + ".norm1.weight", (11, 402), 30.0 * g)
+    _scale_rows(sd, blk(min(2, depth - 1)) + ".mlp.fc1.weight", OUTLIER_HIDDEN, 40.0 * g)
+    _scale_rows(sd, blk(min(8, depth - 1)) + ".mlp.fc1.weight", OUTLIER_HIDDEN[2:], 100.0 * g)
+    _scale_rows(sd, blk(min(4, depth - 1)) + ".attn.q_norm.weight", (3, 40), 4.0 * g)
+    _scale_rows(sd, blk(min(4, depth - 1)) + ".attn.k_norm.weight", (3, 40), 4.0 * g)
+    _scale_rows(sd, "input_transform.fc1.weight", (9, 500), 40.0 * g)
+    return sd
+
+
+def rescale_function_preserving(dino_sd: dict, betr_sd: dict, s_norm: float = 256.0, s_v: float = 64.0, s_qk: float = 32.0):
+    """Operand-RANGE stress that leaves the network's function unchanged: power-of-two gains moved between a producer and its only
+    consumer, so every fp32 product is the same number scaled by a power of two and the fp32 forward is (bit for bit, barring
+    under / overflow) the forward of the original weights -- while the 16-bit / e4m3 operands see LayerNorm outputs up to ~1000,
+    weight columns down to ~1e-4 next to ordinary ones in the same tensor, attention values x64 and DINOv2 q / k features x32 / 32:
+      * LayerNorm gain and shift of a few channels x s_norm, the consuming Linear's columns / s_norm   (norm1 -> qkv, norm2 -> fc1,
+        DINOv2's final norm -> BETR's adapter fc1);
+      * value features x s_v (qkv rows + bias), proj columns / s_v   (attention output is linear in v);
+      * DINOv2 only (BETR RMS-normalises q, k): q feature x s_qk, the same k feature / s_qk  (logits unchanged).
+    Returns new (dino_sd, betr_sd)."""
+    d, b = {k: v.clone() for k, v in dino_sd.items()}, {k: v.clone() for k, v in betr_sd.items()}
+
+    def chans(tag, n, count, i):
+        return sorted({int(c) for c in (uniform_np(f"rescale.{tag}.{i}", (count,), 0.0, float(n), 97) // 1)})
+
+    def norm_to_linear(sd, norm, lin, cs, f):
+        sd[norm + ".weight"][cs] *= f
+        if norm + ".bias" in sd:
+            sd[norm + ".bias"][cs] *= f
+        sd[lin + ".weight"][:, cs] /= f
+
+    def stack(sd, prefix, depth, dim, qk: bool):
+        for i in range(depth):
+            p = f"{prefix}{i}"
+            norm_to_linear(sd, p + ".norm1", p + ".attn.qkv", chans("n1" + prefix, dim, 6, i), s_norm)
+            norm_to_linear(sd, p + ".norm2", p + ".mlp.fc1", chans("n2" + prefix, dim, 6, i), s_norm)
+            vj = chans("v" + prefix, dim, 5, i)
+            rows = [2 * dim + j for j in vj]
+            sd[p + ".attn.qkv.weight"][rows] *= s_v
+            sd[p + ".attn.qkv.bias"][rows] *= s_v
+            sd[p + ".attn.proj.weight"][:, vj] /= s_v
+            if qk:
+                qj = chans("q" + prefix, dim, 5, i)
+                sd[p + ".attn.qkv.weight"][qj] *= s_qk
+                sd[p + ".attn.qkv.bias"][qj] *= s_qk
+                kr = [dim + j for j in qj]
+                sd[p + ".attn.qkv.weight"][kr] /= s_qk
+                sd[p + ".attn.qkv.bias"][kr] /= s_qk
+
+    dim = d["cls_token"].shape[-1]
+    ddepth = 1 + max(int(k.split(".")[1]) for k in d if k.startswith("blocks."))
+    bdepth = 1 + max(int(k.split(".")[1]) for k in b if k.startswith("attn."))
+    stack(d, "blocks.", ddepth, dim, qk=True)
+    stack(b, "attn.", bdepth, dim, qk=False)
+    cn = chans("final", dim, 6, 0)
+    d["norm.weight"][cn] *= s_norm
+    d["norm.bias"][cn] *= s_norm
+    b["input_transform.fc1.weight"][:, cn] /= s_norm
+    return d, b
+
+
 # --------------------------------------------------------------------------- inputs
 
 def corner_heatmaps_np(corners: np.ndarray, size: int) -> np.ndarray:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define BD_ABI_VERSION 3
+#define BD_ABI_VERSION 4
 
 #define BD_DTYPE_BF16 0
 #define BD_DTYPE_F16 1
@@ -67,7 +67,8 @@ extern "C" {
  * points.  NOT by bd_attention[_q] / bd_qk_rmsnorm (BD_ERR_DTYPE): attention runs on an f16 plane or on split-bf16 planes and
  * EMITS the class through BD_PREC_F16_OUT_F16C8 / BD_PREC_BF16X3_OUT_F16C8 below.
  * Storage of an operand [rows][K], K % 32 == 0, ld % 32 == 0; "plane" = 2-byte units between plane 0 and plane 1:
- *   plane 0                f16 hi = f16(x), row-major, 2 bytes per element (activations: x clamped to +-448 first).
+ *   plane 0                f16 hi = f16(x), row-major, 2 bytes per element (full f16 range; the e4m3 images below SATURATE at
+ *                          +-448, so an element beyond 448 degrades towards single-f16-pass accuracy instead of being clipped).
  *   plane 1, ACTIVATIONS   lo8 = e4m3((x - hi) * 2^11): ONE byte per element, rows of `ld` BYTES packed into the first rows*ld
  *                          bytes of the plane (the rest of the plane's storage is unused); inside every 32-element block the
  *                          byte at 16 h + 8 a + j holds k = 16 a + 8 h + j (a, h < 2, j < 8).  q8 = e4m3(hi) is derived by the
@@ -81,6 +82,13 @@ extern "C" {
 /*   BD_PREC_F16C8_QKV16      whole-path only: BD_PREC_F16C8 Linears with BD_PREC_BF16X3_QKV16's exception (BETR's QKV Linear as ONE f16
  *                            pass on an f16 LayerNorm output; needs bd_block_weights.qkv16): round 2's fastest mode inside 1e-3. */
 #define BD_PREC_F16C8_QKV16 12
+/*   BD_PREC_F16C8_QK16       whole-path only (round 3's default): BD_PREC_F16C8 Linears; in the blocks whose q, k are RMS-normalised
+ *                            (BETR) the QKV Linear is split by output column: q, k (2/3 of the columns) as ONE f16 pass on the f16
+ *                            plane of the F16C8 LayerNorm output, v as a full F16C8 product.  Column-wise sensitivity
+ *                            (tools/policy_sim.py): the whole 5e-4 a single-pass QKV costs comes from the v columns; q, k -- normalised
+ *                            right away and consumed through a softmax -- cost 2e-5.  1.33 pass-equivalents for that Linear
+ *                            instead of 1 (QKV16) or 2 (F16C8), logits error 1.9e-4 instead of 5.9e-4.  Needs bd_block_weights.qkv16. */
+#define BD_PREC_F16C8_QK16 13
 #define BD_PREC_F16_OUT_F16C8 9     /* bd_attention[_q] only: f16 qkv (one plane) in, one f16 MFMA pass, F16C8 operand out */
 #define BD_PREC_BF16X3_OUT_F16C8 10 /* bd_attention[_q] only: split-bf16 qkv planes in, split-bf16 attention, F16C8 operand out */
 
@@ -129,6 +137,8 @@ typedef struct bd_gemm_args {
      * accumulators, before the 16-bit store (no extra rounding, no separate pass over qkv).  Only where the launch uses 256 x 192
      * tiles (each wave tile is one head); bd_gemm returns BD_ERR_SHAPE otherwise -- ask bd_gemm_fuses_qk_rmsnorm first. */
     const float* rms_wq; const float* rms_wk; float rms_eps;
+    int rms_parts;                                 /* with rms_wq: 0 or 3 = output columns are [q | k | v] (v untouched); 2 = [q | k] only
+                                                      (a QKV Linear split into a q,k launch and a v launch, BD_PREC_F16C8_QK16) */
 } bd_gemm_args;
 int bd_gemm(const bd_gemm_args* args /*[host]*/, int prec, void* stream);
 /* 1 if bd_gemm(args, prec) with args->rms_wq set would fuse the q/k RMSNorm (tile shape and head geometry fit), else 0. */

@@ -102,10 +102,18 @@ def make_linear(scheme: str):
         wq, wl = e4m3(w * 2.0 ** sw) * 2.0 ** -sw, e4m3((w - wh) * 2.0 ** (sw + D)) * 2.0 ** -(sw + D)
         return F.linear(xh, wh) + F.linear(xl, wq) + F.linear(xq, wl) + (0 if b is None else b)
 
-    table = {"f16c8fix": lin_f16c8_fixed, "bf16x3": lin_bf16x3, "f16": lin_16(torch.float16), "bf16": lin_16(torch.bfloat16),
+    def lin_f16c8_clamp448(x, w, b):
+        """Round 2's kernel: the producer clamped the WHOLE activation to +-448 (hi plane included)."""
+        return lin_f16c8_fixed(x.clamp(-448.0, 448.0), w, b)
+
+    table = {"f16c8fix": lin_f16c8_fixed, "f16c8clamp": lin_f16c8_clamp448, "bf16x3": lin_bf16x3, "f16": lin_16(torch.float16), "bf16": lin_16(torch.bfloat16),
              "f16c8": lin_f16c("e4m3"), "f16c6": lin_f16c("e2m3"), "f16c4": lin_f16c("e2m1"),
              "f16a8": lin_f16c_one("e4m3"), "fp32": lambda x, w, b: F.linear(x, w, b)}
     return table[scheme]
+
+
+POLICY = {}     # optional per-call override (see _FShim.linear)
+STATS = {}      # range of the A operands seen by the emulated Linears (reset by run())
 
 
 class _FShim(types.ModuleType):
@@ -119,6 +127,15 @@ class _FShim(types.ModuleType):
         return getattr(F, name)
 
     def linear(self, x, w, b=None):
+        STATS["max_abs_A"] = max(STATS.get("max_abs_A", 0.0), float(x.abs().max()))
+        STATS["n_over_448"] = STATS.get("n_over_448", 0) + int((x.abs() > 448).sum())
+        if callable(POLICY.get("fn")):      # per-call scheme selection: fn(kind, index, x, w, b) -> result or None (= the default scheme)
+            kind = {(2304, 768): "qkv", (768, 768): "proj768", (3072, 768): "fc1", (768, 3072): "fc2"}.get(tuple(w.shape), "other")
+            n = STATS.get("n_" + kind, 0)
+            STATS["n_" + kind] = n + 1
+            y = POLICY["fn"](kind, n, x.float(), w.float(), b)
+            if y is not None:
+                return y
         return self._lin(x.float(), w.float(), b)
 
     def conv2d(self, x, w, b, stride):
@@ -132,6 +149,7 @@ class _FShim(types.ModuleType):
 
 def run(scheme: str, data, bsd, dsd):
     old = orc.F
+    STATS.clear()
     orc.F = _FShim(make_linear(scheme))
     try:
         with torch.no_grad():
@@ -146,9 +164,16 @@ def main():
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--schemes", default="bf16x3,f16,f16c8,f16c8fix,f16c6,f16c4,f16a8")
+    ap.add_argument("--outliers", type=float, default=0.0, help="gain of the trained-like outlier grafts (synth.*_outliers); 0 = plain")
+    ap.add_argument("--rescale", action="store_true", help="function-preserving operand-range stress (synth.rescale_function_preserving)")
     a = ap.parse_args()
     torch.set_num_threads(8)
-    bsd, dsd = synth.betr_state_dict(1234, a.depth), synth.dino_state_dict(4321, a.depth)
+    if a.outliers > 0:
+        bsd, dsd = synth.betr_state_dict_outliers(1234, a.depth, a.outliers), synth.dino_state_dict_outliers(4321, a.depth, a.outliers)
+    else:
+        bsd, dsd = synth.betr_state_dict(1234, a.depth), synth.dino_state_dict(4321, a.depth)
+    if a.rescale:
+        dsd, bsd = synth.rescale_function_preserving(dsd, bsd)
     data = synth.make_batch(seed=a.seed, B=1, T=a.views)
     with torch.no_grad():
         ref = orc.boxdreamer_forward(data, bsd, dsd)
@@ -159,7 +184,8 @@ def main():
         err = (o["logits"] - ref["logits"]).abs()
         same = (o["topk_idx"].sort(-1)[0] == ref["topk_idx"].sort(-1)[0]).all(-1).float().mean().item()
         print(f"{s:8s} logits max-abs err {err.max():.3e}  rms {err.pow(2).mean().sqrt():.3e}  feats err "
-              f"{(o['rgb_feat'] - ref['rgb_feat']).abs().max():.3e}  top20 sets equal {same:.2f}  ({time.time() - t0:.1f}s)")
+              f"{(o['rgb_feat'] - ref['rgb_feat']).abs().max():.3e}  top20 sets equal {same:.2f}  max|A| {STATS.get('max_abs_A', 0):.0f} "
+              f"(> 448: {STATS.get('n_over_448', 0)})  ({time.time() - t0:.1f}s)")
         sys.stdout.flush()
 
 

@@ -253,6 +253,29 @@ def test_gemm_fused_qk_rmsnorm(hip, prec, out_mode, M):
     assert err < 2 * eps * max(1.0, ref.abs().max().item()) + 1e-4, (prec, out_mode, err)
 
 
+@pytest.mark.parametrize("M", [300, 6144])
+def test_gemm_fused_qk_rmsnorm_two_parts(hip, M):
+    """rms_parts = 2: the q, k launch of a column-split QKV Linear (BD_PREC_F16C8_QK16): N = 2 x heads x 96 output columns, BOTH halves
+    normalised (q with wq, k with wk), written with the full [q | k | v] row stride next to a v block that must stay untouched."""
+    heads, hd, K = 8, 96, 768
+    D = heads * hd
+    a, w, b = _rand("a", (M, K)), _rand("w", (2 * D, K), 0.05), _rand("b", (2 * D,), 0.1)
+    wq, wk = (_rand("wq", (hd,), 0.1) + 1).cuda(), (_rand("wk", (hd,), 0.1) + 1).cuda()
+    a16, w16 = hip_ops.to_operand(a.cuda(), "fp16"), hip_ops.to_operand(w.cuda(), "fp16")
+    full = torch.full((M, 3 * D), 7.0, dtype=torch.float16, device="cuda")
+    out = full[:, : 2 * D]                                   # a view with row stride 3 D
+    hip_ops.gemm(a16, w16, b.cuda(), prec="fp16", out=out, rms=(wq, wk, 1e-6, 2))
+    lin = _q(a, "fp16").double() @ _q(w, "fp16").double().t() + b.double()
+    x = lin.reshape(M, 2, heads, hd)
+    ref = x.clone()
+    ref[:, 0] = wq.cpu().double() * (x[:, 0] * torch.rsqrt(x[:, 0].pow(2).mean(-1, keepdim=True) + 1e-6))
+    ref[:, 1] = wk.cpu().double() * (x[:, 1] * torch.rsqrt(x[:, 1].pow(2).mean(-1, keepdim=True) + 1e-6))
+    got = full[:, : 2 * D].float().cpu()
+    err = (got - ref.reshape(M, 2 * D).float()).abs().max().item()
+    assert err < 2 * 2.0 ** -11 * max(1.0, ref.abs().max().item()) + 1e-4, err
+    assert torch.equal(full[:, 2 * D:], torch.full((M, D), 7.0, dtype=torch.float16, device="cuda"))
+
+
 @pytest.mark.parametrize("prec", ["bf16", "bf16x3", "f16c8"])
 def test_fused_qk_rmsnorm_refuses_odd_head_counts(hip, prec):
     """with an odd head count (N = 3 x 3 x 96 = 864, not a multiple of the 192-column workgroup tile) the last column

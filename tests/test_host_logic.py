@@ -180,7 +180,7 @@ def test_c_abi_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.bd_abi_version() == 3 and lib.bd_target_arch() == b"gfx950"
+    assert lib.bd_abi_version() == 4 and lib.bd_target_arch() == b"gfx950"
     # argument validation happens before any launch: NULL / bad shapes are rejected on a GPU-less box
     g = _lib.GemmArgs()
     assert lib.bd_gemm(ctypes.byref(g), 0, None) == -5
@@ -311,12 +311,13 @@ def test_precision_ids():
     assert _lib.operand_prec("fp8") == _lib.PREC_FP8 and _lib.planes("fp8") == 1
     # the strict family of round 2: f16 + e4m3-correction operand class and its whole-path variant with BETR's single-pass qkv
     assert _lib.prec_id("f16c8") == 8 and _lib.prec_id("bf16x3_qkv16") == 11 and _lib.prec_id("f16c8_qkv16") == 12
-    for name in ("f16c8", "f16c8_qkv16"):
+    assert _lib.prec_id("f16c8_qk16") == 13
+    for name in ("f16c8", "f16c8_qkv16", "f16c8_qk16"):
         assert _lib.planes(name) == 2 and _lib.operand_prec(name) == _lib.PREC_F16C8 and _lib.op_dtype(name) == torch.float16
     assert _lib.operand_prec("bf16x3_qkv16") == _lib.PREC_BF16X3
     hdr = open(os.path.join(ROOT, "include", "boxdreamer_hip.h")).read()
     for name, val in (("BD_PREC_BF16X3_ATTN_X3", 6), ("BD_PREC_BF16X3_ATTN_F16", 7), ("BD_PREC_F16C8", 8), ("BD_PREC_BF16X3_QKV16", 11),
-                      ("BD_PREC_F16C8_QKV16", 12), ("BD_ABI_VERSION", 3)):
+                      ("BD_PREC_F16C8_QKV16", 12), ("BD_PREC_F16C8_QK16", 13), ("BD_ABI_VERSION", 4)):
         assert re.search(rf"#define {name} {val}\b", hdr), name
     # the library keeps no environment switches: nothing under csrc/ reads the environment
     for f in os.listdir(os.path.join(ROOT, "boxdreamer_amd", "csrc")):
