@@ -31,7 +31,7 @@ ACT_NONE, ACT_GELU = 0, 1
 # The precision a module runs when its config names none: the fastest mode that MEETS the path's parity bar (heatmap logits
 # within 1e-3 of the fp32 CPU forward, identical top-20 sets).  "bf16" -- the reference's own `precision`, 4e-2 off its fp32
 # forward -- is the explicit throughput opt-in (`hip_precision: bf16` in the decoder / encoder config, or $BOXDREAMER_HIP_PREC).
-DEFAULT_PREC = "f16c8_qkv16"
+DEFAULT_PREC = "f16c8_qk16"
 
 _ERR = {-1: "BD_ERR_SHAPE", -2: "BD_ERR_DTYPE", -3: "BD_ERR_ALIGN", -4: "BD_ERR_WORKSPACE", -5: "BD_ERR_NULL"}
 
@@ -51,7 +51,9 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("act", C.c_int),
                 ("rpg_in", C.c_int), ("rpg_out", C.c_int), ("row_off", C.c_int), ("w_qexp", C.c_int),
-                ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("rms_parts", C.c_int)]
+                ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("rms_parts", C.c_int),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+                ("ln_out", C.c_void_p), ("ln_out_plane", C.c_int64), ("ln_sync", C.c_void_p)]
 
 
 class Linear(C.Structure):
@@ -93,7 +95,7 @@ EXPORTS = [
     "bd_gather_query_tokens", "bd_unpatchify_sigmoid", "bd_decode_topk",
     "bd_encoder_workspace_bytes", "bd_encoder_forward", "bd_decoder_workspace_bytes", "bd_decoder_forward",
     "bd_trace_begin", "bd_trace_end", "bd_render_corner_heatmaps", "bd_attention_q", "bd_gather_query_rows_f32",
-    "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm",
+    "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm", "bd_gemm_fuses_layernorm",
 ]
 
 _lib = None
@@ -120,6 +122,7 @@ def load() -> C.CDLL:
     lib.bd_target_arch.restype = C.c_char_p
     lib.bd_gemm.argtypes = [C.POINTER(GemmArgs), i, vp]
     lib.bd_gemm_fuses_qk_rmsnorm.argtypes = [C.POINTER(GemmArgs), i]
+    lib.bd_gemm_fuses_layernorm.argtypes = [C.POINTER(GemmArgs), i]
     lib.bd_layernorm.argtypes = [vp, i64, vp, vp, f, vp, i64, vp, i64, i, i, i, i, i, i, vp]
     lib.bd_qk_rmsnorm.argtypes = [vp, i64, vp, vp, f, i, i, i, i, vp]
     lib.bd_attention.argtypes = [vp, i64, vp, i64, i, i, i, i, f, i, vp]

@@ -293,6 +293,70 @@ __device__ __forceinline__ void f16c8_store4(f16c8* base, int64_t plane, int64_t
     *(int*)((unsigned char*)(base + plane) + f16c8_lo_index(e & ~(int64_t)7) + (e & 4)) = l0;
 }
 
+// ---- LayerNorm of ONE row by ONE wave64 (fp32 statistics, two-pass variance as nn.LayerNorm computes it): a row of <= 1024 fp32
+// lives in 4 float4 registers per lane (lane l owns columns (i*64 + l)*4 .. +3).  Shared by the stand-alone kernel (norm.hip) and
+// by the persistent GEMMs' fused form (gemm.hip: the workgroup that completes a 256-row panel of the residual stream normalises
+// it), so both produce the same bits.  NT: non-temporal row loads (stand-alone kernel: the stream is far larger than the L2s).
+template <class T, int NS, bool NT>
+__device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float eps, T* __restrict__ out16, int64_t out16_plane, float* __restrict__ out32_row,
+                                       int64_t orow, int cols, int lane) {
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            f32x4 t_;
+            if constexpr (NT) t_ = __builtin_nontemporal_load((const f32x4*)(xr + c));
+            else t_ = *(const f32x4*)(xr + c);
+            v[i] = make_float4(t_[0], t_[1], t_[2], t_[3]);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            float y[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd,
+                          (v[i].w - mean) * rstd};
+            if (gamma) {
+                const float4 g = *(const float4*)(gamma + c);
+                y[0] *= g.x; y[1] *= g.y; y[2] *= g.z; y[3] *= g.w;
+            }
+            if (beta) {
+                const float4 bb = *(const float4*)(beta + c);
+                y[0] += bb.x; y[1] += bb.y; y[2] += bb.z; y[3] += bb.w;
+            }
+            if (out32_row) *(float4*)(out32_row + c) = make_float4(y[0], y[1], y[2], y[3]);
+            if (out16) {
+                if constexpr (__is_same(T, f16c8)) {
+                    f16c8_store4(out16, out16_plane, orow * cols + c, y);
+                } else if constexpr (NS == 2) {
+                    float hi4[4], lo4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { hi4[j] = to_f32<T>(from_f32<T>(y[j])); lo4[j] = y[j] - hi4[j]; }
+                    store_cvt<T, 4>(out16 + orow * cols + c, hi4);
+                    store_cvt<T, 4>(out16 + out16_plane + orow * cols + c, lo4);
+                } else {
+                    store_cvt<T, 4>(out16 + orow * cols + c, y);
+                }
+            }
+        }
+    }
+}
+
 // trace.hip
 int bd_trace_open(hipStream_t s, int kind, int M, int N, int K);
 void bd_trace_close(hipStream_t s, int slot);

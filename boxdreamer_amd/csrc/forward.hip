@@ -28,6 +28,8 @@ struct BlockBufs {
     void* qkv;       // 16-bit               [M, 3D]
     void* ao;        // 16-bit attention out [M, D]
     void* h;         // 16-bit MLP hidden    [M, 4D]
+    int* ln_sync;    // int32 [ceil(M / 256)] panel counters of the fused LayerNorm (zeroed once per forward; the kernels leave them zero)
+    size_t ln_sync_bytes;
 };
 
 inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const bd_linear& lin, int64_t ldw, int N,
@@ -66,9 +68,9 @@ inline bool qk_single_f16(int prec) { return prec == BD_PREC_F16C8_QK16; }
 // q/k RMSNorm fused where the launch allows it), launch 2 is the full F16C8 product for the v rows.  q, k, v land in one f16
 // [M, 3D] buffer exactly as the single-launch forms lay them out.  Returns through *rms_fused whether q, k still need bd_qk_rmsnorm.
 int qkv_split_qk16(const bd_block_weights& w, const float* x, void* xn, void* qkv, int M, int D, int hd, float ln_eps, float rms_eps,
-                   bool* rms_fused, void* stream) {
+                   bool ln1_ready, bool* rms_fused, void* stream) {
     const int64_t pD = (int64_t)M * D;
-    BD_TRY(bd_layernorm(x, D, w.ln1_w, w.ln1_b, ln_eps, xn, pD, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16C8, stream));
+    if (!ln1_ready) BD_TRY(bd_layernorm(x, D, w.ln1_w, w.ln1_b, ln_eps, xn, pD, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16C8, stream));
     {
         bd_gemm_args g = gemm_args(xn, D, 0, w.qkv16, D, 2 * D, qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);      // rows [0, 2D) of the f16 copy
         g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps; g.rms_parts = 2;
@@ -86,14 +88,26 @@ int qkv_split_qk16(const bd_block_weights& w, const float* x, void* xn, void* qk
     }
     return BD_OK;
 }
+// LayerNorm of a residual GEMM's result rows inside that launch (include/boxdreamer_hip.h: bd_gemm_args.ln_*): attach it when the
+// launch can run it (persistent kernel), else leave the arguments alone -- the caller then runs bd_layernorm as before (same bits).
+inline bool try_fuse_layernorm(bd_gemm_args& g, const float* gamma, const float* beta, float eps, void* out, int64_t plane, int* sync,
+                               int prec) {
+    g.ln_gamma = gamma; g.ln_beta = beta; g.ln_eps = eps; g.ln_out = out; g.ln_out_plane = plane; g.ln_sync = sync;
+    if (bd_gemm_fuses_layernorm(&g, prec)) return true;
+    g.ln_gamma = g.ln_beta = nullptr; g.ln_out = nullptr; g.ln_sync = nullptr; g.ln_out_plane = 0;
+    return false;
+}
+
 inline bool x3_f16_attention(int prec, bool qk_normed) {
     return prec == BD_PREC_BF16X3_ATTN_F16 || ((prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_QKV16) && qk_normed);
 }
 
 // One pre-LN transformer block: x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x))).
 // BETR: blocks.py:876-886 (+ q/k RMSNorm :257); DINOv2: layers/block.py:89-114 (LayerScale folded).
-int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, int seq, int D, int heads,
-              float ln_eps, float rms_eps, int wprec, void* stream) {
+// `ln1_ready`: in: LayerNorm 1 of THIS block already sits in b.xn (the previous block's fc2 launch produced it); out: whether this
+// block's fc2 launch produced LayerNorm 1 of `next` (nullptr: nothing follows in this form).
+int run_block(const bd_block_weights& w, const bd_block_weights* next, bool& ln1_ready, const BlockBufs& b, int M, int batch, int seq,
+              int D, int heads, float ln_eps, float rms_eps, int wprec, void* stream) {
     const int hd = D / heads;
     const int prec = gemm_prec(wprec);
     const bool c8 = prec == BD_PREC_F16C8;    // f16 + e4m3-correction Linears; attention as in BD_PREC_BF16X3
@@ -107,9 +121,10 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
     bool rms_fused = false;
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D, p4D = (int64_t)M * 4 * D;
     if (qk_single_f16(wprec) && hyb && w.qkv16.w) {
-        BD_TRY(qkv_split_qk16(w, b.x, b.xn, b.qkv, M, D, hd, ln_eps, rms_eps, &rms_fused, stream));
+        BD_TRY(qkv_split_qk16(w, b.x, b.xn, b.qkv, M, D, hd, ln_eps, rms_eps, ln1_ready, &rms_fused, stream));
     } else if (qkv_single_f16(wprec) && hyb && w.qkv16.w) {
         // the one Linear that may leave the split scheme: f16 LayerNorm output x f16 weights, one pass, f16 q, k, v out
+        // (its LayerNorm output is an f16 plane, not the operand class: never produced by the previous block's fc2 launch)
         BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, 0, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16, stream));
         bd_gemm_args g = gemm_args(b.xn, D, 0, w.qkv16, D, 3 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);
         g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
@@ -117,7 +132,7 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
         if (!rms_fused) g.rms_wq = g.rms_wk = nullptr;
         BD_TRY(bd_gemm(&g, BD_PREC_F16, stream));
     } else {
-        BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
+        if (!ln1_ready) BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
         bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, qkv_out, M, D, BD_ACT_NONE);
         if (w.q_norm_w && hd == 96) {            // q/k RMSNorm in the QKV epilogue where the launch allows it
             g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
@@ -126,21 +141,29 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
         }
         BD_TRY(bd_gemm(&g, prec, stream));
     }
+    ln1_ready = false;
     if (w.q_norm_w && !rms_fused) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, aprec_in, stream));
     BD_TRY(bd_attention(b.qkv, p3D, b.ao, pD, batch, seq, heads, hd, 1.0f / sqrtf((float)hd), aprec, stream));
+    bool ln2_fused = false;
     {
+        // proj + residual; LayerNorm 2 of the new stream rides in the same launch where it runs the persistent kernel
         bd_gemm_args g = gemm_args(b.ao, D, pD, w.proj, D, D, b.x, D, 0, 1, M, D, BD_ACT_NONE);
         g.resid = b.x; g.ldr = D;
+        ln2_fused = try_fuse_layernorm(g, w.ln2_w, w.ln2_b, ln_eps, b.xn, pD, b.ln_sync, prec);
         BD_TRY(bd_gemm(&g, prec, stream));
     }
-    BD_TRY(bd_layernorm(b.x, D, w.ln2_w, w.ln2_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
+    if (!ln2_fused) BD_TRY(bd_layernorm(b.x, D, w.ln2_w, w.ln2_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
     {
         bd_gemm_args g = gemm_args(b.xn, D, pD, w.fc1, D, 4 * D, b.h, 4 * D, p4D, 0, M, D, BD_ACT_GELU);
         BD_TRY(bd_gemm(&g, prec, stream));
     }
     {
+        // fc2 + residual; the NEXT block's LayerNorm 1 rides along (its output is the operand class unless that block's QKV runs
+        // as one f16 pass on an f16 LayerNorm output)
         bd_gemm_args g = gemm_args(b.h, 4 * D, p4D, w.fc2, 4 * D, D, b.x, D, 0, 1, M, 4 * D, BD_ACT_NONE);
         g.resid = b.x; g.ldr = D;
+        const bool next_f16_ln = qkv_single_f16(wprec) && next && next->q_norm_w && next->qkv16.w && hyb;
+        if (next && !next_f16_ln) ln1_ready = try_fuse_layernorm(g, next->ln1_w, next->ln1_b, ln_eps, b.xn, pD, b.ln_sync, prec);
         BD_TRY(bd_gemm(&g, prec, stream));
     }
     return BD_OK;
@@ -150,7 +173,7 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
 // LN1 + QKV (+ q/k RMSNorm) run on all rows; attention takes queries from the query view's P rows and writes a
 // compact [B*P, D] result; proj, LN2 and the MLP then run on B*P rows (1/T of the work).  Row-wise arithmetic is
 // unchanged, so the result is bit-identical to the full-width block.  xc: fp32 [B*P, D] compact residual stream.
-int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, float* xc, const int32_t* query_idx, int B,
+int run_last_block_query_only(const bd_block_weights& w, bool ln1_ready, const BlockBufs& b, float* xc, const int32_t* query_idx, int B,
                               int T, int P, int D, int heads, float ln_eps, float rms_eps, int wprec, void* stream) {
     const int hd = D / heads, M = B * T * P, Mq = B * P;
     const int prec = gemm_prec(wprec);
@@ -166,7 +189,7 @@ int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, flo
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D;
     const int64_t qD = (int64_t)Mq * D, q4D = (int64_t)Mq * 4 * D;
     if (qk_single_f16(wprec) && hyb && w.qkv16.w) {
-        BD_TRY(qkv_split_qk16(w, b.x, b.xn, b.qkv, M, D, hd, ln_eps, rms_eps, &rms_fused, stream));
+        BD_TRY(qkv_split_qk16(w, b.x, b.xn, b.qkv, M, D, hd, ln_eps, rms_eps, ln1_ready, &rms_fused, stream));
     } else if (qkv_single_f16(wprec) && hyb && w.qkv16.w) {
         // the one Linear that may leave the split scheme: f16 LayerNorm output x f16 weights, one pass, f16 q, k, v out
         BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, 0, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16, stream));
@@ -176,7 +199,7 @@ int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, flo
         if (!rms_fused) g.rms_wq = g.rms_wk = nullptr;
         BD_TRY(bd_gemm(&g, BD_PREC_F16, stream));
     } else {
-        BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
+        if (!ln1_ready) BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
         bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, qkv_out, M, D, BD_ACT_NONE);
         if (w.q_norm_w && hd == 96) {            // q/k RMSNorm in the QKV epilogue where the launch allows it
             g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
@@ -213,6 +236,8 @@ BlockBufs carve_block(Carver& c, int64_t M, int D, int np) {
     b.qkv = c.take((size_t)M * 3 * D * 2 * np);
     b.ao = c.take((size_t)M * D * 2 * np);
     b.h = c.take((size_t)M * 4 * D * 2 * np);
+    b.ln_sync_bytes = (size_t)((M + 255) / 256) * 4;
+    b.ln_sync = (int*)c.take(b.ln_sync_bytes);
     return b;
 }
 
@@ -288,8 +313,11 @@ extern "C" int bd_encoder_forward(const bd_dino_weights* w, const void* images, 
         BD_TRY(bd_gemm(&g, prec, stream));
     }
     BD_TRY(bd_write_prefix_tokens(e.blk.x, w->prefix_tokens, n_images, tpi, w->n_prefix, D, stream));
+    if (hipMemsetAsync(e.blk.ln_sync, 0, e.blk.ln_sync_bytes, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
+    bool ln1_ready = false;
     for (int i = 0; i < w->depth; ++i)
-        BD_TRY(run_block(w->blocks[i], e.blk, Md, n_images, tpi, D, w->heads, w->ln_eps, 0.f, wprec, stream));
+        BD_TRY(run_block(w->blocks[i], i + 1 < w->depth ? &w->blocks[i + 1] : nullptr, ln1_ready, e.blk, Md, n_images, tpi, D, w->heads,
+                         w->ln_eps, 0.f, wprec, stream));
     // final LayerNorm on the patch tokens only (vision_transformer.py:263-267)
     BD_TRY(bd_layernorm(e.blk.x, D, w->norm_w, w->norm_b, w->ln_eps, feats16, feats16_plane, feats32, D, Mp, D, P, tpi,
                         w->n_prefix, prec, stream));
@@ -340,10 +368,12 @@ extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_fea
     }
     BD_TRY(bd_query_substitute(d.blk.x, d.rgb, w->pos_table, w->query_token, query_idx, B, T, P, D, stream));
     // K9: joint self-attention over all T*P tokens of a sample
+    if (hipMemsetAsync(d.blk.ln_sync, 0, d.blk.ln_sync_bytes, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
+    bool ln1_ready = false;
     for (int i = 0; i + 1 < w->depth; ++i)
-        BD_TRY(run_block(w->blocks[i], d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, wprec, stream));
+        BD_TRY(run_block(w->blocks[i], &w->blocks[i + 1], ln1_ready, d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, wprec, stream));
     // last block: query-view rows only past the K/V projection; d.t2 (dead since the adapter) holds the compact stream
-    BD_TRY(run_last_block_query_only(w->blocks[w->depth - 1], d.blk, d.t2, query_idx, B, T, P, D, w->heads,
+    BD_TRY(run_last_block_query_only(w->blocks[w->depth - 1], ln1_ready, d.blk, d.t2, query_idx, B, T, P, D, w->heads,
                                      w->ln_eps, w->rms_eps, wprec, stream));
     // K10: head on the query view's tokens (no final norm, betr.py:298-306)
     BD_TRY(bd_gather_query_tokens(d.t2, nullptr, d.qtok, (int64_t)Mq * D, B, 1, P, D, prec, stream));

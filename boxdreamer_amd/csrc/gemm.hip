@@ -760,7 +760,41 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
     }
 }
 
-template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NPW, int EP, int OUTK, bool GELU>
+// Fused LayerNorm of a finished row panel (LNF kernels, EP 3: the fp32 result IS the residual stream).  Called by every consumer wave
+// after its epilogue.  Protocol (agent scope, placement-independent): each wave releases its stores; workgroup barrier Y1 (producers
+// take part: they idle there instead of at the next tile's first slab barrier); one lane counts the tile in on the panel's counter
+// and learns whether it was the panel's last column tile; barrier Y2 hands that flag to all waves through one LDS word; the last
+// workgroup acquires and normalises the panel, rows split over the consumer waves, each row by one wave exactly as
+// norm.hip does (ln_row: same bits).  The counter goes back to zero for the next launch.  The release costs nothing extra: an
+// EP-3 consumer already waits for its stores at the first MFMA of the next tile (in-order vmcnt behind the residual pre-loads).
+template <class T, int NS, int NCW, int TBM>
+__device__ __forceinline__ void fused_panel_layernorm(const bd_gemm_args& p, unsigned* flag_lds, int m0, int tilesN, int wid, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    pc_barrier();                                  // Y1: every consumer wave's part of the tile is visible device-wide
+    if (wid == 0 && lane == 0) {
+        int* cnt = p.ln_sync + m0 / TBM;
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = old == tilesN - 1;
+        if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *(volatile unsigned*)flag_lds = last;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (pc_barrier is a bare s_barrier: the LDS word must have landed)
+    }
+    pc_barrier();                                  // Y2
+    if (*(volatile unsigned*)flag_lds) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        constexpr int RPW = TBM / NCW;             // rows per consumer wave
+        const float* x = (const float*)p.out;
+#pragma unroll 2
+        for (int k = 0; k < RPW; ++k) {
+            const int r = m0 + wid * RPW + k;
+            if (r < p.M)
+                ln_row<T, NS, false>(x + (int64_t)r * p.ldo, p.ln_gamma, p.ln_beta, p.ln_eps, (T*)p.ln_out, p.ln_out_plane, nullptr,
+                                     (int64_t)r, p.N, lane);
+        }
+    }
+}
+
+template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NPW, int EP, int OUTK, bool GELU, bool LNF = false>
 __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const bd_gemm_args p) {
     bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 frag_t;
@@ -896,6 +930,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 ++g;
             }
             pc_barrier();                              // X: every consumer is done with the tile's last slab
+            if constexpr (LNF) { pc_barrier(); pc_barrier(); }      // Y1, Y2 of fused_panel_layernorm
         }
 #ifdef BD_GEMM_PROBE
         if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * 16 + wid) * 64 + lane] = probe_ts;
@@ -1084,6 +1119,10 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 pc_epilogue<T, NS, EP, OUTK, GELU, MI>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
                                                   (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
                                                   lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
+                if constexpr (LNF) {
+                    static_assert(!LNF || EP == 3, "the fused LayerNorm follows the fp32 residual epilogue");
+                    fused_panel_layernorm<T, NS, NCW, TBM>(p, (unsigned*)(lds + AUX_RMS), m0, tilesN, wid, lane);
+                }
             }
         }
         BD_PROBE_IF(g == nk, 62)
@@ -1113,7 +1152,7 @@ inline bool wide_epilogue_ok(const bd_gemm_args& p, int ns) {
 //     slab in this operand class, is off the critical path.  NSTAGE = 2 (scratch separate) serves the other K.
 //   * the e4m3 image q8 of an f16 fragment derived in registers (v_cvt_scalef32_pk_fp8_f16, 4 per fragment), so the
 //     correction pass costs one extra ds_read_b128 per 32-row fragment pair instead of two.
-template <int NSTAGE, int EP, int OUTK, bool GELU>
+template <int NSTAGE, int EP, int OUTK, bool GELU, bool LNF = false>
 __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_args p) {
     constexpr int WM = 4, WN = 2, MI = 2, NI = 3, NPW = 4, NCW = WM * WN;
     constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32, BK = 32;
@@ -1236,6 +1275,7 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
                 ++g;
             }
             pc_barrier();                                 // X: consumers are done with the tile's last slab (scratch = stage 2 ..)
+            if constexpr (LNF) { pc_barrier(); pc_barrier(); }         // Y1, Y2 of fused_panel_layernorm
         }
 #ifdef BD_GEMM_PROBE
         if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * 16 + wid) * 64 + lane] = probe_ts;
@@ -1359,6 +1399,10 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
             pc_epilogue<f16c8, 2, EP, OUTK, GELU>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
                                                  (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
                                                  lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
+            if constexpr (LNF) {
+                static_assert(!LNF || EP == 3, "the fused LayerNorm follows the fp32 residual epilogue");
+                fused_panel_layernorm<f16c8, 2, NCW, TBM>(p, (unsigned*)(lds + AUX_RMS), m0, tilesN, wid, lane);
+            }
         }
         BD_PROBE_IF(g == nk, 62)
     }
@@ -1388,6 +1432,13 @@ template <class T, int NS> int pc_epilogue_kind(const bd_gemm_args& a, int& outk
     return 1;
 }
 
+// a fused LayerNorm needs: the fp32 residual result over complete rows of <= 1024 columns in 192-column tiles, identity row map
+inline bool ln_geometry_ok(const bd_gemm_args& a) {
+    return a.ln_out && a.ln_sync && a.out_f32 == OUT_F32 && a.act == BD_ACT_NONE && !a.addtab && a.rpg_in <= 0 && !a.rms_wq &&
+           a.N % 192 == 0 && a.N <= 1024 && a.ldo == a.N && (a.ln_out_plane % 8) == 0 &&
+           (((uintptr_t)a.ln_out | (uintptr_t)a.ln_gamma | (uintptr_t)a.ln_beta) & 15) == 0 && ((uintptr_t)a.ln_sync & 3) == 0;
+}
+
 template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_pc(const bd_gemm_args& a, hipStream_t s, int cus) {
     constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32;
     constexpr int NPW = 4;        // one producer wave per SIMD: a single wave issues one LDS-DMA piece per ~70 cycles, the CU ~23
@@ -1399,7 +1450,8 @@ template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_p
     const int ep = (a.N % TBN == 0) ? pc_epilogue_kind<T, NS>(a, outk, gelu) : 0;
 #define BD_PC_LAUNCH(EP_, OUTK_, GELU_) hipLaunchKernelGGL((gemm_kernel_pc<T, NS, BK, WM, WN, MI, NI, NPW, EP_, OUTK_, GELU_>), g, b, 0, s, a)
     constexpr int ALT = (NS == 2 && sizeof(T) == 2) ? OUT_F16 : (sizeof(T) == 1 ? OUT_BF16 : OUT_OPERAND);   // the one non-native 16-bit kind
-    if (ep == 3) BD_PC_LAUNCH(3, OUT_F32, false);
+    if (ep == 3 && a.ln_out) hipLaunchKernelGGL((gemm_kernel_pc<T, NS, BK, WM, WN, MI, NI, NPW, 3, OUT_F32, false, true>), g, b, 0, s, a);
+    else if (ep == 3) BD_PC_LAUNCH(3, OUT_F32, false);
     else if (ep == 2) { if (outk == OUT_OPERAND) BD_PC_LAUNCH(2, OUT_OPERAND, false); else BD_PC_LAUNCH(2, ALT, false); }
     else if (ep == 1 && gelu && outk == OUT_OPERAND) BD_PC_LAUNCH(1, OUT_OPERAND, true);
     else if (ep == 1 && !gelu) { if (outk == OUT_OPERAND) BD_PC_LAUNCH(1, OUT_OPERAND, false); else BD_PC_LAUNCH(1, ALT, false); }
@@ -1464,9 +1516,26 @@ inline bool rms_geometry_ok(const bd_gemm_args& a) {
            a.N % (a.rms_parts == 2 ? 2 : 3) == 0 && (a.N / (a.rms_parts == 2 ? 2 : 3)) % 96 == 0 && a.N % 192 == 0 && (((uintptr_t)a.rms_wq | (uintptr_t)a.rms_wk) & 3) == 0;
 }
 
+// does bd_gemm run the fused LayerNorm for these arguments (persistent kernel + fp32 residual epilogue)?
+template <class T, int NS> bool fuses_ln(const bd_gemm_args& a, int cus) {
+#ifdef BD_EXP_PC_HYBRID
+    return false;                    // (A/B builds with the row split: a panel's tiles would come from two launches)
+#endif
+    if (!ln_geometry_ok(a) || !uses_pc192(a, NS, OpGeom<T>::ESZ, cus)) return false;
+    int outk = 0;
+    bool gelu = false;
+    return pc_epilogue_kind<T, NS>(a, outk, gelu) == 3;
+}
+inline bool f16c8_ep3_ok(const bd_gemm_args& a) {
+    return wide_epilogue_ok(a, 2) && 256 * a.lda * 2 < ((int64_t)1 << 31) && 256 * a.ldw * 2 < ((int64_t)1 << 31) && !a.addtab &&
+           a.rpg_in <= 0 && !a.wscale && a.N % 192 == 0 && a.K >= 128 && !(a.bias && ((uintptr_t)a.bias & 15)) &&
+           a.out_f32 == OUT_F32 && a.act != BD_ACT_GELU && !a.rms_wq;
+}
+
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {
     const int kCUs = cu_count();
     if (a.rms_wq && !(rms_geometry_ok(a) && pc192_possible(a, NS, OpGeom<T>::ESZ))) return BD_ERR_SHAPE;
+    if (a.ln_out && !fuses_ln<T, NS>(a, kCUs)) return BD_ERR_SHAPE;
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     // the producer wave of gemm_kernel_pc addresses a tile's operand rows with 32-bit byte offsets from the tile origin
     constexpr int ESZ_ = OpGeom<T>::ESZ;
@@ -1596,6 +1665,7 @@ int launch_f16c8(const bd_gemm_args& a, hipStream_t s) {
     if (a.out_f32 == OUT_OPERAND && (a.ldo % 32)) return BD_ERR_SHAPE;
     if (a.w_qexp + BD_F16C8_D < -100 || a.w_qexp + BD_F16C8_D > 120) return BD_ERR_SHAPE;
     if (a.rms_wq && !rms_geometry_ok(a)) return BD_ERR_SHAPE;
+    if (a.ln_out && !(ln_geometry_ok(a) && f16c8_ep3_ok(a))) return BD_ERR_SHAPE;
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     const int cus = cu_count();
     const int tiles = ((a.M + 255) / 256) * ((a.N + 191) / 192);
@@ -1613,7 +1683,11 @@ int launch_f16c8(const bd_gemm_args& a, hipStream_t s) {
 #define BD_C8_LAUNCH(EP_, OUTK_, GELU_)                                                                     \
     { if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_>), g, b, 0, s, a);                 \
       else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, EP_, OUTK_, GELU_>), g, b, 0, s, a); }
-    if (ep == 3) BD_C8_LAUNCH(3, OUT_F32, false)
+    if (ep == 3 && a.ln_out) {
+        if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 3, OUT_F32, false, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, 3, OUT_F32, false, true>), g, b, 0, s, a);
+    }
+    else if (ep == 3) BD_C8_LAUNCH(3, OUT_F32, false)
     else if (ep == 2 && outk == OUT_OPERAND) BD_C8_LAUNCH(2, OUT_OPERAND, false)
     else if (ep == 2 && outk == OUT_F16) BD_C8_LAUNCH(2, OUT_F16, false)
     else if (ep == 2) BD_C8_LAUNCH(2, OUT_BF16X2, false)
@@ -1640,6 +1714,22 @@ extern "C" int bd_gemm_fuses_qk_rmsnorm(const bd_gemm_args* args, int prec) {
         case BD_PREC_BF16X3: return pc192_possible(*args, 2, 2) ? 1 : 0;
         case BD_PREC_FP8: return pc192_possible(*args, 1, 1) ? 1 : 0;
         case BD_PREC_F16C8: return wide_epilogue_ok(*args, 2) ? 1 : 0;
+        default: return 0;
+    }
+}
+
+extern "C" int bd_gemm_fuses_layernorm(const bd_gemm_args* args, int prec) {
+    if (!args) return 0;
+#ifdef BD_EXP_NO_LN_FUSE       // A/B build only: the separate bd_layernorm kernel runs instead
+    return 0;
+#endif
+    const int cus = cu_count();
+    switch (prec) {
+        case BD_PREC_BF16: return fuses_ln<__bf16, 1>(*args, cus) ? 1 : 0;
+        case BD_PREC_F16: return fuses_ln<_Float16, 1>(*args, cus) ? 1 : 0;
+        case BD_PREC_BF16X3: return fuses_ln<__bf16, 2>(*args, cus) ? 1 : 0;
+        case BD_PREC_FP8: return fuses_ln<fp8e4, 1>(*args, cus) ? 1 : 0;
+        case BD_PREC_F16C8: return (ln_geometry_ok(*args) && f16c8_ep3_ok(*args) && (args->K % 32) == 0 && (args->lda % 32) == 0 && (args->ldw % 32) == 0) ? 1 : 0;
         default: return 0;
     }
 }

@@ -18,61 +18,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (r >= rows) return;
     int64_t ir = r;
     if (rpg_in > 0) ir = (int64_t)(r / rpg_in) * rpg_out + r % rpg_in + row_off;
-    const float* xr = x + ir * ldx;
-    float4 v[4];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < cols) {
-            // non-temporal: the residual stream (151 MB) is far larger than the L2s and is not read again by this kernel
-            // (whole step +0.6 %; the same hint on the residual loads of the GEMM epilogue, on q/k RMSNorm and on the
-            // attention K/V loads measured neutral to -3 %)
-            { const f32x4 t_ = __builtin_nontemporal_load((const f32x4*)(xr + c)); v[i] = make_float4(t_[0], t_[1], t_[2], t_[3]); }
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        }
-    }
-    const float mean = wave_sum(s) / (float)cols;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < cols) {
-            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-            q += (a * a + b * b) + (cc * cc + d * d);
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < cols) {
-            float y[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd,
-                          (v[i].w - mean) * rstd};
-            if (gamma) {
-                const float4 g = *(const float4*)(gamma + c);
-                y[0] *= g.x; y[1] *= g.y; y[2] *= g.z; y[3] *= g.w;
-            }
-            if (beta) {
-                const float4 bb = *(const float4*)(beta + c);
-                y[0] += bb.x; y[1] += bb.y; y[2] += bb.z; y[3] += bb.w;
-            }
-            if (out32) *(float4*)(out32 + (int64_t)r * ldo + c) = make_float4(y[0], y[1], y[2], y[3]);
-            if (out16) {
-                if constexpr (__is_same(T, f16c8)) {
-                    f16c8_store4(out16, out16_plane, (int64_t)r * cols + c, y);
-                } else if constexpr (NS == 2) {
-                    float hi4[4], lo4[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { hi4[j] = to_f32<T>(from_f32<T>(y[j])); lo4[j] = y[j] - hi4[j]; }
-                    store_cvt<T, 4>(out16 + (int64_t)r * cols + c, hi4);
-                    store_cvt<T, 4>(out16 + out16_plane + (int64_t)r * cols + c, lo4);
-                } else {
-                    store_cvt<T, 4>(out16 + (int64_t)r * cols + c, y);
-                }
-            }
-        }
-    }
+    // non-temporal row loads: the residual stream (151 MB) is far larger than the L2s and is not read again by this kernel
+    // (whole step +0.6 %; the same hint on the residual loads of the GEMM epilogue, on q/k RMSNorm and on the attention K/V
+    // loads measured neutral to -3 %)
+    ln_row<T, NS, true>(x + ir * ldx, gamma, beta, eps, out16, out16_plane, out32 ? out32 + (int64_t)r * ldo : nullptr, (int64_t)r, cols, lane);
 }
 
 // ---------------------------------------------------------------- q/k RMSNorm, in place

@@ -139,10 +139,23 @@ typedef struct bd_gemm_args {
     const float* rms_wq; const float* rms_wk; float rms_eps;
     int rms_parts;                                 /* with rms_wq: 0 or 3 = output columns are [q | k | v] (v untouched); 2 = [q | k] only
                                                       (a QKV Linear split into a q,k launch and a v launch, BD_PREC_F16C8_QK16) */
+    /* Fused LayerNorm of the RESULT rows (round 3): for a Linear whose fp32 output is the residual stream (out_f32 == 1, identity row
+     * map, N == the full row, ldo == N), the launch also writes ln_out = LayerNorm(out row; ln_gamma, ln_beta, ln_eps) in the operand
+     * class `prec` (planes ln_out_plane apart) -- the next Linear's A operand -- so that no separate bd_layernorm pass re-reads the
+     * stream from HBM.  The workgroup that completes a 256-row panel (its N / 192 column tiles arrive on ln_sync[panel], int32
+     * counters the caller zeroes once; the kernel leaves them zero) normalises the panel's rows out of the L2; same arithmetic, same
+     * bits as bd_layernorm.  Only where the launch takes the persistent 256 x 192 kernel: ask bd_gemm_fuses_layernorm first
+     * (bd_gemm returns BD_ERR_SHAPE otherwise).  ln_gamma / ln_beta may be NULL (no affine). */
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    void* ln_out; int64_t ln_out_plane;
+    int* ln_sync;
 } bd_gemm_args;
 int bd_gemm(const bd_gemm_args* args /*[host]*/, int prec, void* stream);
 /* 1 if bd_gemm(args, prec) with args->rms_wq set would fuse the q/k RMSNorm (tile shape and head geometry fit), else 0. */
 int bd_gemm_fuses_qk_rmsnorm(const bd_gemm_args* args /*[host]*/, int prec);
+/* 1 if bd_gemm(args, prec) with args->ln_out set would run the fused LayerNorm (persistent kernel, geometry fits), else 0; the number
+ * of int32 counters ln_sync must hold is (M + 255) / 256. */
+int bd_gemm_fuses_layernorm(const bd_gemm_args* args /*[host]*/, int prec);
 
 /* LayerNorm over the last dim (fp32 statistics), optional affine, fp32 input rows gathered by
  * in_row(r) = r if rpg_in == 0 else (r / rpg_in) * rpg_out + r % rpg_in + row_off.

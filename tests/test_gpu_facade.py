@@ -12,7 +12,7 @@ from oracle import boxdreamer_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-STRICT_DEFAULT = "f16c8_qkv16"       # the facade's default mode (boxdreamer_amd._lib.DEFAULT_PREC)
+STRICT_DEFAULT = "f16c8_qk16"       # the facade's default mode (boxdreamer_amd._lib.DEFAULT_PREC)
 
 
 def _config(prec, depth=2):
@@ -102,7 +102,7 @@ def test_unsupported_configs_raise():
 def test_reference_feature_cache_is_bit_identical(hip):
     """"next" row f1: encoding the references once and only the query per pose gives the same bits."""
     from boxdreamer_amd.cache import RefFeatureCache
-    for prec in ("bf16", "bf16x3", "f16c8_qkv16", "f16c8"):
+    for prec in ("bf16", "bf16x3", "f16c8_qk16", "f16c8_qkv16", "f16c8"):
         model = BoxDreamer(_config(prec))
         model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
         model = model.cuda().eval()
@@ -349,7 +349,7 @@ def test_configs2_substitute_b64_end_to_end(hip):
     available offline (checkpoint: run.py:172-183; data: configs/test.yaml:18-24).  SURVEY §8d's substitute: synthetic
     B = 64, T = 6 at FULL depth through the facade -> heatmaps -> corners -> host PnP, in the strict mode, with the oracle
     on two of the 64 samples and batch-independence (bit-exact) on two more.  Runs in the facade's DEFAULT mode."""
-    cfg = _config(None, depth=12)                   # the facade's default mode (f16c8_qkv16)
+    cfg = _config(None, depth=12)                   # the facade's default mode (f16c8_qk16)
     model = BoxDreamer(cfg)
     assert model.decoder.hip_precision == STRICT_DEFAULT
     model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 12).items()}, strict=True)

@@ -104,7 +104,7 @@ def test_strict_attention_policies_full_T6(hip, golden_dir, prec, tol):
     assert e_gold <= tol, e_gold
 
 
-@pytest.mark.parametrize("prec", ["f16c8_qkv16", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f16c8_qk16", "f16c8_qkv16", "bf16x3"])
 def test_views17_reduced_depth(hip, prec):
     """BASELINE configs[3] shape: 1 query + 16 references (T = 17, one BETR sequence of 4352 tokens = 68 key tiles per
     attention row block) at reduced depth (2 + 2 layers, so the CPU oracle finishes in seconds), in the default (strict) mode and
@@ -152,7 +152,7 @@ def test_batch_independence_and_determinism(hip):
         assert torch.equal(dec.last_logits.cpu()[0], l2[b])
 
 
-@pytest.mark.parametrize("prec", ["f16c8_qkv16", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f16c8_qk16", "bf16x3"])
 def test_query_view_position(hip, prec):
     """query_idx anywhere in the view list (reference samples it; betr.py:286-290,303)."""
     enc, dec = _build(prec, 2, 2)
@@ -165,7 +165,7 @@ def test_query_view_position(hip, prec):
     assert (dec.last_logits.cpu() - o["logits"]).abs().max().item() <= 1e-3
 
 
-@pytest.mark.parametrize("prec", ["f16c8_qkv16", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f16c8_qk16", "bf16x3"])
 @pytest.mark.parametrize("size,T,B", [(112, 3, 2), (84, 2, 1), (224, 2, 3), (98, 5, 3), (56, 1, 2), (224, 1, 1)])
 def test_other_crop_sizes_and_view_counts(hip, size, T, B, prec):
     """img_size is a config value in the reference (configs/model/transformer.yaml:46); any multiple of 14 works:
@@ -235,7 +235,7 @@ def _run_full(enc, dec, img, bf, qpos):
     return dec.last_logits.clone(), heat.clone(), kp.clone(), idx.clone().long()
 
 
-@pytest.mark.parametrize("prec", ["f16c8_qkv16", "bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["f16c8_qk16", "f16c8_qkv16", "bf16x3", "bf16"])
 def test_full_size_properties(hip, prec):
     """The oracle cannot run B=32 x full depth in seconds, so the full-size step is checked through properties that do not
     depend on size:
@@ -274,12 +274,12 @@ def test_default_precision_is_the_parity_meeting_mode(hip, golden_dir):
     """a maintainer who applies INTEGRATION.md's 3-line patch and names no precision must get the mode that meets
     north_star's bar (logits <= 1e-3 vs the fp32 CPU forward, identical top-20 sets) -- bf16 is the explicit opt-in."""
     from boxdreamer_amd import _lib
-    assert _lib.DEFAULT_PREC == "f16c8_qkv16"
+    assert _lib.DEFAULT_PREC == "f16c8_qk16"
     enc = DinoV2Wrapper(None, {"model_type": "dinov2_vitb14_reg", "synthetic_seed": 4321, "depth": 12})
     dec = BETR(d_model=768, nhead=8, num_decoder_layers=12, decoder_only=True, patch_size=14, img_size=224,
                diff_emb=False, nvs_supervision=False, ray_supervision=True, use_mask=False, use_pretrained=True,
                patchify_rays=True, pose_representation="bb8", bbox_representation="heatmap")
-    assert enc.prec == dec.hip_precision == "f16c8_qkv16"
+    assert enc.prec == dec.hip_precision == "f16c8_qk16"
     dec.load_state_dict(synth.betr_state_dict(seed=1234, depth=12), strict=True)
     dec = dec.cuda().eval()
     g = np.load(os.path.join(golden_dir, "case_full_T6.npz"))
