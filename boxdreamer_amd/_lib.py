@@ -96,6 +96,7 @@ EXPORTS = [
     "bd_encoder_workspace_bytes", "bd_encoder_forward", "bd_decoder_workspace_bytes", "bd_decoder_forward",
     "bd_trace_begin", "bd_trace_end", "bd_render_corner_heatmaps", "bd_attention_q", "bd_gather_query_rows_f32",
     "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm", "bd_gemm_fuses_layernorm",
+    "bd_gemm_fuses_layernorm_supported",
 ]
 
 _lib = None
@@ -123,6 +124,7 @@ def load() -> C.CDLL:
     lib.bd_gemm.argtypes = [C.POINTER(GemmArgs), i, vp]
     lib.bd_gemm_fuses_qk_rmsnorm.argtypes = [C.POINTER(GemmArgs), i]
     lib.bd_gemm_fuses_layernorm.argtypes = [C.POINTER(GemmArgs), i]
+    lib.bd_gemm_fuses_layernorm_supported.argtypes = [C.POINTER(GemmArgs), i]
     lib.bd_layernorm.argtypes = [vp, i64, vp, vp, f, vp, i64, vp, i64, i, i, i, i, i, i, vp]
     lib.bd_qk_rmsnorm.argtypes = [vp, i64, vp, vp, f, i, i, i, i, vp]
     lib.bd_attention.argtypes = [vp, i64, vp, i64, i, i, i, i, f, i, vp]

@@ -297,20 +297,42 @@ __device__ __forceinline__ void f16c8_store4(f16c8* base, int64_t plane, int64_t
 // lives in 4 float4 registers per lane (lane l owns columns (i*64 + l)*4 .. +3).  Shared by the stand-alone kernel (norm.hip) and
 // by the persistent GEMMs' fused form (gemm.hip: the workgroup that completes a 256-row panel of the residual stream normalises
 // it), so both produce the same bits.  NT: non-temporal row loads (stand-alone kernel: the stream is far larger than the L2s).
-template <class T, int NS, bool NT>
-__device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       float eps, T* __restrict__ out16, int64_t out16_plane, float* __restrict__ out32_row,
-                                       int64_t orow, int cols, int lane) {
+template <bool NT>
+__device__ __forceinline__ void ln_row_load(const float* __restrict__ xr, int cols, int lane, f32x4 (&t)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            if constexpr (NT) t[i] = __builtin_nontemporal_load((const f32x4*)(xr + c));
+            else t[i] = *(const f32x4*)(xr + c);
+        }
+    }
+}
+// The same row fetched with device-coherent (sc1) loads: they bypass this CU's L1 and the XCD's L2, so rows that OTHER workgroups
+// wrote with write-through stores earlier in the same launch are read correctly without an acquire fence (buffer_inv sc1 drops the
+// whole L2's clean lines: every CU of the XCD then re-fetches its GEMM operands -- measured 3.4x on the launch).  Inline asm: the
+// caller waits with ln_rows_wait() before it touches the registers.
+__device__ __forceinline__ void ln_row_load_sc1(const float* xr, int cols, int lane, f32x4 (&t)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(t[i]) : "v"(xr + c) : "memory");
+    }
+}
+__device__ __forceinline__ void ln_rows_wait(f32x4 (&a)[4], f32x4 (&b)[4]) {      // the registers pass THROUGH the wait: nothing moves above it
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : : "memory");
+}
+template <class T, int NS>
+__device__ __forceinline__ void ln_row_finish(const f32x4 (&t)[4], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              float eps, T* __restrict__ out16, int64_t out16_plane, float* __restrict__ out32_row,
+                                              int64_t orow, int cols, int lane) {
     float4 v[4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < cols) {
-            f32x4 t_;
-            if constexpr (NT) t_ = __builtin_nontemporal_load((const f32x4*)(xr + c));
-            else t_ = *(const f32x4*)(xr + c);
-            v[i] = make_float4(t_[0], t_[1], t_[2], t_[3]);
+            v[i] = make_float4(t[i][0], t[i][1], t[i][2], t[i][3]);
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
     }
@@ -355,6 +377,15 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
             }
         }
     }
+}
+
+template <class T, int NS, bool NT>
+__device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float eps, T* __restrict__ out16, int64_t out16_plane, float* __restrict__ out32_row,
+                                       int64_t orow, int cols, int lane) {
+    f32x4 t[4];
+    ln_row_load<NT>(xr, cols, lane, t);
+    ln_row_finish<T, NS>(t, gamma, beta, eps, out16, out16_plane, out32_row, orow, cols, lane);
 }
 
 // trace.hip

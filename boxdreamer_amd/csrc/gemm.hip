@@ -576,7 +576,9 @@ __device__ __forceinline__ float quad_sum(float x) {
 //   rmsw: q weights at [0, 96), k weights at [256, 352)
 //   wcol: first column of the wave tile inside the workgroup tile;  (wm0, wn0): its global origin
 //   next: the wave tile origin of this workgroup's next tile (EP 3 pre-loads its residual), has_next = there is one
-template <class T, int NS, int EP, int OUTK, bool GELU, int MI = 2>
+// WT: the fp32 rows leave as WRITE-THROUGH (sc1) 16-byte stores -- the payload of the fused LayerNorm's inter-workgroup hand-off
+// (fused_panel_layernorm): visible device-wide once the storing wave's vmcnt drains, without an L2 write-back fence.
+template <class T, int NS, int EP, int OUTK, bool GELU, int MI = 2, bool WT = false>
 __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)[MI][3], float* sc, const float* colp, const float* colp_next,
                                             const float* rmsw, int wcol, int wm0, int wn0, int lane, bool has_next, int nwm0, int nwn0) {
     constexpr int COLS = 96;
@@ -638,7 +640,10 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
                 if (gr < M) {
                     float* op = (float*)p.out + (int64_t)gr * p.ldo + wn0 + c4 * 4;
 #pragma unroll
-                    for (int cb = 0; cb < 3; ++cb) *(f32x4*)(op + cb * 32) = v[cb];
+                    for (int cb = 0; cb < 3; ++cb) {
+                        if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(op + cb * 32), "v"(v[cb]) : "memory");
+                        else *(f32x4*)(op + cb * 32) = v[cb];
+                    }
                 }
             }
         }
@@ -761,35 +766,44 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
 }
 
 // Fused LayerNorm of a finished row panel (LNF kernels, EP 3: the fp32 result IS the residual stream).  Called by every consumer wave
-// after its epilogue.  Protocol (agent scope, placement-independent): each wave releases its stores; workgroup barrier Y1 (producers
-// take part: they idle there instead of at the next tile's first slab barrier); one lane counts the tile in on the panel's counter
-// and learns whether it was the panel's last column tile; barrier Y2 hands that flag to all waves through one LDS word; the last
-// workgroup acquires and normalises the panel, rows split over the consumer waves, each row by one wave exactly as
-// norm.hip does (ln_row: same bits).  The counter goes back to zero for the next launch.  The release costs nothing extra: an
-// EP-3 consumer already waits for its stores at the first MFMA of the next tile (in-order vmcnt behind the residual pre-loads).
+// after its epilogue.  Inter-workgroup hand-off in its counter form, placement-independent (cdna_hip_programming.md G16): every wave
+// drains its stores, which are WRITE-THROUGH (sc1: pc_epilogue WT), so no release fence is needed (an agent-scope release is a
+// write-back of the whole L2: one per wave measured 3.7x on the whole GEMM, one per workgroup tile still 3.4x); workgroup barrier Y1
+// (the producers take part: they idle there instead of at the next tile's first slab barrier); one lane counts the tile in on the
+// panel's counter (relaxed, agent scope), learning whether it was the panel's last column tile; barrier
+// Y2 hands that flag to all waves through one LDS word; the last workgroup's consumer waves then normalise the panel, reading its
+// rows with device-coherent (sc1) loads -- no acquire fence: buffer_inv sc1 empties the XCD's L2 under every other CU's GEMM --
+// rows split over the waves, TWO rows in flight per wave, each row by one wave exactly as norm.hip does (ln_row_*: same bits).  The counter goes back to zero for the next launch.  The drain costs nothing
+// extra: an EP-3 consumer already waits for its stores at the first MFMA of the next tile (in-order vmcnt behind the residual
+// pre-loads).
 template <class T, int NS, int NCW, int TBM>
 __device__ __forceinline__ void fused_panel_layernorm(const bd_gemm_args& p, unsigned* flag_lds, int m0, int tilesN, int wid, int lane) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    pc_barrier();                                  // Y1: every consumer wave's part of the tile is visible device-wide
-    if (wid == 0 && lane == 0) {
-        int* cnt = p.ln_sync + m0 / TBM;
-        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned last = old == tilesN - 1;
-        if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *(volatile unsigned*)flag_lds = last;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (pc_barrier is a bare s_barrier: the LDS word must have landed)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pc_barrier();                                  // Y1: every consumer wave's part of the tile has reached the L2
+    if (wid == 0) {
+        if (lane == 0) {
+            int* cnt = p.ln_sync + m0 / TBM;
+            const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = old == tilesN - 1;
+            if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *(volatile unsigned*)flag_lds = last;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (pc_barrier is a bare s_barrier: the LDS word must have landed)
+        }
     }
     pc_barrier();                                  // Y2
     if (*(volatile unsigned*)flag_lds) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         constexpr int RPW = TBM / NCW;             // rows per consumer wave
         const float* x = (const float*)p.out;
-#pragma unroll 2
-        for (int k = 0; k < RPW; ++k) {
-            const int r = m0 + wid * RPW + k;
-            if (r < p.M)
-                ln_row<T, NS, false>(x + (int64_t)r * p.ldo, p.ln_gamma, p.ln_beta, p.ln_eps, (T*)p.ln_out, p.ln_out_plane, nullptr,
-                                     (int64_t)r, p.N, lane);
+        const int r0 = m0 + wid * RPW;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < RPW; k += 2) {
+            const int ra = r0 + k, rb = r0 + k + 1;
+            f32x4 ta[4] = {z, z, z, z}, tb[4] = {z, z, z, z};
+            if (ra < p.M) ln_row_load_sc1(x + (int64_t)ra * p.ldo, p.N, lane, ta);
+            if (rb < p.M) ln_row_load_sc1(x + (int64_t)rb * p.ldo, p.N, lane, tb);
+            ln_rows_wait(ta, tb);
+            if (ra < p.M) ln_row_finish<T, NS>(ta, p.ln_gamma, p.ln_beta, p.ln_eps, (T*)p.ln_out, p.ln_out_plane, nullptr, (int64_t)ra, p.N, lane);
+            if (rb < p.M) ln_row_finish<T, NS>(tb, p.ln_gamma, p.ln_beta, p.ln_eps, (T*)p.ln_out, p.ln_out_plane, nullptr, (int64_t)rb, p.N, lane);
         }
     }
 }
@@ -1116,7 +1130,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 const bool has_next = t + stride < t_end;
                 int nm0 = 0, nn0 = 0;
                 if (has_next) tile_origin(t + stride, nm0, nn0);
-                pc_epilogue<T, NS, EP, OUTK, GELU, MI>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
+                pc_epilogue<T, NS, EP, OUTK, GELU, MI, LNF>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
                                                   (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
                                                   lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
                 if constexpr (LNF) {
@@ -1396,7 +1410,7 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
             const bool has_next = t + stride < t_end;
             int nm0 = 0, nn0 = 0;
             if (has_next) tile_origin(t + stride, nm0, nn0);
-            pc_epilogue<f16c8, 2, EP, OUTK, GELU>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
+            pc_epilogue<f16c8, 2, EP, OUTK, GELU, 2, LNF>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
                                                  (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
                                                  lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
             if constexpr (LNF) {
@@ -1718,11 +1732,20 @@ extern "C" int bd_gemm_fuses_qk_rmsnorm(const bd_gemm_args* args, int prec) {
     }
 }
 
-extern "C" int bd_gemm_fuses_layernorm(const bd_gemm_args* args, int prec) {
-    if (!args) return 0;
-#ifdef BD_EXP_NO_LN_FUSE       // A/B build only: the separate bd_layernorm kernel runs instead
-    return 0;
+// BD_LN_FUSE (compile-time policy, default 0): 1 lets the whole-path entry points run LayerNorm inside the residual GEMMs.  The fused
+// form is correct (bit-identical, tests/test_gpu_ops.py) but measured SLOWER than the separate kernel on MI355X in every hand-off
+// variant (profiles/r3_layernorm_fusion.md): the panel's last workgroup spends 40-60 us of MFMA-dead time per panel.  bd_gemm itself
+// still honours ln_out for callers that ask for it explicitly (bd_gemm_fuses_layernorm_supported).
+#ifndef BD_LN_FUSE
+#define BD_LN_FUSE 0
 #endif
+static int ln_fusion_supported(const bd_gemm_args* args, int prec);
+extern "C" int bd_gemm_fuses_layernorm(const bd_gemm_args* args, int prec) {
+    return BD_LN_FUSE ? ln_fusion_supported(args, prec) : 0;
+}
+extern "C" int bd_gemm_fuses_layernorm_supported(const bd_gemm_args* args, int prec) { return ln_fusion_supported(args, prec); }
+static int ln_fusion_supported(const bd_gemm_args* args, int prec) {
+    if (!args) return 0;
     const int cus = cu_count();
     switch (prec) {
         case BD_PREC_BF16: return fuses_ln<__bf16, 1>(*args, cus) ? 1 : 0;

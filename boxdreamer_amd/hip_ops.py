@@ -106,12 +106,13 @@ _OUT_DTYPES = {2: torch.float16, 3: torch.bfloat16}      # 4: split-bf16 planes 
 
 
 def gemm_fuses_layernorm(M, N, K, prec) -> bool:
-    """Would a residual Linear of this shape run its LayerNorm inside the launch (persistent kernel)?"""
+    """Can a residual Linear of this shape run its LayerNorm inside the launch (persistent kernel)?  (Capability, not the policy
+    of the whole-path entry points: that is bd_gemm_fuses_layernorm, 0 in the default build.)"""
     lib = _lib.load()
     g = _lib.GemmArgs()
     g.M, g.N, g.K, g.lda, g.ldw, g.ldo, g.ldr, g.out_f32 = M, N, K, K, K, N, N, 1
     g.A = g.W = g.out = g.resid = g.ln_out = g.ln_sync = 256          # aligned dummies: only geometry is looked at
-    return bool(lib.bd_gemm_fuses_layernorm(C.byref(g), prec_id(prec)))
+    return bool(lib.bd_gemm_fuses_layernorm_supported(C.byref(g), prec_id(prec)))
 
 
 def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, addtab=None, out=None,

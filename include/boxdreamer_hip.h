@@ -153,9 +153,12 @@ typedef struct bd_gemm_args {
 int bd_gemm(const bd_gemm_args* args /*[host]*/, int prec, void* stream);
 /* 1 if bd_gemm(args, prec) with args->rms_wq set would fuse the q/k RMSNorm (tile shape and head geometry fit), else 0. */
 int bd_gemm_fuses_qk_rmsnorm(const bd_gemm_args* args /*[host]*/, int prec);
-/* 1 if bd_gemm(args, prec) with args->ln_out set would run the fused LayerNorm (persistent kernel, geometry fits), else 0; the number
- * of int32 counters ln_sync must hold is (M + 255) / 256. */
+/* bd_gemm_fuses_layernorm_supported: 1 if bd_gemm(args, prec) with args->ln_out set can run the fused LayerNorm (persistent kernel,
+ * geometry fits), else 0; ln_sync must hold (M + 255) / 256 int32 counters.  bd_gemm_fuses_layernorm: the POLICY the whole-path
+ * entry points follow -- the same answer in a build with -DBD_LN_FUSE=1, 0 in the default build: the fused form is bit-identical
+ * but measured slower than the separate kernel on MI355X (profiles/r3_layernorm_fusion.md). */
 int bd_gemm_fuses_layernorm(const bd_gemm_args* args /*[host]*/, int prec);
+int bd_gemm_fuses_layernorm_supported(const bd_gemm_args* args /*[host]*/, int prec);
 
 /* LayerNorm over the last dim (fp32 statistics), optional affine, fp32 input rows gathered by
  * in_row(r) = r if rpg_in == 0 else (r / rpg_in) * rpg_out + r % rpg_in + row_off.

@@ -287,12 +287,22 @@ def test_gemm_fused_layernorm_matches_separate_kernel(hip, prec, M, K):
         assert torch.equal(x, x_ref), (prec, rep)
         assert torch.equal(xn.view(torch.uint8), xn_ref.view(torch.uint8)), (prec, rep)
         assert int(sync.abs().max()) == 0
-    # a shape the persistent kernel does not take must be REFUSED, never silently unfused
+    # a shape the persistent kernel does not take must be REFUSED, never silently unfused (F16C8 always takes it: must be right)
     small = hip_ops.to_operand(a[:300].cuda(), prec)
-    with pytest.raises(_lib.HipLibraryError, match="BD_ERR_SHAPE"):
-        xs = x0[:300].clone()
-        hip_ops.gemm(small, w16, b.cuda(), prec=prec, resid=xs, out=xs, out_f32=True, w_qexp=e, wscale=ws,
-                     ln=(gam, bet, 1e-5, xn_ref.clone(), sync))
+    xs = x0[:300].clone()
+    if hip_ops.gemm_fuses_layernorm(300, N, K, prec):
+        xns = hip_ops.to_operand(torch.zeros(300, N, device="cuda"), prec)
+        hip_ops.gemm(small, w16, b.cuda(), prec=prec, resid=xs, out=xs, out_f32=True, w_qexp=e, wscale=ws, ln=(gam, bet, 1e-5, xns, sync))
+        assert torch.equal(xs, x_ref[:300])
+        np_ = _lib.planes(prec)
+        for pl in range(np_):
+            got = (xns[pl] if np_ == 2 else xns).view(torch.uint8).reshape(-1)[: 300 * N * (1 if (prec == "f16c8" and pl == 1) else xns.element_size())]
+            ref = (xn_ref[pl] if np_ == 2 else xn_ref).view(torch.uint8).reshape(-1)[: got.numel()]
+            assert torch.equal(got, ref)
+    else:
+        with pytest.raises(_lib.HipLibraryError, match="BD_ERR_SHAPE"):
+            hip_ops.gemm(small, w16, b.cuda(), prec=prec, resid=xs, out=xs, out_f32=True, w_qexp=e, wscale=ws,
+                         ln=(gam, bet, 1e-5, xn_ref.clone(), sync))
 
 
 @pytest.mark.parametrize("M", [300, 6144])
