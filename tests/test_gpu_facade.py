@@ -281,6 +281,24 @@ def test_dense_mode_multi_round(hip):
     out3 = model3({kk: (v.cuda() if torch.is_tensor(v) else v) for kk, v in data3.items()})
     assert out3["images"].shape[1] == 3 and out3["pred_bbox"].shape == (B, 3, 8, 224, 224)
     assert out3["camera_mask"][:, -1].all() and torch.isfinite(out3["pred_poses"]).all()
+    # VALUES of the fine round (it was shape / finite-checked only): the re-packed batch holds fine_topk of the ORIGINAL
+    # references (in their original order) + the query last, and the fine decode equals the oracle run on exactly those views
+    for b in range(B):
+        refs_b = [t for t in range(T) if not cm[b, t]]
+        picked = []
+        for j in range(2):
+            hit = [t for t in refs_b if torch.equal(data3["images"][b, t], out3["images"][b, j].cpu())]
+            assert len(hit) >= 1
+            picked.append(hit[0])
+            assert torch.equal(data3["bbox_feat"][b, hit[0]], out3["bbox_feat"][b, j].cpu())
+        assert picked == sorted(picked) and len(set(picked)) == 2
+        assert torch.equal(out3["images"][b, 2].cpu(), data3["images"][b][cm[b]][0])
+    o3 = orc.boxdreamer_forward({"images": out3["images"].cpu().float(), "bbox_feat": out3["bbox_feat"].cpu().float(),
+                                 "query_idx": torch.full((B,), 2)}, synth.betr_state_dict(1234, 2), synth.dino_state_dict(4321, 2))
+    assert (model3.decoder.last_logits.cpu() - o3["logits"]).abs().max().item() <= 1e-3
+    got3 = out3["pred_bbox"].cpu()[out3["camera_mask"].cpu()].float()
+    assert (got3 - o3["heat"]).abs().max().item() <= 1e-3
+    assert (out3["pred_corners_px"].cpu() - o3["corners_px"]).abs().max().item() <= 224 / 20 * 2
 
 
 # ---------------------------------------------------------------- pose VALUES through process_prediction
