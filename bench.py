@@ -383,7 +383,15 @@ def algorithmic_gemm_bytes(prec: str, B: int, T: int) -> tuple[int, int]:
     gemm(M, 768, 1600 if prec != "fp8" else 1664, a, w, 4, True)                                # heatmap patch embedding + rgb + pos
     q16 = prec in ("f16c8_qkv16", "bf16x3_qkv16")
     for i in range(12):                                       # BETR: f16 attention in the strict modes (q, k RMS-normalised)
-        block(M, M if i < 11 else Mq, 2 if q16 else a, 2 if q16 else w, 2)
+        Mt = M if i < 11 else Mq
+        if prec == "f16c8_qk16":                              # QKV split by column: q, k one f16 pass on the f16 plane, v full F16C8
+            gemm(M, 1536, 768, 2, 2, 2)
+            gemm(M, 768, 768, a, w, 2)
+            gemm(Mt, 768, 768, a, w, 4, True)
+            gemm(Mt, 3072, 768, a, w, a)
+            gemm(Mt, 768, 3072, a, w, 4, True)
+        else:
+            block(M, Mt, 2 if q16 else a, 2 if q16 else w, 2)
     gemm(Mq, 1568, 768, a, w, 4)                                                               # head
     return total, calls
 
@@ -405,6 +413,10 @@ def _kclass(name: str) -> str:
     for key, c in (("gemm_kernel", "gemm"), ("attn_kernel", "attention"), ("layernorm", "layernorm"), ("rmsnorm", "rmsnorm")):
         if key in name:
             return c
+    # torch / runtime kernels in the profiled process are one-off harness work (weight packing at load time, input upload, the
+    # bench's own bookkeeping), not launches of the step: kept out of the per-step figures
+    if "at::native" in name or "rocclr" in name:
+        return "harness (one-off torch / runtime kernels: weight packing, uploads)"
     return "other"
 
 
@@ -412,7 +424,7 @@ def measure_counters(args) -> None:
     import collections, csv
     prec, B, T = args.prec, args.batch, args.views
     child = ["--prec", prec, "--batch", str(B), "--views", str(T), "--steps", "2", "--warmup", "1", "--no-graph", "--in-flight", "1",
-             "--no-strict", "--no-cpu-baseline", "--no-parity", "--no-pnp", "--no-h2d"]
+             "--no-strict", "--no-fp8", "--no-cpu-baseline", "--no-parity", "--no-pnp", "--no-h2d"]
     acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")}
     launches, dur_ns, steps_seen = collections.defaultdict(int), collections.defaultdict(float), 0
     for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")):
@@ -440,11 +452,12 @@ def measure_counters(args) -> None:
                   "hbm_gb_per_s": round((fetch + write) / max(dur_ns[k] / steps_seen, 1) , 1),
                   "mfma_busy": round(acc["SQ_VALU_MFMA_BUSY_CYCLES"][k] / max(cyc * 1024.0, 1.0), 4),
                   "delivered_clock_ghz": round(cyc / max(dur_ns[k], 1), 3)}
-    tb = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"].values())
-    tc = sum(acc["SQ_BUSY_CYCLES"].values()) / 32.0
+    step_classes = [k for k in launches if not k.startswith("harness")]
+    tb = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"][k] for k in step_classes)
+    tc = sum(acc["SQ_BUSY_CYCLES"][k] for k in step_classes) / 32.0
     g = per.get("gemm", {})
     out = {"prec": prec, "batch": B, "views": T, "kernel_source_sha": kernel_source_sha(), "steps_profiled": steps_seen,
-           "gemm_calls_per_step": calls,
+           "gemm_calls_per_step": calls, "gemm_kernel_launches_per_step": g.get("launches_per_step"),
            "gemm_hbm_bytes_per_call": round((g.get("fetch_bytes_per_step", 0) + g.get("write_bytes_per_step", 0)) / calls),
            "gemm_algorithmic_bytes_per_call": round(alg_bytes / calls),
            "gemm_traffic_over_algorithmic": round((g.get("fetch_bytes_per_step", 0) + g.get("write_bytes_per_step", 0)) / alg_bytes, 3),
@@ -789,6 +802,7 @@ def main():
                     help="batches in flight in graph mode: 2 = two captured copies of the path replayed alternately on two streams "
                          "(default), 1 = one batch at a time")
     ap.add_argument("--no-strict", action="store_true", help="skip the second (strict-mode) timing")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the configs[4] leg (fp8 Linears, batch 64) of the default single-GPU run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-pnp", action="store_true", help="skip the PnP-inclusive side measurement (host PnP, SURVEY 8d / 8f3)")
@@ -934,6 +948,28 @@ def run(args):
                 line["strict"]["parity"] = parity_probe(STRICT_PREC, T, device, (srun.enc, srun.dec) if B >= 2 else None)
         sres["run"].close()
         del sres
+    # ---- BASELINE configs[4]: fp8 (e4m3) Linears + bf16 attention at batch 64, single GPU, default workload only (its tolerance is
+    # RESTATED: 3 mantissa bits cannot meet 1e-3) -- reported in the same line so the driver's run covers it
+    PROGRESS["stage"] = "fp8 leg (configs[4])"
+    if rank == 0:
+        PROGRESS["line"] = dict(line)
+    if world == 1 and not args.no_fp8 and prec != "fp8" and not args.cache_refs and B == 32 and T == 6:
+        torch.cuda.empty_cache()
+        B8 = 64
+        one8 = synth.make_batch(seed=300 + rank, B=B8, T=T)
+        img8, bb8 = one8["images"].to(torch.bfloat16).to(device), one8["bbox_feat"].to(torch.bfloat16).to(device)
+        mask8 = torch.zeros(B8, T, dtype=torch.bool, device=device); mask8[:, T - 1] = True
+        args8 = argparse.Namespace(**{**vars(args), "batch": B8, "in_flight": 1})
+        fres = measure_mode("fp8", args8, device, world, rank, dist, img8, bb8, mask8)
+        par = parity_probe("fp8", T, device, (fres["run"].enc, fres["run"].dec)) if not args.no_parity else None
+        line["fp8"] = {"workload": workload_name(B8, T, "fp8", world, False), "value": round(fres["value"], 2), "unit": "poses/s",
+                       "ms_per_step": round(fres["ms_per_step"], 3), "dtype": DTYPE_LABEL["fp8"], "batches_in_flight": 1,
+                       "roofline": fres["roofline"],
+                       "parity": par,
+                       "tolerance_restated": "e4m3 Linears: logits <= 1.0 max-abs and <= 0.2 rms of a unit-rms heatmap at full depth "
+                                             "(tests/test_gpu_path.py::test_fp8_mode_restated_tolerance); not a mode that meets the 1e-3 bar"}
+        fres["run"].close()
+        del fres
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(T)

@@ -113,4 +113,4 @@ def test_workload_label_names_the_config_actually_run():
     # algorithmic GEMM bytes: 101 bd_gemm calls per step at T = 6, ~0.4 GB per call in bf16, more in the strict classes
     b16, calls = m.algorithmic_gemm_bytes("bf16", 32, 6)
     bs, _ = m.algorithmic_gemm_bytes("f16c8_qkv16", 32, 6)
-    assert calls == 101 and 3.5e8 < b16 / calls < 4.5e8 and b16 < bs < 2 * b16
+    assert calls == 101 and m.algorithmic_gemm_bytes("f16c8_qk16", 32, 6)[1] == 113 and 3.5e8 < b16 / calls < 4.5e8 and b16 < bs < 2 * b16
