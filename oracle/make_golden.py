@@ -39,10 +39,24 @@ def summary(t: torch.Tensor, n: int = 256) -> dict:
             "samples": f[::step][:n].numpy().astype(np.float32)}
 
 
-def run_case(name, B, T, dino_depth, betr_depth, seed, full_logits):
-    torch.set_grad_enabled(False)
+def case_weights(kind: str, dino_depth: int, betr_depth: int):
+    """Seeded weights of a fixture case: "plain"; "rescaled" = synth.rescale_function_preserving (operand-range stress, same function);
+    "outliers_g<gain>" = synth.*_state_dict_outliers (trained-like statistics, function changes)."""
+    if kind.startswith("outliers_g"):
+        g = float(kind[len("outliers_g"):])
+        return synth.betr_state_dict_outliers(1234, betr_depth, g), synth.dino_state_dict_outliers(4321, dino_depth, g)
     bsd = synth.betr_state_dict(seed=1234, depth=betr_depth)
     dsd = synth.dino_state_dict(seed=4321, depth=dino_depth)
+    if kind == "rescaled":
+        dsd, bsd = synth.rescale_function_preserving(dsd, bsd)
+    else:
+        assert kind == "plain", kind
+    return bsd, dsd
+
+
+def run_case(name, B, T, dino_depth, betr_depth, seed, full_logits, weights="plain", tol=TOL):
+    torch.set_grad_enabled(False)
+    bsd, dsd = case_weights(weights, dino_depth, betr_depth)
     betr = ref_import.build_betr(depth=betr_depth)
     dino = ref_import.build_dino(depth=dino_depth)
     betr.load_state_dict(bsd, strict=True)
@@ -76,14 +90,17 @@ def run_case(name, B, T, dino_depth, betr_depth, seed, full_logits):
     }
     same_sets = bool((o["topk_idx"].sort(-1)[0] == ref_idx).all())
     print(f"[{name}] oracle-vs-reference max-abs: {errs}  top20 sets equal: {same_sets}")
+    fscale = max(1.0, float(feats.abs().max()) / 8.0)       # (rescaled / outlier weights: features in the hundreds)
     for k, v in errs.items():
-        lim = TOL if k not in ("corners_px",) else 1e-4
+        lim = tol if k not in ("corners_px",) else max(1e-4, tol)
+        if k == "rgb_feat":
+            lim = tol * fscale
         assert v <= lim or (k.startswith("corners") and not same_sets), (name, k, v)
-    assert errs["logits"] <= TOL and errs["rgb_feat"] <= TOL
+    assert errs["logits"] <= tol and errs["rgb_feat"] <= tol * fscale
 
     out = {
         "meta": np.array(json.dumps({"B": B, "T": T, "dino_depth": dino_depth, "betr_depth": betr_depth,
-                                     "input_seed": seed, "betr_seed": 1234, "dino_seed": 4321,
+                                     "input_seed": seed, "betr_seed": 1234, "dino_seed": 4321, "weights": weights,
                                      "oracle_vs_reference": errs, "top20_sets_equal": same_sets})),
         "corners_px": kp.numpy(), "corners_norm": norm_kp.numpy(),
         "topk_idx_sorted": ref_idx.numpy().astype(np.int32),
@@ -166,10 +183,22 @@ def unit_vectors(betr, dino):
     np.savez_compressed(os.path.join(GOLD, "unit_vectors.npz"), **out)
 
 
+def robustness_cases():
+    """Round 3: the REAL reference on weights whose operand ranges stress the 16-bit / e4m3 classes."""
+    # same function as `full_T2` (power-of-two gains moved between a producer and its only consumer), operands up to ~1000
+    run_case("rescaled_T2", 1, 2, 12, 12, 7, False, weights="rescaled")
+    # trained-like outliers at half gain: logits rms 1.9 / max 9.5; the reference's and the oracle's fp32 forwards differ by their own
+    # re-association noise there, so the restatement is pinned at 5e-4 instead of 2e-5
+    run_case("outliers_g0.5_T2", 1, 2, 12, 12, 11, False, weights="outliers_g0.5", tol=5e-4)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     assert ref_import.available(), "reference tree required"
+    if "--only-robustness" in sys.argv:
+        robustness_cases()
+        return
     # key/shape manifest of the reference modules (pins the drop-in state_dict contract)
     betr = ref_import.build_betr(12)
     dino = ref_import.build_dino(12)
@@ -183,6 +212,7 @@ def main():
     b, d = run_case("full_T2", 1, 2, 12, 12, 7, True)
     unit_vectors(b, d)
     run_case("full_T6", 1, 6, 12, 12, 11, False)
+    robustness_cases()
     print("golden fixtures written to", GOLD)
 
 
