@@ -30,6 +30,14 @@ import sys
 import threading
 import time
 
+# Rank 0 of a multi-rank launch must be able to report a failure even while its main thread is blocked inside a C++ call (process-group
+# rendezvous, an NCCL collective, a device synchronise) -- Python runs signal handlers only between bytecodes.  So SIGTERM (what
+# torch.distributed.run sends the survivors when a rank dies) is BLOCKED here, before `import torch` creates any thread (threads inherit
+# the mask), and a dedicated thread picks it up with sigwait() and prints the failure line (see _sigterm_watcher below).
+_WATCH_SIGTERM = int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("RANK", "0") == "0" and hasattr(signal, "pthread_sigmask")
+if _WATCH_SIGTERM:
+    signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -201,7 +209,7 @@ def init_dist(args):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=to)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=to)
-        if rank == 0:
+        if rank == 0 and not _WATCH_SIGTERM:
             signal.signal(signal.SIGTERM, _on_sigterm)      # torch.distributed.run terminates the survivors when a rank fails
     return world, rank, local_rank, dist
 
@@ -210,7 +218,7 @@ def init_dist(args):
 # What rank 0 knows so far (filled stage by stage).  If any rank fails -- its own exception, a collective timeout, or the
 # launcher's SIGTERM after ANOTHER rank died -- rank 0 still prints ONE JSON line carrying n_gpus and whatever of
 # per_rank_ms_per_step / corner_allgather_ms was measured, plus `error`, and exits non-zero.
-PROGRESS = {"line": {}, "stage": "start", "printed": False}
+PROGRESS = {"line": {"n_gpus": int(os.environ.get("WORLD_SIZE", "1"))}, "stage": "start", "printed": False}
 
 
 def emit_failure(reason: str) -> None:
@@ -226,6 +234,17 @@ def emit_failure(reason: str) -> None:
 def _on_sigterm(signum, frame):
     emit_failure("terminated by the launcher: another rank failed (see its traceback above)")
     os._exit(1)
+
+
+def _sigterm_watcher():
+    signal.sigwait({signal.SIGTERM})
+    emit_failure("terminated by the launcher: another rank failed (see its traceback above)")
+    sys.stdout.flush()
+    os._exit(1)
+
+
+if _WATCH_SIGTERM:
+    threading.Thread(target=_sigterm_watcher, daemon=True, name="bench-sigterm-watcher").start()
 
 
 def interruptible_sync(device):
