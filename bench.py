@@ -291,7 +291,8 @@ def timed_steps(step, steps: int, warmup: int, world: int, dist, sync, device=No
     dt = time.perf_counter() - t0
     per_rank = [dt]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
+        on_host = device is None or dist.get_backend() == "gloo"      # (gloo gathers host tensors only: CPU plumbing / --single-device-test)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if on_host else device)
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         per_rank = [float(g.item()) for g in gathered]
@@ -515,6 +516,12 @@ class ModeRun:
         self.prec, self.args, self.device, self.world, self.rank, self.dist = prec, args, device, world, rank, dist
         self.images, self.bbox, self.mask = images, bbox, mask
         self.hip_ops, self.gather = hip_ops, gather_corners
+        if getattr(args, "single_device_test", False) and world > 1:
+            def host_staged_gather(kp, w):          # TEST mode only (gloo): the product's gather is dist.gather_corners on RCCL
+                parts = [torch.zeros(kp.shape, dtype=kp.dtype) for _ in range(w)]
+                dist.all_gather(parts, kp.detach().cpu())
+                return torch.cat(parts, 0).to(kp.device)
+            self.gather = host_staged_gather
         self.enc, self.dec = build_models(prec, device)
         self.B, self.T = images.shape[:2]
         self.kp_all = torch.empty((self.B, 8, 2), dtype=torch.float32, device=device)
@@ -829,6 +836,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--cpu-plumbing", action="store_true",
                     help="run ONLY the launcher / barrier / corner-gather plumbing on CPU (tests); needs --backend gloo")
+    ap.add_argument("--single-device-test", action="store_true",
+                    help="TEST ONLY: every rank uses cuda:0 and the collectives go through gloo -- exercises the whole N > 1 bench flow "
+                         "(sharded seeds, lane agreement, barriers, corner gather, failure report) with the real kernels on a 1-GPU box; "
+                         "not a measurement (the ranks share one GPU) and not RCCL")
     ap.add_argument("--dry-run", action="store_true",
                     help="print the exact launch command + environment `--gpus N` turns into (JSON) and exit")
     ap.add_argument("--dist-timeout", type=int, default=600, help="collective timeout in seconds (a dead rank must not hang the others)")
@@ -880,9 +891,11 @@ def run(args):
         return cpu_plumbing(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback for the product path")
-    if args.backend != "nccl":
+    if args.backend != "nccl" and not (args.single_device_test and args.backend == "gloo"):
         raise SystemExit("the GPU sweep runs on RCCL (--backend nccl)")
     _, _, local_rank = dist_env()
+    if args.single_device_test:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     world, rank, local_rank, dist = init_dist(args)

@@ -114,3 +114,36 @@ def test_workload_label_names_the_config_actually_run():
     b16, calls = m.algorithmic_gemm_bytes("bf16", 32, 6)
     bs, _ = m.algorithmic_gemm_bytes("f16c8_qkv16", 32, 6)
     assert calls == 101 and m.algorithmic_gemm_bytes("f16c8_qk16", 32, 6)[1] == 113 and 3.5e8 < b16 / calls < 4.5e8 and b16 < bs < 2 * b16
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_rank_flow_with_the_real_kernels_on_one_gpu():
+    """The N > 1 flow of bench.py -- per-rank seeded shards, in-flight lane agreement, barrier-bracketed timed steps, max over ranks,
+    corner gather every step, gather-latency probe -- executed with the REAL kernels by two ranks that share cuda:0
+    (`--single-device-test`: collectives through gloo, since RCCL refuses two ranks on one device).  Not a measurement and not RCCL;
+    it is the only multi-rank GPU execution a 1-GPU box allows, and what the driver's multi-GPU sweep runs except for the backend."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device-test",
+                        "--steps", "2", "--warmup", "1", "--no-strict", "--no-fp8", "--no-cpu-baseline", "--no-h2d", "--no-pnp", "--no-parity",
+                        "--dist-timeout", "300"], capture_output=True, text=True, env=_env(), timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _one_line(r)
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and j["config"]["parallelism"] == "dp2"
+    assert len(j["per_rank_ms_per_step"]) == 2 and j["corner_allgather_ms"] > 0 and j["value"] > 0
+    assert j["config"]["workload"].startswith("configs[1]:")
+
+
+@pytest.mark.gpu
+def test_rank_failure_on_the_gpu_box_is_reported():
+    """`--gpus 2` on a box with ONE GPU: rank 1 cannot take cuda:1 and dies while rank 0 blocks in the RCCL rendezvous (a C++ call).
+    The launch must end at once with ONE JSON line carrying n_gpus and `error`, and a non-zero rc (the sigwait watcher of bench.py)."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-timeout", "120"],
+                       capture_output=True, text=True, env=_env(), timeout=600)
+    assert r.returncode != 0
+    j = _one_line(r)
+    assert j["n_gpus"] == 2 and j["value"] is None and "error" in j
