@@ -19,6 +19,7 @@
 // NS = 2 is the split-bf16 strict mode: Q, K, V, P each carry (hi, lo) and every product issues
 // hi*hi + hi*lo + lo*hi.
 #include "bd_common.h"
+#include <type_traits>
 
 #ifdef BD_ATTN_PROBE
 // Measurement build only (tools/attn_phase_probe.py): per-wave shader-clock stamps of the ping-pong kernel's segments.
@@ -62,7 +63,7 @@ __device__ __forceinline__ int vswz(int d) { return ((d >> 1) ^ (d >> 4)) & 7; }
 // (The streaming form re-stages every tile in each of the pair's three query-block workgroups: ~40 % of its key-tile time is staging
 // work, profiles/r2_attention.md section 8.)
 template <class T, int NS, int HD, int NW, int OUTMODE = 0, int RES = 0>
-__global__ __launch_bounds__(NW * 64, RES ? 5 : 2) void attn_kernel(const AttnArgs p) {      // (HIP: 2nd argument = min waves per SIMD)
+__global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) void attn_kernel(const AttnArgs p) {      // (HIP: 2nd argument = min waves per SIMD)
     bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 vec8;
     constexpr int NT = NW * 64;
@@ -352,15 +353,24 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : 2) void attn_kernel(const AttnAr
     STORE_TILE(0)
     __syncthreads();
     AP(61)
-    for (int kt = 0; kt < nt; ++kt) {
+    // One key tile.  Two instances: TAIL 0 = any tile (a ragged last one masks its scores), TAIL 2 = a ragged last tile of <= 16 keys
+    // (DINOv2: 261 = 4 x 64 + 5), which skips the second 32-key M-tile of S^T and the three 16-key P.V groups that lie wholly past
+    // the sequence -- their scores would be masked to -inf and their P exactly 0, so the result is bit-identical and the tile costs
+    // 6 instead of 16 MFMAs per plane product.  The tail is PEELED: the same skip as wave-uniform branches inside one loop body
+    // costs the main loop its schedule (seq 261: 121 -> 182 us), and so does skipping the staging of the tail's unused rows
+    // (profiles/r3_attention_tail.md).  hd 64 only: the hd-96 split-plane instances have no registers for a second tile instance.
+    const bool small_tail = HD == 64 && nt > 1 && seq % KT != 0 && seq % KT <= 16;
+    auto tile = [&](const int kt, auto tail_c) {
+        constexpr int TAIL = decltype(tail_c)::value;
+        constexpr int KMN = TAIL == 2 ? 1 : 2, GN = TAIL == 2 ? 1 : 4;
         if (kt + 1 < nt) { LOAD_TILE(kt + 1) }
         const unsigned char* cur = lds + (NBUF == 2 ? (kt & 1) : 0) * BUF_BYTES;
         if (kt < 7) AP(kt * 8)
 
         // ---- S^T = K . Q^T  (two 32-key M-tiles)
-        f32x16 sacc[2];
+        f32x16 sacc[KMN];
 #pragma unroll
-        for (int km = 0; km < 2; ++km) {
+        for (int km = 0; km < KMN; ++km) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[km][r] = 0.f;
 #pragma unroll
@@ -380,10 +390,9 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : 2) void attn_kernel(const AttnAr
         // (times log2 e) is folded into the exponent:  p = exp2(s*sc - m*sc)  = one FMA + v_exp_f32 per score.
         if (kt < 7) AP(kt * 8 + 1)
         float tmax = -INFINITY;
-        const bool tail = (kt + 1) * KT > seq;
-        if (tail) {
+        if (TAIL == 2 || (kt + 1) * KT > seq) {
 #pragma unroll
-            for (int km = 0; km < 2; ++km)
+            for (int km = 0; km < KMN; ++km)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * KT + km * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : 2) void attn_kernel(const AttnAr
                 }
         }
 #pragma unroll
-        for (int km = 0; km < 2; ++km)
+        for (int km = 0; km < KMN; ++km)
 #pragma unroll
             for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[km][r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : 2) void attn_kernel(const AttnAr
         const float mneg = -m_run * sc;
         float psum = 0.f;
 #pragma unroll
-        for (int km = 0; km < 2; ++km)
+        for (int km = 0; km < KMN; ++km)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[km][r], sc, mneg));
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : 2) void attn_kernel(const AttnAr
 
         // ---- O^T += V^T . P^T   (four 16-key groups)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < GN; ++g) {
             vec8 pf[NS];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -452,7 +461,9 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : 2) void attn_kernel(const AttnAr
         if (kt < 7) AP(kt * 8 + 5)
         __syncthreads();
         if (kt < 7) AP(kt * 8 + 6)
-    }
+    };
+    for (int kt = 0; kt < nt - (small_tail ? 1 : 0); ++kt) tile(kt, std::integral_constant<int, 0>{});
+    if (small_tail) tile(nt - 1, std::integral_constant<int, 2>{});
     }      // (RES == 0)
 #undef LOAD_TILE
 #undef STORE_TILE

@@ -899,8 +899,9 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
         // Issue cursor: slab number `ig` of this workgroup's slab sequence (all its tiles, K-slab by K-slab) is the next one
         // to fetch, into stage ig & 1.  Consumers are released into slab g by barrier B(g); after B(g) the stage of slab g-1
         // is free, so slab g+1 may be fetched.  At a tile boundary the consumers signal "done with the tile's last slab" with
-        // one extra barrier X before they start their (LDS-free) epilogue: the producers then already fetch the SECOND slab
-        // of the next tile, so both of its first slabs land while the epilogue runs.
+        // one extra barrier X before their epilogue, whose scratch is that slab's stage: the next tile's FIRST slab (fetched after
+        // B of the last slab, into the other stage) lands while the epilogue runs; its second slab follows B of the first, when
+        // the scratch is free again.
         int ig = 0, it = t_begin + (bid >> 3), ikt = 0, im0 = 0, in0 = 0, itn = 0;
         if (it < t_end) tile_origin(it, im0, in0);
         if constexpr (EP == 2) {
