@@ -118,3 +118,19 @@ def test_layernorm_random_row_counts(hip, prec):
             got, eps = hip_ops.from_operand(out, prec).cpu(), EPS[prec]
         ref = torch.nn.functional.layer_norm(x.double(), (C,), gamma.double(), beta.double(), 1e-5).float()
         assert (got - ref).abs().max().item() < 2 * eps * max(1.0, ref.abs().max().item()) + 1e-5, (prec, rows, C)
+
+
+@pytest.mark.parametrize("n_maps,H,W,levels,seed", [(3, 224, 224, 5, 1), (16, 224, 224, 3, 2), (8, 112, 112, 7, 3), (5, 56, 98, 2, 4),
+                                                     (1, 224, 224, 1, 5), (64, 28, 28, 4, 6), (2, 224, 224, 1000, 7)])
+def test_decode_topk_random_maps_with_ties(hip, n_maps, H, W, levels, seed):
+    """Top-20 decode on maps quantised to a few levels (ties everywhere, across the rank-20 boundary too): index sets, order and
+    the mean keypoints must equal the oracle's (lower index wins a tie), bit for bit."""
+    from oracle import boxdreamer_oracle as orc
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randint(0, levels, (1, n_maps, H, W), generator=g).float()
+    hm = (q / max(levels - 1, 1)) * 2.0 - 1.0 if levels > 1 else torch.full((1, n_maps, H, W), 0.25)
+    kp, kn, idx = hip_ops.decode_topk(hm.cuda())
+    on, okp, oidx = orc.recover_bb8_corners(hm)
+    assert torch.equal(idx.cpu().long().reshape(oidx.shape), oidx)
+    assert torch.equal(kp.cpu().reshape(okp.shape), okp)
+    assert (kn.cpu().reshape(on.shape) - on).abs().max().item() < 1e-6
