@@ -13,6 +13,8 @@ biases, LN weights near 1) so that softmax / LayerNorm are not degenerate.
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 import torch
 
@@ -74,7 +76,13 @@ def _t(a: np.ndarray) -> torch.Tensor:
 
 def betr_state_dict(seed: int = 1234, depth: int = 12, d_model: int = 768, nhead: int = 8,
                     patch: int = 14, box_dim: int = 8) -> dict:
-    """Random BETR decoder weights keyed exactly like the reference state_dict."""
+    """Random BETR decoder weights keyed exactly like the reference state_dict.  (A fresh dict per call over memoised tensors --
+    generating 88 M seeded values takes seconds; callers replace entries, never write into a tensor in place.)"""
+    return dict(_betr_state_dict(int(seed), int(depth), int(d_model), int(nhead), int(patch), int(box_dim)))
+
+
+@functools.lru_cache(maxsize=4)
+def _betr_state_dict(seed, depth, d_model, nhead, patch, box_dim) -> dict:
     hd = d_model // nhead
     pf = patch * patch * box_dim
     sd = {}
@@ -108,7 +116,12 @@ def betr_state_dict(seed: int = 1234, depth: int = 12, d_model: int = 768, nhead
 
 def dino_state_dict(seed: int = 4321, depth: int = 12, dim: int = 768, nheads: int = 12,
                     patch: int = 14, img_size: int = 518, nreg: int = 4) -> dict:
-    """Random DINOv2 ViT weights keyed like hub `dinov2_vitb14_reg` (vendored copy's names)."""
+    """Random DINOv2 ViT weights keyed like hub `dinov2_vitb14_reg` (vendored copy's names).  (Memoised like betr_state_dict.)"""
+    return dict(_dino_state_dict(int(seed), int(depth), int(dim), int(nheads), int(patch), int(img_size), int(nreg)))
+
+
+@functools.lru_cache(maxsize=4)
+def _dino_state_dict(seed, depth, dim, nheads, patch, img_size, nreg) -> dict:
     sd = {}
     npos = (img_size // patch) ** 2 + 1
 
