@@ -52,6 +52,11 @@ constexpr int KT = 64;   // keys per tile
 //    the (d >> 4) term spreads them over all 8 (<= 2-way).
 __device__ __forceinline__ int vswz(int d) { return ((d >> 1) ^ (d >> 4)) & 7; }
 
+// low / high 16-bit halves of two dwords as one dword (the 4 x 4 register transposition of the V staging): one v_perm_b32 each
+// (written as and / shift / or hipcc emits two VALU instructions per pair: 32 instead of 16 per staged micro-tile)
+__device__ __forceinline__ unsigned pack_lo16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }   // (a & 0xffff) | (b << 16)
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // (a >> 16) | (b & 0xffff0000)
+
 // OUTSPLIT: single-pass f16 attention whose result is written as split-bf16 (hi, lo) planes -- the strict mode's
 // attention (its GEMMs stay split-bf16 x3): q/k are RMS-normalised and P is in [0, 1], so one f16 pass costs ~1e-4 on
 // the logits while the x3 attention kernel is register-bound at one wave per SIMD.
@@ -160,8 +165,8 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) v
                     const unsigned a0 = r4[0][w], a1 = r4[1][w], a2 = r4[2][w], a3 = r4[3][w];
                     const int d = dc * 8 + 2 * w;
                     uint2 lo, hi;
-                    lo.x = (a0 & 0xffffu) | (a1 << 16); lo.y = (a2 & 0xffffu) | (a3 << 16);
-                    hi.x = (a0 >> 16) | (a1 & 0xffff0000u); hi.y = (a2 >> 16) | (a3 & 0xffff0000u);
+                    lo.x = pack_lo16(a0, a1); lo.y = pack_lo16(a2, a3);
+                    hi.x = pack_hi16(a0, a1); hi.y = pack_hi16(a2, a3);
                     *(uint2*)(vl + d * rstride + (vd ^ (swz ? vswz(d) << 4 : 0))) = lo;
                     *(uint2*)(vl + (d + 1) * rstride + (vd ^ (swz ? vswz(d + 1) << 4 : 0))) = hi;
                 }
@@ -245,8 +250,8 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) v
                 const unsigned a0 = rv[s][0][w], a1 = rv[s][1][w], a2 = rv[s][2][w], a3 = rv[s][3][w]; \
                 const int d = vm_dc * 8 + 2 * w;                                              \
                 uint2 lo, hi;                                                                 \
-                lo.x = (a0 & 0xffffu) | (a1 << 16); lo.y = (a2 & 0xffffu) | (a3 << 16);       \
-                hi.x = (a0 >> 16) | (a1 & 0xffff0000u); hi.y = (a2 >> 16) | (a3 & 0xffff0000u); \
+                lo.x = pack_lo16(a0, a1); lo.y = pack_lo16(a2, a3);       \
+                hi.x = pack_hi16(a0, a1); hi.y = pack_hi16(a2, a3); \
                 *(uint2*)(vl + d * 128 + (vdst ^ (vswz(d) << 4))) = lo;                \
                 *(uint2*)(vl + (d + 1) * 128 + (vdst ^ (vswz(d + 1) << 4))) = hi;    \
             }                                                                                 \
@@ -657,8 +662,8 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
                 const unsigned a0 = rv[0][w], a1 = rv[1][w], a2 = rv[2][w], a3 = rv[3][w];
                 const int d = vm_dc * 8 + 2 * w;
                 uint2 lo, hi;
-                lo.x = (a0 & 0xffffu) | (a1 << 16); lo.y = (a2 & 0xffffu) | (a3 << 16);
-                hi.x = (a0 >> 16) | (a1 & 0xffff0000u); hi.y = (a2 >> 16) | (a3 & 0xffff0000u);
+                lo.x = pack_lo16(a0, a1); lo.y = pack_lo16(a2, a3);
+                hi.x = pack_hi16(a0, a1); hi.y = pack_hi16(a2, a3);
                 *(uint2*)(vl + d * 128 + (vdst ^ (vswz(d) << 4))) = lo;
                 *(uint2*)(vl + (d + 1) * 128 + (vdst ^ (vswz(d + 1) << 4))) = hi;
             }
