@@ -62,6 +62,99 @@ __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ 
     store_operand8<T, NS>(out, plane, row * kpad + j * 8, v);
 }
 
+// ---------------------------------------------------------------- row-strip forms of im2col / patchify (patch 14: the path's geometry)
+// The one-thread-per-chunk kernels above gather 2-byte elements (14-pixel runs per plane and patch row: 1.4 / 2.2 TB/s on the
+// path's shapes).  im2col: one workgroup takes a horizontal strip of <= 8 patches of one patch row: every (plane, pixel row) of the
+// strip is one contiguous run of <= 112 pixels, loaded in 4-byte pieces into an LDS image [patch][plane][14 x 14] of fp32 values,
+// and the operand rows leave as whole 16-byte chunks.  patchify: see patchify_pair_kernel.  Same arithmetic per element as the
+// kernels above (same bits: tools/layout_hash.py).
+constexpr int STRIP = 8, P14 = 14, PP14 = P14 * P14;
+
+__device__ __forceinline__ void load_pair_f32(const void* src, int64_t e, int dtype, float& a, float& b) {       // elements e, e + 1 (e even)
+    if (dtype == BD_DTYPE_F32) {
+        const float2 v = *(const float2*)((const float*)src + e);
+        a = v.x; b = v.y;
+    } else {
+        const unsigned u = *(const unsigned*)((const unsigned short*)src + e);
+        if (dtype == BD_DTYPE_BF16) {
+            a = __builtin_bit_cast(float, u << 16); b = __builtin_bit_cast(float, u & 0xffff0000u);
+        } else {
+            a = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); b = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+        }
+    }
+}
+
+// planes: 3 (images, normalised) or 8 (heatmaps).  Fills tile[p][c][py * 14 + px] for the strip's np patches.
+template <int NC, bool NORMALISE>
+__device__ __forceinline__ void strip_load(const void* src, int dtype, int64_t n, int size, int gy, int x0, int np, float* tile) {
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    // lane = 4-byte piece of the run (<= 56 of 64 lanes), wave = (plane, pixel row) mod 4: no per-element index division
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane >= np * (P14 / 2)) return;
+    const int x = 2 * lane, p = x / P14, px = x % P14;  // (14 is even: both pixels of a piece lie in the same patch)
+    float* dcol = tile + p * NC * PP14 + px;
+    const int64_t base = ((n * NC) * size + gy * P14) * (int64_t)size + x0 + x;
+#pragma unroll 4
+    for (int cy = wid; cy < NC * P14; cy += 4) {
+        const int c = cy / P14, py = cy - c * P14;
+        float a, b;
+        load_pair_f32(src, base + ((int64_t)c * size + py) * size, dtype, a, b);
+        if constexpr (NORMALISE) { a = (a - mean[c < 3 ? c : 0]) / stdv[c < 3 ? c : 0]; b = (b - mean[c < 3 ? c : 0]) / stdv[c < 3 ? c : 0]; }   // encoder/dinov2.py:45-46
+        float* d = dcol + c * PP14 + py * P14;
+        d[0] = a; d[1] = b;
+    }
+}
+
+template <class T, int NS>
+__global__ __launch_bounds__(256) void im2col_strip_kernel(const void* __restrict__ img, int dtype, void* __restrict__ out_,
+                                                           int64_t plane, int n_images, int size, int kpad) {
+    bd_saturating_conversions();
+    __shared__ __attribute__((aligned(16))) float tile[STRIP * 3 * PP14];
+    const int grid = size / P14, nsb = (grid + STRIP - 1) / STRIP, cpr = kpad / 8, kreal = 3 * PP14;
+    const int sb = blockIdx.x % nsb, gy = (blockIdx.x / nsb) % grid;
+    const int64_t n = blockIdx.x / (nsb * grid);
+    const int gx0 = sb * STRIP, np = grid - gx0 < STRIP ? grid - gx0 : STRIP;
+    strip_load<3, true>(img, dtype, n, size, gy, gx0 * P14, np, tile);
+    __syncthreads();
+    T* out = (T*)out_;
+    for (int i = threadIdx.x; i < np * cpr; i += 256) {
+        const int p = i / cpr, kc = i % cpr;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int k = kc * 8 + j; v[j] = k < kreal ? tile[p * kreal + k] : 0.f; }     // k = c*196 + py*14 + px
+        const int64_t row = (n * grid + gy) * grid + gx0 + p;
+        store_operand8<T, NS>(out, plane, row * kpad + kc * 8, v);
+    }
+}
+
+// patchify without the LDS: a thread takes the two pixels (y, x), (y, x + 1) of ALL 8 channel planes (eight 4-byte loads, 256
+// contiguous bytes per wave instruction) -- exactly the two adjacent 8-channel chunks (py, px), (py, px + 1) of one operand row.
+// (The strip form with an LDS image measured slower than the gather it replaces: 161 against 114 us.)
+template <class T, int NS>
+__global__ __launch_bounds__(256) void patchify_pair_kernel(const void* __restrict__ heat, int dtype, void* __restrict__ out_,
+                                                            int64_t plane, int n_images, int size, int kpad) {
+    bd_saturating_conversions();
+    const int half = size / 2, grid = size / P14, cpr = kpad / 8;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)n_images * size * half) return;
+    const int xp = (int)(t % half), y = (int)((t / half) % size);
+    const int64_t n = t / ((int64_t)half * size);
+    const int x = 2 * xp, gx = x / P14, px = x % P14, gy = y / P14, py = y % P14;
+    float a[8], b[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) load_pair_f32(heat, ((n * 8 + c) * size + y) * (int64_t)size + x, dtype, a[c], b[c]);
+    T* out = (T*)out_;
+    const int64_t row = (n * grid + gy) * grid + gx;
+    const int j = py * P14 + px;
+    store_operand8<T, NS>(out, plane, row * kpad + j * 8, a);
+    store_operand8<T, NS>(out, plane, row * kpad + (j + 1) * 8, b);
+    if (py == 0) {                                       // the row's zero padding chunks [196, kpad / 8): by the patch's first pixel row
+        const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int jj = PP14 + px / 2; jj < cpr; jj += P14 / 2) store_operand8<T, NS>(out, plane, row * kpad + jj * 8, z);
+    }
+}
+
 __global__ __launch_bounds__(256) void prefix_kernel(float* __restrict__ x, const float* __restrict__ prefix,
                                                      int n_images, int tpi, int n_prefix, int dim) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -220,8 +313,15 @@ extern "C" int bd_im2col_images(const void* images, int img_dtype, void* out16, 
     const int grid = size / patch;
     const int64_t total = (int64_t)n_images * grid * grid * (kpad / 8);
     hipStream_t s = (hipStream_t)stream;
-    BD_PREC_SWITCH(im2col_kernel, dim3(nblk(total)), dim3(256), 0, s, images, img_dtype, out16, out_plane,
-                   n_images, size, patch, kpad)
+    // (4-byte input pieces: even image width and an aligned base)
+    if (patch == P14 && size % 2 == 0 && ((uintptr_t)images & 7) == 0) {
+        const int nsb = (grid + STRIP - 1) / STRIP;
+        BD_PREC_SWITCH(im2col_strip_kernel, dim3((unsigned)((int64_t)n_images * grid * nsb)), dim3(256), 0, s, images, img_dtype, out16,
+                       out_plane, n_images, size, kpad)
+    } else {
+        BD_PREC_SWITCH(im2col_kernel, dim3(nblk(total)), dim3(256), 0, s, images, img_dtype, out16, out_plane,
+                       n_images, size, patch, kpad)
+    }
     BD_CHECK_LAUNCH();
     return BD_OK;
 }
@@ -234,8 +334,13 @@ extern "C" int bd_patchify_heatmaps(const void* heat, int in_dtype, void* out16,
     const int grid = size / patch;
     const int64_t total = (int64_t)n_images * grid * grid * (kpad / 8);
     hipStream_t s = (hipStream_t)stream;
-    BD_PREC_SWITCH(patchify_kernel, dim3(nblk(total)), dim3(256), 0, s, heat, in_dtype, out16, out_plane,
-                   n_images, size, patch, kpad)
+    if (patch == P14 && size % 2 == 0 && ((uintptr_t)heat & 7) == 0) {
+        BD_PREC_SWITCH(patchify_pair_kernel, dim3(nblk((int64_t)n_images * size * (size / 2))), dim3(256), 0, s, heat, in_dtype, out16,
+                       out_plane, n_images, size, kpad)
+    } else {
+        BD_PREC_SWITCH(patchify_kernel, dim3(nblk(total)), dim3(256), 0, s, heat, in_dtype, out16, out_plane,
+                       n_images, size, patch, kpad)
+    }
     BD_CHECK_LAUNCH();
     return BD_OK;
 }
