@@ -134,3 +134,35 @@ def test_decode_topk_random_maps_with_ties(hip, n_maps, H, W, levels, seed):
     assert torch.equal(idx.cpu().long().reshape(oidx.shape), oidx)
     assert torch.equal(kp.cpu().reshape(okp.shape), okp)
     assert (kn.cpu().reshape(on.shape) - on).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "bf16x3", "f16c8"])
+@pytest.mark.parametrize("size,n", [(224, 2), (112, 3), (98, 2), (56, 5), (28, 1)])
+def test_im2col_and_patchify_sizes_and_dtypes(hip, prec, size, n):
+    """The strip / pair forms of the two input-layout kernels (patch 14) on grids that are not a multiple of the 8-patch strip, a single
+    image, and all three input dtypes, against torch.unfold / the oracle's patchify."""
+    import torch.nn.functional as F
+    from oracle import boxdreamer_oracle as orc
+    g = torch.Generator().manual_seed(size * 7 + n)
+    grid = size // 14
+    eps = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11, "bf16x3": 2.0 ** -15, "f16c8": 2.0 ** -14}[prec]
+
+    def decode(a):
+        if prec == "f16c8":
+            hi, lo, _ = hip_ops.f16c8_decode(a)
+            return (hi + lo).cpu()
+        return hip_ops.from_operand(a, prec).cpu()
+
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        img = torch.rand(n, 3, size, size, generator=g).to(dt)
+        heat = (torch.rand(n, 8, size, size, generator=g) * 2 - 1).to(dt)
+        got = decode(hip_ops.im2col_images(img.cuda(), prec=prec))
+        mean = torch.tensor(orc._IMAGENET_MEAN).view(1, 3, 1, 1)
+        std = torch.tensor(orc._IMAGENET_STD).view(1, 3, 1, 1)
+        cols = F.unfold((img.float() - mean) / std, 14, stride=14).transpose(1, 2).reshape(n * grid * grid, 588)
+        assert torch.equal(got[:, 588:], torch.zeros(n * grid * grid, 52))
+        assert (got[:, :588] - cols).abs().max().item() < 8 * eps * 3 + 1e-6, (prec, size, dt)
+        got = decode(hip_ops.patchify_heatmaps(heat.cuda(), prec=prec))
+        ref = orc.patchify(heat.float(), 14, 8).reshape(n * grid * grid, 1568)
+        assert torch.equal(got[:, 1568:], torch.zeros(n * grid * grid, 32))
+        assert (got[:, :1568] - ref).abs().max().item() < 2 * eps + 1e-7, (prec, size, dt)
