@@ -394,8 +394,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <class T, int NS, int BK, int WM, int WN, int MI, int NI>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gemm_args p) {
+// NSTG > 2 (small-batch launches: fewer tiles than the chip has workgroup slots, so a tile's time is the chain of its slabs' DMA
+// latencies, not the matrix work): a ring of NSTG stages with NSTG - 1 slabs in flight and counted vmcnt waits; the arithmetic
+// (K order per row) is that of the 2-stage form, so a row's result does not depend on which form a launch takes.
+template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NSTG = 2>
+__global__ __launch_bounds__(WM * WN * 64, NSTG == 2 ? 2 : 1) void gemm_kernel_glds(const bd_gemm_args p) {
     bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 frag_t;
     constexpr int ESZ = OpGeom<T>::ESZ, KSTEP = OpGeom<T>::KSTEP, CPF = OpGeom<T>::CPF;
@@ -411,7 +414,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gem
     constexpr int KS = BK / KSTEP;
     static_assert(KS >= 1 && CH * 16 == ROWB && (CH == 4 || CH == 8), "slab geometry");
     constexpr int EPI_SCRATCH = NWAVE * 32 * NI * 32 * 4;   // the wide epilogue's per-wave transpose scratch
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES > EPI_SCRATCH ? 2 * STAGE_BYTES : EPI_SCRATCH];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTG * STAGE_BYTES > EPI_SCRATCH ? NSTG * STAGE_BYTES : EPI_SCRATCH];
+    constexpr int PPW = (PPW_A + PPW_W) * NS;         // DMA pieces this wave issues per slab
+    static_assert(NSTG >= 2 && NSTG <= 4 && (NSTG - 2) * PPW < 64, "ring depth / vmcnt range");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -454,13 +459,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel_glds(const bd_gem
 #endif
     BD_PROBE(60)
     DMA_SLAB(0, 0)
+    if constexpr (NSTG > 2) {
+#pragma unroll
+        for (int s2 = 1; s2 < NSTG - 1; ++s2)
+            if (s2 < nk) { DMA_SLAB(s2, s2 * ROWB) }
+    }
     for (int kt = 0; kt < nk; ++kt) {
         BD_PROBE(kt * 3)
-        slab_barrier();                                    // slab kt landed; buffer (kt+1)&1 is free
+        if constexpr (NSTG == 2) {
+            slab_barrier();                                // slab kt landed; buffer (kt+1)&1 is free
+        } else {
+            // everything but the (up to NSTG - 2) younger slabs' pieces of this wave has landed; then everyone else's
+            const int younger = nk - 1 - kt < NSTG - 2 ? nk - 1 - kt : NSTG - 2;
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         BD_PROBE(kt * 3 + 1)
-        if (kt + 1 < nk) { DMA_SLAB((kt + 1) & 1, (kt + 1) * ROWB) }
+        if (kt + NSTG - 1 < nk) { DMA_SLAB((kt + NSTG - 1) % NSTG, (kt + NSTG - 1) * ROWB) }      // into the stage of slab kt - 1
         BD_PROBE(kt * 3 + 2)
-        const unsigned char* base = lds + (kt & 1) * STAGE_BYTES;
+        const unsigned char* base = lds + (kt % NSTG) * STAGE_BYTES;
         // fragments are double-buffered in registers (one plane only: two sets next to 128 accumulators would
         // spill in the split mode): the LDS reads of k-step ks+1 are in flight while the MFMAs of ks issue
         constexpr int FB = NS == 1 ? 2 : 1;
@@ -1474,10 +1494,10 @@ template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_p
 #undef BD_PC_LAUNCH
 }
 
-template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_glds(const bd_gemm_args& a, hipStream_t s) {
+template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NSTG = 2> void launch_glds(const bd_gemm_args& a, hipStream_t s) {
     constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32;
     const int tiles = ((a.M + TBM - 1) / TBM) * ((a.N + TBN - 1) / TBN);
-    hipLaunchKernelGGL((gemm_kernel_glds<T, NS, BK, WM, WN, MI, NI>), dim3(tiles), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((gemm_kernel_glds<T, NS, BK, WM, WN, MI, NI, NSTG>), dim3(tiles), dim3(WM * WN * 64), 0, s, a);
 }
 
 // Compute units of the current device (MI355X: 256; partitioned / harvested parts differ): the tile-choice model counts
@@ -1663,10 +1683,23 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
             }
         } else if (e256 >= e128 && e256 >= e64)
             launch_glds<T, NS, BK, 2, 4, 4, 2>(a, s);             // 256 x 256, one tile per workgroup
-        else if (e128 >= e64)
-            launch_glds<T, NS, BK, 2, 2, 2, 2>(a, s);             // 128 x 128, 2 workgroups / CU
-        else
-            launch_glds<T, NS, BK, 2, 2, 1, 1>(a, s);             // 64 x 64 (latency mode: batch 1, M = 1536)
+        else {
+            // Sparse launches (small batch: every tile gets its own workgroup slot at once, so the launch lasts one tile's chain of
+            // slab latencies): the 4-stage ring form of the same tile (three slabs in flight; 128 / 64 KiB of LDS: one / two per CU).
+            const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128), t64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
+#ifdef BD_EXP_NO_DEEP_RING
+            const bool deep_ok = false;
+#else
+            const bool deep_ok = true;
+#endif
+            if (e128 >= e64) {
+                if (deep_ok && t128 <= kCUs) launch_glds<T, NS, BK, 2, 2, 2, 2, 4>(a, s);
+                else launch_glds<T, NS, BK, 2, 2, 2, 2>(a, s);    // 128 x 128, 2 workgroups / CU
+            } else {
+                if (deep_ok && t64 <= 2 * kCUs) launch_glds<T, NS, BK, 2, 2, 1, 1, 4>(a, s);
+                else launch_glds<T, NS, BK, 2, 2, 1, 1>(a, s);    // 64 x 64 (latency mode: batch 1, M = 1536)
+            }
+        }
     }
     bd_trace_close(s, slot);
     BD_CHECK_LAUNCH();
