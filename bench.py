@@ -429,6 +429,24 @@ def _rocprof_pass(counters, child_args, timeout_s=600):
     return files[0]
 
 
+# LDS pass (SQ block, 8 slots): instruction count, cycles the LDS pipe is busy / stalls issue, conflict cycles, all LDS-array cycles,
+# next to the wave / busy cycle bases they are read against (MI355X_MICROARCH.md: PMC slots, LDS section)
+LDS_COUNTERS = ("SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_ADDR_CONFLICT",
+                "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F16")
+
+
+def _available_counters(names):
+    """The subset of `names` this rocprofv3 / device lists (`rocprofv3 -L`); [] when the listing itself fails."""
+    import subprocess
+    try:
+        r = subprocess.run(["rocprofv3", "-L"], capture_output=True, text=True, timeout=120, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+    except Exception:                                            # noqa: BLE001
+        return []
+    text = r.stdout + r.stderr
+    import re as _re
+    return [n for n in names if _re.search(r"\b" + n + r"\b", text)]
+
+
 def _kclass(name: str) -> str:
     for key, c in (("gemm_kernel", "gemm"), ("attn_kernel", "attention"), ("layernorm", "layernorm"), ("rmsnorm", "rmsnorm")):
         if key in name:
@@ -445,9 +463,11 @@ def measure_counters(args) -> None:
     prec, B, T = args.prec, args.batch, args.views
     child = ["--prec", prec, "--batch", str(B), "--views", str(T), "--steps", "2", "--warmup", "1", "--no-graph", "--in-flight", "1",
              "--no-strict", "--no-fp8", "--no-cpu-baseline", "--no-parity", "--no-pnp", "--no-h2d"]
-    acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")}
+    acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES") + LDS_COUNTERS}
     launches, dur_ns, steps_seen = collections.defaultdict(int), collections.defaultdict(float), 0
-    for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")):
+    lds_group = _available_counters(LDS_COUNTERS)          # one more pass: where the LDS time of the mainloops goes
+    groups = [("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")] + ([tuple(lds_group)] if lds_group else [])
+    for group in groups:
         path = _rocprof_pass(group, child)
         first = group[0]
         for r in csv.DictReader(open(path)):
@@ -472,6 +492,16 @@ def measure_counters(args) -> None:
                   "hbm_gb_per_s": round((fetch + write) / max(dur_ns[k] / steps_seen, 1) , 1),
                   "mfma_busy": round(acc["SQ_VALU_MFMA_BUSY_CYCLES"][k] / max(cyc * 1024.0, 1.0), 4),
                   "delivered_clock_ghz": round(cyc / max(dur_ns[k], 1), 3)}
+        if lds_group:
+            # SQ counters are summed over the chip: per step, and as fractions of the class's wave-cycles / LDS-array cycles
+            wc = acc["SQ_WAVE_CYCLES"][k]
+            per[k]["lds"] = {c: round(acc[c][k] / steps_seen) for c in lds_group}
+            per[k]["lds"]["wait_inst_lds_over_wave_cycles"] = round(acc["SQ_WAIT_INST_LDS"][k] / wc, 4) if wc else None
+            per[k]["lds"]["active_inst_lds_over_wave_cycles"] = round(acc["SQ_ACTIVE_INST_LDS"][k] / wc, 4) if wc else None
+            ia = acc["SQ_LDS_IDX_ACTIVE"][k]
+            per[k]["lds"]["bank_conflict_over_idx_active"] = round(acc["SQ_LDS_BANK_CONFLICT"][k] / ia, 4) if ia else None
+            # LDS-array busy fraction: IDX_ACTIVE cycles are summed over the CUs' LDS arrays; the class ran `cyc` shader cycles
+            per[k]["lds"]["lds_array_busy"] = round(ia / max(cyc * 256.0, 1.0), 4) if ia else None
     step_classes = [k for k in launches if not k.startswith("harness")]
     tb = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"][k] for k in step_classes)
     tc = sum(acc["SQ_BUSY_CYCLES"][k] for k in step_classes) / 32.0
@@ -482,7 +512,8 @@ def measure_counters(args) -> None:
            "gemm_algorithmic_bytes_per_call": round(alg_bytes / calls),
            "gemm_traffic_over_algorithmic": round((g.get("fetch_bytes_per_step", 0) + g.get("write_bytes_per_step", 0)) / alg_bytes, 3),
            "mfma_busy_whole_step": round(tb / max(tc * 1024.0, 1.0), 4), "per_kernel_class": per,
-           "how": "rocprofv3 --kernel-trace --pmc <one group per pass: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES> over "
+           "lds_counters": list(lds_group),
+           "how": "rocprofv3 --kernel-trace --pmc <one group per pass: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES | the LDS group> over "
                   "`bench.py " + " ".join(child) + "` (one batch at a time, un-graphed); bytes = counter KB x 1024, FETCH_SIZE x 2 (gfx950 "
                   "correction, MI355X_MICROARCH.md HBM section), WRITE_SIZE as is; MFMA busy = MFMA-busy SIMD-cycles / (SQ_BUSY_CYCLES / 32 x "
                   "1024 SIMDs); per step = totals / decode_kernel dispatches"}

@@ -22,12 +22,20 @@ PREC_F16_OUT_F16C8, PREC_BF16X3_OUT_F16C8 = 9, 10      # bd_attention[_q] only: 
 PREC_BF16X3_QKV16 = 11                                 # whole-path only: split-bf16, BETR's QKV Linear as one f16 pass
 PREC_F16C8_QKV16 = 12                                  # whole-path only: F16C8 Linears, BETR's QKV Linear as one f16 pass
 PREC_F16C8_QK16 = 13                                   # whole-path only: F16C8 Linears, BETR's QKV split: q, k one f16 pass, v F16C8
+PREC_F16X3, PREC_F16X3_ATTN_X3 = 14, 15                # split-f16 Linears (the promoted class); _ATTN_X3: split-bf16 attention everywhere
+PREC_F16_OUT_F16X3, PREC_BF16X3_OUT_F16X3 = 16, 17     # bd_attention[_q] only: split-f16 planes out
 F16C8_D = 11                                           # lo planes are scaled 2^D above their q plane
 PREC_NAMES = {"bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8,
               "bf16x3_attn_x3": PREC_BF16X3_ATTN_X3, "bf16x3_attn_f16": PREC_BF16X3_ATTN_F16, "f16c8": PREC_F16C8,
-              "bf16x3_qkv16": PREC_BF16X3_QKV16, "f16c8_qkv16": PREC_F16C8_QKV16, "f16c8_qk16": PREC_F16C8_QK16}
+              "bf16x3_qkv16": PREC_BF16X3_QKV16, "f16c8_qkv16": PREC_F16C8_QKV16, "f16c8_qk16": PREC_F16C8_QK16,
+              "f16x3": PREC_F16X3, "f16x3_attn_x3": PREC_F16X3_ATTN_X3}
+_F16X3_FAMILY = (PREC_F16X3, PREC_F16X3_ATTN_X3)
 _X3_FAMILY = (PREC_BF16X3, PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16, 11)
 ACT_NONE, ACT_GELU = 0, 1
+# per-Linear promotion of the F16C8 family to split-bf16 (include/boxdreamer_hip.h: BD_PROMOTE_*)
+PROMOTE_QKV, PROMOTE_PROJ, PROMOTE_FC1, PROMOTE_FC2, PROMOTE_ATTN = 1, 2, 4, 8, 16
+PROMOTE_ADAPTER_FC1, PROMOTE_ADAPTER_FC2, PROMOTE_BBOX_EMB, PROMOTE_BBOX_PROJ = 1, 2, 4, 8
+PROMOTE_PATCH_EMBED = 1
 # The precision a module runs when its config names none: the fastest mode that MEETS the path's parity bar (heatmap logits
 # within 1e-3 of the fp32 CPU forward, identical top-20 sets).  "bf16" -- the reference's own `precision`, 4e-2 off its fp32
 # forward -- is the explicit throughput opt-in (`hip_precision: bf16` in the decoder / encoder config, or $BOXDREAMER_HIP_PREC).
@@ -51,9 +59,7 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("act", C.c_int),
                 ("rpg_in", C.c_int), ("rpg_out", C.c_int), ("row_off", C.c_int), ("w_qexp", C.c_int),
-                ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("rms_parts", C.c_int),
-                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
-                ("ln_out", C.c_void_p), ("ln_out_plane", C.c_int64), ("ln_sync", C.c_void_p)]
+                ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("rms_parts", C.c_int)]
 
 
 class Linear(C.Structure):
@@ -63,7 +69,7 @@ class Linear(C.Structure):
 class BlockWeights(C.Structure):
     _fields_ = [("ln1_w", C.c_void_p), ("ln1_b", C.c_void_p), ("ln2_w", C.c_void_p), ("ln2_b", C.c_void_p),
                 ("qkv", Linear), ("proj", Linear), ("fc1", Linear), ("fc2", Linear),
-                ("q_norm_w", C.c_void_p), ("k_norm_w", C.c_void_p), ("qkv16", Linear)]
+                ("q_norm_w", C.c_void_p), ("k_norm_w", C.c_void_p), ("qkv16", Linear), ("promote", C.c_int)]
 
 
 class DinoWeights(C.Structure):
@@ -73,7 +79,7 @@ class DinoWeights(C.Structure):
                 ("patch_embed", Linear),
                 ("pos_patch", C.c_void_p), ("prefix_tokens", C.c_void_p),
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
-                ("blocks", C.POINTER(BlockWeights))]
+                ("blocks", C.POINTER(BlockWeights)), ("promote_misc", C.c_int), ("feats_prec", C.c_int)]
 
 
 class BetrWeights(C.Structure):
@@ -82,7 +88,7 @@ class BetrWeights(C.Structure):
                 ("ln_eps", C.c_float), ("adapter_ln_eps", C.c_float), ("rms_eps", C.c_float),
                 ("adapter_fc1", Linear), ("adapter_fc2", Linear), ("bbox_emb", Linear), ("bbox_proj", Linear),
                 ("pos_table", C.c_void_p), ("query_token", C.c_void_p),
-                ("blocks", C.POINTER(BlockWeights))]
+                ("blocks", C.POINTER(BlockWeights)), ("promote_misc", C.c_int)]
 
 
 class TraceRecord(C.Structure):
@@ -95,8 +101,7 @@ EXPORTS = [
     "bd_gather_query_tokens", "bd_unpatchify_sigmoid", "bd_decode_topk",
     "bd_encoder_workspace_bytes", "bd_encoder_forward", "bd_decoder_workspace_bytes", "bd_decoder_forward",
     "bd_trace_begin", "bd_trace_end", "bd_render_corner_heatmaps", "bd_attention_q", "bd_gather_query_rows_f32",
-    "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm", "bd_gemm_fuses_layernorm",
-    "bd_gemm_fuses_layernorm_supported",
+    "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm",
 ]
 
 _lib = None
@@ -123,8 +128,6 @@ def load() -> C.CDLL:
     lib.bd_target_arch.restype = C.c_char_p
     lib.bd_gemm.argtypes = [C.POINTER(GemmArgs), i, vp]
     lib.bd_gemm_fuses_qk_rmsnorm.argtypes = [C.POINTER(GemmArgs), i]
-    lib.bd_gemm_fuses_layernorm.argtypes = [C.POINTER(GemmArgs), i]
-    lib.bd_gemm_fuses_layernorm_supported.argtypes = [C.POINTER(GemmArgs), i]
     lib.bd_layernorm.argtypes = [vp, i64, vp, vp, f, vp, i64, vp, i64, i, i, i, i, i, i, vp]
     lib.bd_qk_rmsnorm.argtypes = [vp, i64, vp, vp, f, i, i, i, i, vp]
     lib.bd_attention.argtypes = [vp, i64, vp, i64, i, i, i, i, f, i, vp]
@@ -149,7 +152,7 @@ def load() -> C.CDLL:
     lib.bd_solve_pnp.argtypes = [vp, vp, vp, i, i, i, vp, vp]
     lib.bd_trace_begin.argtypes = [i]
     lib.bd_trace_end.argtypes = [C.POINTER(TraceRecord), i]
-    if lib.bd_abi_version() != 4:
+    if lib.bd_abi_version() != 5:
         raise HipLibraryError("libboxdreamer_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -189,6 +192,8 @@ def operand_prec(prec) -> int:
     pid = prec_id(prec)
     if pid in (PREC_F16C8_QKV16, PREC_F16C8_QK16):
         return PREC_F16C8
+    if pid in _F16X3_FAMILY:
+        return PREC_F16X3
     return PREC_BF16X3 if pid in _X3_FAMILY else pid
 
 
@@ -196,7 +201,7 @@ def op_dtype(prec) -> torch.dtype:
     pid = prec_id(prec)
     if pid == PREC_FP8:
         return torch.float8_e4m3fn          # OCP e4m3 (gfx950), not MI300's fnuz
-    return torch.float16 if pid in (PREC_F16, PREC_F16C8, PREC_F16C8_QKV16, PREC_F16C8_QK16) else torch.bfloat16     # F16C8: plane 1 holds raw e4m3 bytes
+    return torch.float16 if pid in (PREC_F16, PREC_F16C8, PREC_F16C8_QKV16, PREC_F16C8_QK16) + _F16X3_FAMILY else torch.bfloat16     # F16C8: plane 1 holds raw e4m3 bytes
 
 
 def k_multiple(prec) -> int:
@@ -205,7 +210,7 @@ def k_multiple(prec) -> int:
 
 
 def planes(prec) -> int:
-    return 2 if prec_id(prec) in _X3_FAMILY or prec_id(prec) in (PREC_F16C8, PREC_F16C8_QKV16, PREC_F16C8_QK16) else 1
+    return 2 if prec_id(prec) in _X3_FAMILY + _F16X3_FAMILY or prec_id(prec) in (PREC_F16C8, PREC_F16C8_QKV16, PREC_F16C8_QK16) else 1
 
 
 def dtype_id(t: torch.Tensor) -> int:

@@ -82,6 +82,11 @@ class BETR(nn.Module):
         self.box_dim = 8
         self.cat_dim = 3 + 8
         self.hip_precision = kwargs.get("hip_precision", os.environ.get("BOXDREAMER_HIP_PREC", _lib.DEFAULT_PREC))
+        # per-Linear promotion of the F16C8 family to split-bf16 (include/boxdreamer_hip.h: BD_PROMOTE_*): one mask per block and
+        # one for the Linears outside the blocks; all zero until boxdreamer_amd/calibrate.py (or the caller) sets them
+        self.hip_promote = [0] * num_decoder_layers
+        self.hip_promote_misc = 0
+        self.hip_calibration = None   # report of the last calibrate.calibrate() that looked at this decoder
 
         self.attn = nn.Sequential(*[SelfAttentionBlock(d_model, nhead) for _ in range(num_decoder_layers)])
         self.bbox_proj = nn.Linear(d_model, self.patch_size ** 2 * 8)
@@ -122,7 +127,19 @@ class BETR(nn.Module):
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             hit = (sig, pack.pack_betr(sd, _lib.operand_prec(prec), device, self.nhead, self.patch_size, self.img_size))
             self._packed[key] = hit
-        return hit[1]
+        pk = hit[1]
+        if _lib.operand_prec(prec) == _lib.PREC_F16C8:
+            want = (tuple(m | _lib.PROMOTE_FC2 if m & _lib.PROMOTE_FC1 else m for m in self.hip_promote),
+                    self.hip_promote_misc | (_lib.PROMOTE_ADAPTER_FC2 if self.hip_promote_misc & _lib.PROMOTE_ADAPTER_FC1 else 0), 0)
+            if pk.promote != want:
+                self._check_not_frozen("changing the per-Linear promotion")
+                pk.set_promote(self.hip_promote, self.hip_promote_misc)
+        return pk
+
+    def feats_class(self, prec=None) -> int:
+        """Operand class in which this decoder reads `pretrain_rgb_feat`'s 16-bit copy (the class of its adapter's first Linear)."""
+        cls = _lib.operand_prec(self.hip_precision if prec is None else prec)
+        return _lib.PREC_F16X3 if (cls == _lib.PREC_F16C8 and self.hip_promote_misc & _lib.PROMOTE_ADAPTER_FC1) else cls
 
     def _workspace(self, need: int, dev) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
@@ -173,7 +190,8 @@ class BETR(nn.Module):
                 raise ValueError("masks must mark exactly one query view per sample")
         query_idx = masks.to(torch.int32).argmax(dim=1).to(torch.int32).contiguous()
         np_ = _lib.planes(prec)
-        feats16 = features.operand_of(pretrain_rgb_feat, _lib.operand_prec(prec))
+        fcls = self.feats_class(prec)
+        feats16 = features.operand_of(pretrain_rgb_feat, fcls)
         if feats16 is not None and (feats16.numel() != np_ * B * T * P * D or feats16.device != dev):
             feats16 = None
         if feats16 is None:   # features without an operand copy (computed elsewhere, copied, sliced): explicit re-cast
@@ -181,7 +199,7 @@ class BETR(nn.Module):
             if self.recast_count == 1:
                 warnings.warn("BETR: pretrain_rgb_feat carries no operand-dtype copy from the HIP encoder; re-casting it "
                               "(slow path, see boxdreamer_amd/features.py)", stacklevel=2)
-            feats16 = hip_ops.to_operand(pretrain_rgb_feat.reshape(B * T * P, D).float(), _lib.operand_prec(prec))
+            feats16 = hip_ops.to_operand(pretrain_rgb_feat.reshape(B * T * P, D).float(), fcls)
         pose_feat = pose_feat.contiguous()
         ws = self._workspace(lib.bd_decoder_workspace_bytes(w, B, T, pid), dev)
         logits = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)

@@ -20,6 +20,7 @@ from . import _lib, features
 
 
 def _new_operand(pid: int, n_views: int, P: int, C: int, dtype, dev) -> torch.Tensor:
+    pid = _lib.operand_prec(pid)        # a whole-path id (f16c8_qk16, ...) carries the byte layout of its operand class
     rows = n_views * P
     return torch.zeros((2, rows, C) if _lib.planes(pid) == 2 else (rows, C), dtype=dtype, device=dev)
 
@@ -29,6 +30,7 @@ def _plane_views(t16: torch.Tensor, pid: int, n_views: int, P: int, C: int):
     Split-bf16: two elementwise 16-bit planes.  F16C8 (include/boxdreamer_hip.h): plane 0 is f16, plane 1 is one e4m3 BYTE per
     element -- rows of C bytes packed into the first rows*C bytes of the plane's storage (the rest is unused) -- so it must be
     moved as uint8 rows, never as 16-bit rows."""
+    pid = _lib.operand_prec(pid)
     rows = n_views * P
     if _lib.planes(pid) == 1:
         return [t16.reshape(n_views, P, C)]

@@ -1,0 +1,174 @@
+"""Load-time self-check and per-Linear promotion of the default precision mode.
+
+The default mode (`f16c8_qk16`: F16C8 Linears, ~15 significant bits per product) meets the path's 1e-3 bar on the heatmap logits with a
+4.5x margin on plain weights, but trained checkpoints carry massive-activation channels, LayerNorm gain outliers and MLP hidden units in
+the hundreds (reference modules: /root/reference/src/models/sources/DINOv2/layers/block.py:89-114, src/models/modules/backbone/utils/
+blocks.py:35-56, 808-886); there a handful of Linears -- not necessarily the ones whose operands are large: the ones UPSTREAM of an
+amplifying channel -- decide the error.  They are found by MEASUREMENT on the device, on one calibration sample:
+
+  reference   every Linear split-f16 (fp32-faithful products) + split-bf16 attention: bit-identical to `f16x3_attn_x3`, the most
+              precise GPU mode (include/boxdreamer_hip.h: BD_PREC_F16X3)
+  e[u]        max |logits - reference| with ONLY unit u left in the default class  (u = a block's QKV / proj / MLP / attention form,
+              or one of the Linears outside the blocks)
+  choice      units sorted by e[u] per unit of saved work; the longest prefix that may stay in the default class with
+              max |logits - reference| <= budget (5e-4: half the bar; the reference itself is within ~1e-4 of the fp32 forward)
+
+Everything that is not in that prefix is PROMOTED (bd_block_weights.promote, include/boxdreamer_hip.h).  ~100 batch-1 forwards, about
+a second at load time; nothing here runs in the per-batch path.  Host logic only: the forwards are the HIP path itself.
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+
+from . import _lib
+
+BUDGET = 5e-4
+_BLOCK_UNITS = (("qkv", _lib.PROMOTE_QKV), ("proj", _lib.PROMOTE_PROJ), ("mlp", _lib.PROMOTE_FC1 | _lib.PROMOTE_FC2),
+                ("attn", _lib.PROMOTE_ATTN))
+
+
+def applicable(encoder, decoder) -> bool:
+    """Promotion exists for the F16C8 family only (the other modes are either the reference itself or opt-in throughput modes)."""
+    return (_lib.operand_prec(decoder.hip_precision) == _lib.PREC_F16C8 and _lib.operand_prec(encoder.prec) == _lib.PREC_F16C8)
+
+
+def units_of(encoder, decoder):
+    """[(name, where, block index | None, bits, relative cost of promoting it)]; where: 'enc' / 'dec' / 'enc_misc' / 'dec_misc'."""
+    u = [("dino.patch_embed", "enc_misc", None, _lib.PROMOTE_PATCH_EMBED, 0.8)]
+    for i in range(len(encoder.model.promote)):
+        u += [(f"dino.{i}.qkv", "enc", i, _lib.PROMOTE_QKV, 3.0), (f"dino.{i}.proj", "enc", i, _lib.PROMOTE_PROJ, 1.0),
+              (f"dino.{i}.mlp", "enc", i, _lib.PROMOTE_FC1 | _lib.PROMOTE_FC2, 8.0)]
+    u += [("betr.adapter", "dec_misc", None, _lib.PROMOTE_ADAPTER_FC1 | _lib.PROMOTE_ADAPTER_FC2, 2.0),
+          ("betr.bbox_emb", "dec_misc", None, _lib.PROMOTE_BBOX_EMB, 2.0), ("betr.bbox_proj", "dec_misc", None, _lib.PROMOTE_BBOX_PROJ, 0.4)]
+    qk16 = _lib.prec_id(decoder.hip_precision) == _lib.PREC_F16C8_QK16
+    for i in range(len(decoder.hip_promote)):
+        u += [(f"betr.{i}.qkv", "dec", i, _lib.PROMOTE_QKV, 5.0 if qk16 else 3.0), (f"betr.{i}.proj", "dec", i, _lib.PROMOTE_PROJ, 1.0),
+              (f"betr.{i}.mlp", "dec", i, _lib.PROMOTE_FC1 | _lib.PROMOTE_FC2, 8.0), (f"betr.{i}.attn", "dec", i, _lib.PROMOTE_ATTN, 8.0)]
+    return u
+
+
+def get_state(encoder, decoder) -> dict:
+    return {"enc": list(encoder.model.promote), "enc_misc": int(encoder.model.promote_misc), "dec": list(decoder.hip_promote),
+            "dec_misc": int(decoder.hip_promote_misc)}
+
+
+def set_state(encoder, decoder, state: dict) -> None:
+    """Apply a promotion state (from `get_state` / a calibration report) to an encoder / decoder pair of the same architecture."""
+    encoder.model.promote = list(state["enc"])
+    encoder.model.promote_misc = int(state["enc_misc"])
+    decoder.hip_promote = list(state["dec"])
+    decoder.hip_promote_misc = int(state["dec_misc"])
+    # the encoder hands its features over in the class the decoder's first Linear reads
+    encoder.model.feats_prec = _lib.PREC_F16X3 if decoder.hip_promote_misc & _lib.PROMOTE_ADAPTER_FC1 else 0
+
+
+def _state_of(units, promoted, n_enc, n_dec) -> dict:
+    st = {"enc": [0] * n_enc, "enc_misc": 0, "dec": [0] * n_dec, "dec_misc": 0}
+    for (name, where, idx, bits, _), on in zip(units, promoted):
+        if not on:
+            continue
+        if idx is None:
+            st[where] |= bits
+        else:
+            st[where][idx] |= bits
+    return st
+
+
+@torch.no_grad()
+def _logits(encoder, decoder, images, bbox_feat, masks) -> torch.Tensor:
+    heat = decoder(bbox_feat, images, masks, encoder.predict(images), None)
+    del heat
+    return decoder.last_logits.clone()
+
+
+@torch.no_grad()
+def self_check(encoder, decoder, images, bbox_feat, masks) -> float:
+    """max |logits(current promotion state) - logits(every unit promoted)| on the given samples: what the active mode costs against
+    the most precise GPU mode.  Leaves the promotion state as it found it."""
+    keep = get_state(encoder, decoder)
+    units = units_of(encoder, decoder)
+    cur = _logits(encoder, decoder, images, bbox_feat, masks)
+    try:
+        set_state(encoder, decoder, _state_of(units, [True] * len(units), len(keep["enc"]), len(keep["dec"])))
+        ref = _logits(encoder, decoder, images, bbox_feat, masks)
+    finally:
+        set_state(encoder, decoder, keep)
+    return float((cur - ref).abs().max())
+
+
+@torch.no_grad()
+def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUDGET, promote: bool = True, max_samples: int = 1,
+              verbose: bool = False) -> dict:
+    """Measure the default mode against the all-promoted reference on `max_samples` samples of the given batch and, if it exceeds
+    `budget`, promote the cheapest sufficient set of units.  Returns (and stores in `decoder.hip_calibration`) the report; warns when
+    promotion was needed or -- with promote=False -- when the self-check fails.
+
+    images (B, T, 3, H, W), bbox_feat (B, T, 8, H, W), masks (B, T) bool: as `BETR.forward` / `DinoV2Wrapper.predict` take them."""
+    rep = {"mode": str(decoder.hip_precision), "budget": budget, "applicable": applicable(encoder, decoder)}
+    if not rep["applicable"]:
+        rep["note"] = "per-Linear promotion exists for the f16c8 family only; nothing measured"
+        decoder.hip_calibration = rep
+        return rep
+    n = max(1, min(int(max_samples), images.shape[0]))
+    images, bbox_feat, masks = images[:n].contiguous(), bbox_feat[:n].contiguous(), masks[:n].contiguous()
+    validate, decoder.validate_inputs = decoder.validate_inputs, False
+    units = units_of(encoder, decoder)
+    n_enc, n_dec, nu = len(encoder.model.promote), len(decoder.hip_promote), len(units)
+    forwards = 0
+
+    def run(promoted):
+        nonlocal forwards
+        forwards += 1
+        set_state(encoder, decoder, _state_of(units, promoted, n_enc, n_dec))
+        return _logits(encoder, decoder, images, bbox_feat, masks)
+
+    try:
+        ref = run([True] * nu)
+        d0 = float((run([False] * nu) - ref).abs().max())
+        rep.update(delta_unpromoted=d0, samples=n, views=int(images.shape[1]),
+                   reference="every Linear split-f16 + split-bf16 attention (bit-identical to f16x3_attn_x3)")
+        chosen = [False] * nu
+        if d0 > budget and promote:
+            # e[u]: only unit u in the default class
+            e = []
+            for k in range(nu):
+                on = [True] * nu
+                on[k] = False
+                e.append(float((run(on) - ref).abs().max()))
+            order = sorted(range(nu), key=lambda k: e[k] / units[k][4])          # cheapest-to-keep first
+            lo, hi = 0, nu                     # invariant: keeping order[:lo] is fine, keeping order[:hi] is not (hi = nu: d0 > budget)
+            deltas = {0: 0.0, nu: d0}
+            while hi - lo > 1:
+                mid = (lo + hi) // 2
+                on = [True] * nu
+                for k in order[:mid]:
+                    on[k] = False
+                deltas[mid] = float((run(on) - ref).abs().max())
+                if deltas[mid] <= budget:
+                    lo = mid
+                else:
+                    hi = mid
+            chosen = [True] * nu
+            for k in order[:lo]:
+                chosen[k] = False
+            rep.update(delta_final=deltas[lo], unit_errors={units[k][0]: round(e[k], 7) for k in order[::-1][:12]})
+        else:
+            rep.update(delta_final=d0)
+        set_state(encoder, decoder, _state_of(units, chosen, n_enc, n_dec))
+        rep.update(promoted=[units[k][0] for k in range(nu) if chosen[k]], units=nu, forwards=forwards,
+                   promoted_cost_frac=round(sum(units[k][4] for k in range(nu) if chosen[k]) / sum(u[4] for u in units), 4),
+                   state=get_state(encoder, decoder), ok=bool(rep["delta_final"] <= budget))
+    finally:
+        decoder.validate_inputs = validate
+    if d0 > budget:
+        msg = (f"BoxDreamer HIP path: the default precision mode '{decoder.hip_precision}' is {d0:.2e} off the split-f16 reference on the "
+               f"heatmap logits of the calibration sample (budget {budget:.1e}); ")
+        msg += (f"{len(rep['promoted'])} of {nu} units promoted to split-f16 -> {rep['delta_final']:.2e}" if promote else
+                "promotion is disabled (hip_calibrate=False): expect to miss the 1e-3 parity bar; use hip_precision='f16x3'")
+        warnings.warn(msg, stacklevel=2)
+    if verbose:
+        print("[calibrate] " + ", ".join(f"{k}={v}" for k, v in rep.items() if k not in ("state", "unit_errors")), flush=True)
+    decoder.hip_calibration = rep
+    return rep

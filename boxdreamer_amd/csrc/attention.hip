@@ -502,23 +502,25 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) v
                     for (int j = 0; j < 4; ++j) v4[j] = oacc[dm][rq * 4 + j] * inv;
                     f16c8_store4((f16c8*)p.out, p.out_plane, e0 + dm * 32 + 8 * rq + 4 * lh, v4);
                 }
-        } else if (OUTMODE == 1) {
-            __bf16* orow = (__bf16*)p.out + ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
+        } else if (OUTMODE == 1 || OUTMODE == 4) {
+            // (hi, lo) planes of ANOTHER 16-bit type than the kernel's operands: 1 = split-bf16, 4 = split-f16 (BD_PREC_F16X3)
+            typedef typename std::conditional<OUTMODE == 1, __bf16, _Float16>::type OT;
+            OT* orow = (OT*)p.out + ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
 #pragma unroll
             for (int dm = 0; dm < DM; ++dm)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     const int d0 = dm * 32 + 8 * rq + 4 * lh;
-                    typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bvec4;
-                    bvec4 hi, lo;
+                    typedef __attribute__((__vector_size__(4 * sizeof(OT)))) OT ovec4;
+                    ovec4 hi, lo;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float v = oacc[dm][rq * 4 + j] * inv;
-                        hi[j] = (__bf16)v;
-                        lo[j] = (__bf16)(v - (float)hi[j]);
+                        hi[j] = from_f32<OT>(v);
+                        lo[j] = from_f32<OT>(v - to_f32<OT>(hi[j]));
                     }
-                    *(bvec4*)(orow + d0) = hi;
-                    *(bvec4*)(orow + p.out_plane + d0) = lo;
+                    *(ovec4*)(orow + d0) = hi;
+                    *(ovec4*)(orow + p.out_plane + d0) = lo;
                 }
         } else {
             T* orow = (T*)p.out + ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
@@ -874,12 +876,13 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
                     store_cvt<fp8e4, 4>((fp8e4*)p.out + e, v4);
                 } else if constexpr (OUTMODE == 3) {
                     f16c8_store4((f16c8*)p.out, p.out_plane, e, v4);
-                } else if constexpr (OUTMODE == 1) {
+                } else if constexpr (OUTMODE == 1 || OUTMODE == 4) {
+                    typedef typename std::conditional<OUTMODE == 1, __bf16, _Float16>::type OT;
                     float hi4[4], lo4[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { hi4[j] = (float)(__bf16)v4[j]; lo4[j] = v4[j] - hi4[j]; }
-                    store_cvt<__bf16, 4>((__bf16*)p.out + e, hi4);
-                    store_cvt<__bf16, 4>((__bf16*)p.out + p.out_plane + e, lo4);
+                    for (int j = 0; j < 4; ++j) { hi4[j] = to_f32<OT>(from_f32<OT>(v4[j])); lo4[j] = v4[j] - hi4[j]; }
+                    store_cvt<OT, 4>((OT*)p.out + e, hi4);
+                    store_cvt<OT, 4>((OT*)p.out + p.out_plane + e, lo4);
                 } else {
                     store_cvt<T, 4>((T*)p.out + e, v4);
                 }
@@ -943,6 +946,8 @@ extern "C" int bd_attention_q(const void* qkv, int64_t qkv_plane, void* out, int
         case BD_PREC_BF16_OUT_FP8: return dispatch<__bf16, 1, 2>(a, head_dim, s);
         case BD_PREC_F16_OUT_F16C8: return dispatch<_Float16, 1, 3>(a, head_dim, s);
         case BD_PREC_BF16X3_OUT_F16C8: return dispatch<__bf16, 2, 3>(a, head_dim, s);
+        case BD_PREC_F16_OUT_F16X3: return dispatch<_Float16, 1, 4>(a, head_dim, s);
+        case BD_PREC_BF16X3_OUT_F16X3: return dispatch<__bf16, 2, 4>(a, head_dim, s);
         default: return BD_ERR_DTYPE;
     }
 }

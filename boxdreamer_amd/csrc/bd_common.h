@@ -122,9 +122,7 @@ template <> __device__ __forceinline__ void store_cvt<fp8e4, 4>(fp8e4* dst, cons
 // v_pk_max / v_pk_min pair per f16 pair in the GEMM's K loop cost 3.2 % of the strict step).  Every kernel that produces or consumes
 // the class calls bd_saturating_conversions() first; the mode is per-wave state and dies with the wave.
 __device__ __forceinline__ void bd_saturating_conversions() {
-#ifndef BD_EXP_NO_SAT          // (A/B builds only, tools/ab_build.sh)
     __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);      // hwreg(HW_REG_MODE, 23, 1) = MODE.FP16_OVFL
-#endif
 }
 struct f16c8 { unsigned short v; };              // storage element of either plane (never used arithmetically)
 #define BD_F16C8_D 11

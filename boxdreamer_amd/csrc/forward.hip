@@ -19,7 +19,8 @@ struct Carver {
 
 inline int planes_of(int prec) {      // 2-byte units per element of a 16-bit operand buffer (F16C8: f16 plane + e4m3 plane)
     return (prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_BF16X3_ATTN_F16 ||
-            prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16C8 || prec == BD_PREC_F16C8_QKV16 || prec == BD_PREC_F16C8_QK16) ? 2 : 1;
+            prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16C8 || prec == BD_PREC_F16C8_QKV16 || prec == BD_PREC_F16C8_QK16 ||
+            prec == BD_PREC_F16X3 || prec == BD_PREC_F16X3_ATTN_X3) ? 2 : 1;
 }
 
 struct BlockBufs {
@@ -28,8 +29,6 @@ struct BlockBufs {
     void* qkv;       // 16-bit               [M, 3D]
     void* ao;        // 16-bit attention out [M, D]
     void* h;         // 16-bit MLP hidden    [M, 4D]
-    int* ln_sync;    // int32 [ceil(M / 256)] panel counters of the fused LayerNorm (zeroed once per forward; the kernels leave them zero)
-    size_t ln_sync_bytes;
 };
 
 inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const bd_linear& lin, int64_t ldw, int N,
@@ -58,73 +57,88 @@ inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const
 //                            1e-3 budget -- kept for measurement, misses the bar)
 inline int gemm_prec(int prec) {
     if (prec == BD_PREC_F16C8_QKV16 || prec == BD_PREC_F16C8_QK16) return BD_PREC_F16C8;
+    if (prec == BD_PREC_F16X3_ATTN_X3) return BD_PREC_F16X3;
     return (prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_BF16X3_ATTN_F16 || prec == BD_PREC_BF16X3_QKV16) ? BD_PREC_BF16X3 : prec;
 }
 inline bool qkv_single_f16(int prec) { return prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16C8_QKV16; }
 inline bool qk_single_f16(int prec) { return prec == BD_PREC_F16C8_QK16; }
+inline bool x3_f16_attention(int prec, bool qk_normed) {
+    return prec == BD_PREC_BF16X3_ATTN_F16 || ((prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16X3) && qk_normed);
+}
+inline bool split16(int cls) { return cls == BD_PREC_BF16X3 || cls == BD_PREC_F16X3; }
+// operand class of a Linear of the F16C8 family: split-f16 when its BD_PROMOTE_* bit is set (include/boxdreamer_hip.h)
+inline int lin_class(int base, int promote, int bit) { return (base == BD_PREC_F16C8 && (promote & bit)) ? BD_PREC_F16X3 : base; }
+// fc1 -> fc2 and adapter fc1 -> fc2 hand-offs: a split-f16 GEMM cannot emit the F16C8 operand, so promoting the first promotes the second
+inline int norm_promote(int pm) { return (pm & BD_PROMOTE_FC1) ? (pm | BD_PROMOTE_FC2) : pm; }
+// output kind (bd_gemm_args.out_f32) with which a GEMM of class `from` writes the A operand of a Linear of class `to`
+inline int handoff_kind(int from, int to) { return from == to ? 0 : 5 /* F16C8 GEMM -> split-f16 planes */; }
 
-// BD_PREC_F16C8_QK16: the QKV Linear of a block whose q, k are RMS-normalised, split by output column (include/boxdreamer_hip.h).
+// How one transformer block runs: the operand class of each Linear (F16C8 family: per-Linear promotion to split-bf16), the attention
+// form, and the 16-bit kinds in which producers hand their results on.
+struct BlockPlan {
+    int base;                        // operand class of the un-promoted Linears
+    int c_qkv, c_proj, c_fc1, c_fc2; // operand class per Linear
+    bool hyb;                        // attention as ONE f16 pass on a single f16 q, k, v plane (q, k RMS-normalised)
+    bool qk16, qkv16;                // BETR's QKV Linear split by column (q, k one f16 pass) / as one f16 pass
+    int qkv_out;                     // output kind of the QKV GEMM
+    int aprec_in;                    // class of the attention input (for the stand-alone q/k RMSNorm)
+    int aprec;                       // bd_attention precision code (input form x class of proj's A operand)
+};
+inline BlockPlan plan_block(const bd_block_weights& w, int wprec) {
+    BlockPlan p{};
+    p.base = gemm_prec(wprec);
+    const bool c8 = p.base == BD_PREC_F16C8, f8 = p.base == BD_PREC_FP8, normed = w.q_norm_w != nullptr;
+    const int pm = c8 ? norm_promote(w.promote) : 0;
+    p.c_qkv = lin_class(p.base, pm, BD_PROMOTE_QKV);
+    p.c_proj = lin_class(p.base, pm, BD_PROMOTE_PROJ);
+    p.c_fc1 = lin_class(p.base, pm, BD_PROMOTE_FC1);
+    p.c_fc2 = lin_class(p.base, pm, BD_PROMOTE_FC2);
+    p.hyb = (split16(p.base) && x3_f16_attention(wprec, normed)) || (c8 && normed && !(pm & BD_PROMOTE_ATTN));
+    const bool plain_qkv = p.c_qkv == p.base;          // the special QKV forms exist for the un-promoted Linear only
+    p.qk16 = qk_single_f16(wprec) && p.hyb && w.qkv16.w && plain_qkv;
+    p.qkv16 = qkv_single_f16(wprec) && p.hyb && w.qkv16.w && plain_qkv;
+    if (p.hyb) { p.qkv_out = 2; p.aprec_in = BD_PREC_F16; }                                  // one f16 plane
+    else if (f8) { p.qkv_out = 3; p.aprec_in = BD_PREC_BF16; }                                // one bf16 plane
+    else if (p.c_qkv == BD_PREC_F16C8 || p.c_qkv == BD_PREC_F16X3) { p.qkv_out = 4; p.aprec_in = BD_PREC_BF16X3; }   // split-bf16 planes for
+                                                                                              // the split-bf16 attention (range: probabilities)
+    else { p.qkv_out = 0; p.aprec_in = p.c_qkv; }                                             // the GEMM's own operand class
+    if (p.hyb) p.aprec = p.c_proj == BD_PREC_F16C8 ? BD_PREC_F16_OUT_F16C8 : (p.c_proj == BD_PREC_F16X3 ? BD_PREC_F16_OUT_F16X3 : BD_PREC_F16_OUT_BF16X3);
+    else if (f8) p.aprec = BD_PREC_BF16_OUT_FP8;
+    else if (p.aprec_in == BD_PREC_BF16X3)
+        p.aprec = p.c_proj == BD_PREC_F16C8 ? BD_PREC_BF16X3_OUT_F16C8 : (p.c_proj == BD_PREC_F16X3 ? BD_PREC_BF16X3_OUT_F16X3 : BD_PREC_BF16X3);
+    else p.aprec = p.base;
+    return p;
+}
+
+// LayerNorm 1 + QKV Linear (+ q/k RMSNorm) of a block on M rows: leaves q, k, v in b.qkv in the form the plan's attention reads.
+// BD_PREC_F16C8_QK16: the QKV Linear of a block whose q, k are RMS-normalised, split by output column (include/boxdreamer_hip.h):
 // LayerNorm 1 emits the F16C8 operand; launch 1 multiplies its f16 plane with the f16 copy of the q, k weight rows (one MFMA pass,
 // q/k RMSNorm fused where the launch allows it), launch 2 is the full F16C8 product for the v rows.  q, k, v land in one f16
-// [M, 3D] buffer exactly as the single-launch forms lay them out.  Returns through *rms_fused whether q, k still need bd_qk_rmsnorm.
-int qkv_split_qk16(const bd_block_weights& w, const float* x, void* xn, void* qkv, int M, int D, int hd, float ln_eps, float rms_eps,
-                   bool ln1_ready, bool* rms_fused, void* stream) {
-    const int64_t pD = (int64_t)M * D;
-    if (!ln1_ready) BD_TRY(bd_layernorm(x, D, w.ln1_w, w.ln1_b, ln_eps, xn, pD, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16C8, stream));
-    {
-        bd_gemm_args g = gemm_args(xn, D, 0, w.qkv16, D, 2 * D, qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);      // rows [0, 2D) of the f16 copy
-        g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps; g.rms_parts = 2;
-        *rms_fused = hd == 96 && bd_gemm_fuses_qk_rmsnorm(&g, BD_PREC_F16);
-        if (!*rms_fused) { g.rms_wq = g.rms_wk = nullptr; g.rms_parts = 0; }
-        BD_TRY(bd_gemm(&g, BD_PREC_F16, stream));
-    }
-    {
-        bd_linear v = w.qkv;                                      // rows [2D, 3D) of the F16C8 weight: both planes advance by 2D rows
-        v.w = (const unsigned short*)w.qkv.w + (int64_t)2 * D * D;
-        v.b = w.qkv.b + 2 * D;
-        bd_gemm_args g = gemm_args(xn, D, pD, v, D, D, (unsigned short*)qkv + 2 * D, 3 * D, 0, 2 /* f16 plane */, M, D, BD_ACT_NONE);
-        g.w_plane = (int64_t)3 * D * D;                           // plane 1 still lies one FULL weight plane behind plane 0
-        BD_TRY(bd_gemm(&g, BD_PREC_F16C8, stream));
-    }
-    return BD_OK;
-}
-// LayerNorm of a residual GEMM's result rows inside that launch (include/boxdreamer_hip.h: bd_gemm_args.ln_*): attach it when the
-// launch can run it (persistent kernel), else leave the arguments alone -- the caller then runs bd_layernorm as before (same bits).
-inline bool try_fuse_layernorm(bd_gemm_args& g, const float* gamma, const float* beta, float eps, void* out, int64_t plane, int* sync,
-                               int prec) {
-    g.ln_gamma = gamma; g.ln_beta = beta; g.ln_eps = eps; g.ln_out = out; g.ln_out_plane = plane; g.ln_sync = sync;
-    if (bd_gemm_fuses_layernorm(&g, prec)) return true;
-    g.ln_gamma = g.ln_beta = nullptr; g.ln_out = nullptr; g.ln_sync = nullptr; g.ln_out_plane = 0;
-    return false;
-}
-
-inline bool x3_f16_attention(int prec, bool qk_normed) {
-    return prec == BD_PREC_BF16X3_ATTN_F16 || ((prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_QKV16) && qk_normed);
-}
-
-// One pre-LN transformer block: x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x))).
-// BETR: blocks.py:876-886 (+ q/k RMSNorm :257); DINOv2: layers/block.py:89-114 (LayerScale folded).
-// `ln1_ready`: in: LayerNorm 1 of THIS block already sits in b.xn (the previous block's fc2 launch produced it); out: whether this
-// block's fc2 launch produced LayerNorm 1 of `next` (nullptr: nothing follows in this form).
-int run_block(const bd_block_weights& w, const bd_block_weights* next, bool& ln1_ready, const BlockBufs& b, int M, int batch, int seq,
-              int D, int heads, float ln_eps, float rms_eps, int wprec, void* stream) {
+// [M, 3D] buffer exactly as the single-launch forms lay them out.
+int qkv_stage(const bd_block_weights& w, const BlockPlan& p, const BlockBufs& b, int M, int D, int heads, float ln_eps, float rms_eps,
+              void* stream) {
     const int hd = D / heads;
-    const int prec = gemm_prec(wprec);
-    const bool c8 = prec == BD_PREC_F16C8;    // f16 + e4m3-correction Linears; attention as in BD_PREC_BF16X3
-    const bool hyb = (prec == BD_PREC_BF16X3 && x3_f16_attention(wprec, w.q_norm_w != nullptr)) || (c8 && w.q_norm_w != nullptr);
-    const bool f8 = prec == BD_PREC_FP8;      // e4m3 Linears, bf16 attention
-    // attention input: f16 single plane where q, k are RMS-normalised (hyb), split-bf16 planes otherwise in the strict classes
-    const int aprec_in = hyb ? BD_PREC_F16 : (f8 ? BD_PREC_BF16 : (c8 ? BD_PREC_BF16X3 : prec));
-    const int aprec = c8 ? (hyb ? BD_PREC_F16_OUT_F16C8 : BD_PREC_BF16X3_OUT_F16C8)
-                         : (hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec));
-    const int qkv_out = hyb ? 2 : (f8 ? 3 : (c8 ? 4 : 0));          // f16 plane / bf16 plane / split-bf16 planes / operand class
+    const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D;
     bool rms_fused = false;
-    const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D, p4D = (int64_t)M * 4 * D;
-    if (qk_single_f16(wprec) && hyb && w.qkv16.w) {
-        BD_TRY(qkv_split_qk16(w, b.x, b.xn, b.qkv, M, D, hd, ln_eps, rms_eps, ln1_ready, &rms_fused, stream));
-    } else if (qkv_single_f16(wprec) && hyb && w.qkv16.w) {
+    if (p.qk16) {
+        BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16C8, stream));
+        {
+            bd_gemm_args g = gemm_args(b.xn, D, 0, w.qkv16, D, 2 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);      // rows [0, 2D) of the f16 copy
+            g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps; g.rms_parts = 2;
+            rms_fused = hd == 96 && bd_gemm_fuses_qk_rmsnorm(&g, BD_PREC_F16);
+            if (!rms_fused) { g.rms_wq = g.rms_wk = nullptr; g.rms_parts = 0; }
+            BD_TRY(bd_gemm(&g, BD_PREC_F16, stream));
+        }
+        {
+            bd_linear v = w.qkv;                                      // rows [2D, 3D) of the F16C8 weight: both planes advance by 2D rows
+            v.w = (const unsigned short*)w.qkv.w + (int64_t)2 * D * D;
+            v.b = w.qkv.b + 2 * D;
+            bd_gemm_args g = gemm_args(b.xn, D, pD, v, D, D, (unsigned short*)b.qkv + 2 * D, 3 * D, 0, 2 /* f16 plane */, M, D, BD_ACT_NONE);
+            g.w_plane = (int64_t)3 * D * D;                           // plane 1 still lies one FULL weight plane behind plane 0
+            BD_TRY(bd_gemm(&g, BD_PREC_F16C8, stream));
+        }
+    } else if (p.qkv16) {
         // the one Linear that may leave the split scheme: f16 LayerNorm output x f16 weights, one pass, f16 q, k, v out
-        // (its LayerNorm output is an f16 plane, not the operand class: never produced by the previous block's fc2 launch)
         BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, 0, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16, stream));
         bd_gemm_args g = gemm_args(b.xn, D, 0, w.qkv16, D, 3 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);
         g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
@@ -132,101 +146,64 @@ int run_block(const bd_block_weights& w, const bd_block_weights* next, bool& ln1
         if (!rms_fused) g.rms_wq = g.rms_wk = nullptr;
         BD_TRY(bd_gemm(&g, BD_PREC_F16, stream));
     } else {
-        if (!ln1_ready) BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
-        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, qkv_out, M, D, BD_ACT_NONE);
+        BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, p.c_qkv, stream));
+        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, p.qkv_out, M, D, BD_ACT_NONE);
         if (w.q_norm_w && hd == 96) {            // q/k RMSNorm in the QKV epilogue where the launch allows it
             g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
-            rms_fused = bd_gemm_fuses_qk_rmsnorm(&g, prec);
+            rms_fused = bd_gemm_fuses_qk_rmsnorm(&g, p.c_qkv);
             if (!rms_fused) g.rms_wq = g.rms_wk = nullptr;
         }
-        BD_TRY(bd_gemm(&g, prec, stream));
+        BD_TRY(bd_gemm(&g, p.c_qkv, stream));
     }
-    ln1_ready = false;
-    if (w.q_norm_w && !rms_fused) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, aprec_in, stream));
-    BD_TRY(bd_attention(b.qkv, p3D, b.ao, pD, batch, seq, heads, hd, 1.0f / sqrtf((float)hd), aprec, stream));
-    bool ln2_fused = false;
+    if (w.q_norm_w && !rms_fused) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, p.aprec_in, stream));
+    return BD_OK;
+}
+
+// x += proj(ao); x += fc2(gelu(fc1(LN2 x)))  on Mr rows (the whole stream, or the query view's compact rows of the last block)
+int proj_mlp_stage(const bd_block_weights& w, const BlockPlan& p, const BlockBufs& b, float* x, int Mr, int D, float ln_eps, void* stream) {
+    const int64_t rD = (int64_t)Mr * D, r4D = (int64_t)Mr * 4 * D;
     {
-        // proj + residual; LayerNorm 2 of the new stream rides in the same launch where it runs the persistent kernel
-        bd_gemm_args g = gemm_args(b.ao, D, pD, w.proj, D, D, b.x, D, 0, 1, M, D, BD_ACT_NONE);
-        g.resid = b.x; g.ldr = D;
-        ln2_fused = try_fuse_layernorm(g, w.ln2_w, w.ln2_b, ln_eps, b.xn, pD, b.ln_sync, prec);
-        BD_TRY(bd_gemm(&g, prec, stream));
+        bd_gemm_args g = gemm_args(b.ao, D, rD, w.proj, D, D, x, D, 0, 1, Mr, D, BD_ACT_NONE);
+        g.resid = x; g.ldr = D;
+        BD_TRY(bd_gemm(&g, p.c_proj, stream));
     }
-    if (!ln2_fused) BD_TRY(bd_layernorm(b.x, D, w.ln2_w, w.ln2_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
+    BD_TRY(bd_layernorm(x, D, w.ln2_w, w.ln2_b, ln_eps, b.xn, rD, nullptr, 0, Mr, D, 0, 0, 0, p.c_fc1, stream));
     {
-        bd_gemm_args g = gemm_args(b.xn, D, pD, w.fc1, D, 4 * D, b.h, 4 * D, p4D, 0, M, D, BD_ACT_GELU);
-        BD_TRY(bd_gemm(&g, prec, stream));
+        bd_gemm_args g = gemm_args(b.xn, D, rD, w.fc1, D, 4 * D, b.h, 4 * D, r4D, handoff_kind(p.c_fc1, p.c_fc2), Mr, D, BD_ACT_GELU);
+        BD_TRY(bd_gemm(&g, p.c_fc1, stream));
     }
     {
-        // fc2 + residual; the NEXT block's LayerNorm 1 rides along (its output is the operand class unless that block's QKV runs
-        // as one f16 pass on an f16 LayerNorm output)
-        bd_gemm_args g = gemm_args(b.h, 4 * D, p4D, w.fc2, 4 * D, D, b.x, D, 0, 1, M, 4 * D, BD_ACT_NONE);
-        g.resid = b.x; g.ldr = D;
-        const bool next_f16_ln = qkv_single_f16(wprec) && next && next->q_norm_w && next->qkv16.w && hyb;
-        if (next && !next_f16_ln) ln1_ready = try_fuse_layernorm(g, next->ln1_w, next->ln1_b, ln_eps, b.xn, pD, b.ln_sync, prec);
-        BD_TRY(bd_gemm(&g, prec, stream));
+        bd_gemm_args g = gemm_args(b.h, 4 * D, r4D, w.fc2, 4 * D, D, x, D, 0, 1, Mr, 4 * D, BD_ACT_NONE);
+        g.resid = x; g.ldr = D;
+        BD_TRY(bd_gemm(&g, p.c_fc2, stream));
     }
     return BD_OK;
+}
+
+// One pre-LN transformer block: x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x))).
+// BETR: blocks.py:876-886 (+ q/k RMSNorm :257); DINOv2: layers/block.py:89-114 (LayerScale folded).
+int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, int seq, int D, int heads, float ln_eps, float rms_eps,
+              int wprec, void* stream) {
+    const BlockPlan p = plan_block(w, wprec);
+    const int hd = D / heads;
+    BD_TRY(qkv_stage(w, p, b, M, D, heads, ln_eps, rms_eps, stream));
+    BD_TRY(bd_attention(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)M * D, batch, seq, heads, hd, 1.0f / sqrtf((float)hd), p.aprec, stream));
+    return proj_mlp_stage(w, p, b, b.x, M, D, ln_eps, stream);
 }
 
 // Last decoder block: its output is consumed for the query view only (betr.py:303), so only K/V need every token.
 // LN1 + QKV (+ q/k RMSNorm) run on all rows; attention takes queries from the query view's P rows and writes a
 // compact [B*P, D] result; proj, LN2 and the MLP then run on B*P rows (1/T of the work).  Row-wise arithmetic is
 // unchanged, so the result is bit-identical to the full-width block.  xc: fp32 [B*P, D] compact residual stream.
-int run_last_block_query_only(const bd_block_weights& w, bool ln1_ready, const BlockBufs& b, float* xc, const int32_t* query_idx, int B,
-                              int T, int P, int D, int heads, float ln_eps, float rms_eps, int wprec, void* stream) {
+int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, float* xc, const int32_t* query_idx, int B, int T, int P,
+                              int D, int heads, float ln_eps, float rms_eps, int wprec, void* stream) {
+    const BlockPlan p = plan_block(w, wprec);
     const int hd = D / heads, M = B * T * P, Mq = B * P;
-    const int prec = gemm_prec(wprec);
-    const bool c8 = prec == BD_PREC_F16C8;    // f16 + e4m3-correction Linears; attention as in BD_PREC_BF16X3
-    const bool hyb = (prec == BD_PREC_BF16X3 && x3_f16_attention(wprec, w.q_norm_w != nullptr)) || (c8 && w.q_norm_w != nullptr);
-    const bool f8 = prec == BD_PREC_FP8;      // e4m3 Linears, bf16 attention
-    // attention input: f16 single plane where q, k are RMS-normalised (hyb), split-bf16 planes otherwise in the strict classes
-    const int aprec_in = hyb ? BD_PREC_F16 : (f8 ? BD_PREC_BF16 : (c8 ? BD_PREC_BF16X3 : prec));
-    const int aprec = c8 ? (hyb ? BD_PREC_F16_OUT_F16C8 : BD_PREC_BF16X3_OUT_F16C8)
-                         : (hyb ? BD_PREC_F16_OUT_BF16X3 : (f8 ? BD_PREC_BF16_OUT_FP8 : prec));
-    const int qkv_out = hyb ? 2 : (f8 ? 3 : (c8 ? 4 : 0));          // f16 plane / bf16 plane / split-bf16 planes / operand class
-    bool rms_fused = false;
-    const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D;
-    const int64_t qD = (int64_t)Mq * D, q4D = (int64_t)Mq * 4 * D;
-    if (qk_single_f16(wprec) && hyb && w.qkv16.w) {
-        BD_TRY(qkv_split_qk16(w, b.x, b.xn, b.qkv, M, D, hd, ln_eps, rms_eps, ln1_ready, &rms_fused, stream));
-    } else if (qkv_single_f16(wprec) && hyb && w.qkv16.w) {
-        // the one Linear that may leave the split scheme: f16 LayerNorm output x f16 weights, one pass, f16 q, k, v out
-        BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, 0, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16, stream));
-        bd_gemm_args g = gemm_args(b.xn, D, 0, w.qkv16, D, 3 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);
-        g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
-        rms_fused = hd == 96 && bd_gemm_fuses_qk_rmsnorm(&g, BD_PREC_F16);
-        if (!rms_fused) g.rms_wq = g.rms_wk = nullptr;
-        BD_TRY(bd_gemm(&g, BD_PREC_F16, stream));
-    } else {
-        if (!ln1_ready) BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, prec, stream));
-        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, qkv_out, M, D, BD_ACT_NONE);
-        if (w.q_norm_w && hd == 96) {            // q/k RMSNorm in the QKV epilogue where the launch allows it
-            g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
-            rms_fused = bd_gemm_fuses_qk_rmsnorm(&g, prec);
-            if (!rms_fused) g.rms_wq = g.rms_wk = nullptr;
-        }
-        BD_TRY(bd_gemm(&g, prec, stream));
-    }
-    if (w.q_norm_w && !rms_fused) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, aprec_in, stream));
-    BD_TRY(bd_attention_q(b.qkv, p3D, b.ao, qD, B, T * P, heads, hd, 1.0f / sqrtf((float)hd), query_idx, P, aprec, stream));
+    BD_TRY(qkv_stage(w, p, b, M, D, heads, ln_eps, rms_eps, stream));
+    BD_TRY(bd_attention_q(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)Mq * D, B, T * P, heads, hd, 1.0f / sqrtf((float)hd), query_idx, P,
+                          p.aprec, stream));
     BD_TRY(bd_gather_query_rows_f32(b.x, query_idx, xc, B, T, P, D, stream));
-    {
-        bd_gemm_args g = gemm_args(b.ao, D, qD, w.proj, D, D, xc, D, 0, 1, Mq, D, BD_ACT_NONE);
-        g.resid = xc; g.ldr = D;
-        BD_TRY(bd_gemm(&g, prec, stream));
-    }
-    BD_TRY(bd_layernorm(xc, D, w.ln2_w, w.ln2_b, ln_eps, b.xn, qD, nullptr, 0, Mq, D, 0, 0, 0, prec, stream));
-    {
-        bd_gemm_args g = gemm_args(b.xn, D, qD, w.fc1, D, 4 * D, b.h, 4 * D, q4D, 0, Mq, D, BD_ACT_GELU);
-        BD_TRY(bd_gemm(&g, prec, stream));
-    }
-    {
-        bd_gemm_args g = gemm_args(b.h, 4 * D, q4D, w.fc2, 4 * D, D, xc, D, 0, 1, Mq, 4 * D, BD_ACT_NONE);
-        g.resid = xc; g.ldr = D;
-        BD_TRY(bd_gemm(&g, prec, stream));
-    }
-    return BD_OK;
+    return proj_mlp_stage(w, p, b, xc, Mq, D, ln_eps, stream);
 }
 
 BlockBufs carve_block(Carver& c, int64_t M, int D, int np) {
@@ -236,8 +213,6 @@ BlockBufs carve_block(Carver& c, int64_t M, int D, int np) {
     b.qkv = c.take((size_t)M * 3 * D * 2 * np);
     b.ao = c.take((size_t)M * D * 2 * np);
     b.h = c.take((size_t)M * 4 * D * 2 * np);
-    b.ln_sync_bytes = (size_t)((M + 255) / 256) * 4;
-    b.ln_sync = (int*)c.take(b.ln_sync_bytes);
     return b;
 }
 
@@ -273,7 +248,8 @@ DecBufs carve_decoder(const bd_betr_weights* w, int B, int T, int prec, void* ws
 inline bool bad_prec(int prec) {
     return prec != BD_PREC_BF16 && prec != BD_PREC_F16 && prec != BD_PREC_BF16X3 && prec != BD_PREC_FP8 &&
            prec != BD_PREC_BF16X3_ATTN_X3 && prec != BD_PREC_BF16X3_ATTN_F16 && prec != BD_PREC_BF16X3_QKV16 &&
-           prec != BD_PREC_F16C8 && prec != BD_PREC_F16C8_QKV16 && prec != BD_PREC_F16C8_QK16;
+           prec != BD_PREC_F16C8 && prec != BD_PREC_F16C8_QKV16 && prec != BD_PREC_F16C8_QK16 && prec != BD_PREC_F16X3 &&
+           prec != BD_PREC_F16X3_ATTN_X3;
 }
 
 }  // namespace
@@ -295,6 +271,8 @@ extern "C" int bd_encoder_forward(const bd_dino_weights* w, const void* images, 
     if (n_images <= 0 || size != w->grid * w->patch || w->dim % w->heads || w->kpad % 64 ||
         w->kpad < 3 * w->patch * w->patch)
         return BD_ERR_SHAPE;
+    if (w->feats_prec != 0 && !(w->feats_prec == prec || (prec == BD_PREC_F16C8 && w->feats_prec == BD_PREC_F16X3))) return BD_ERR_DTYPE;
+    const int feats_prec = w->feats_prec ? w->feats_prec : prec;
     if ((uintptr_t)workspace & 255) return BD_ERR_ALIGN;
     const EncBufs e = carve_encoder(w, n_images, prec, workspace);
     if (workspace_bytes < e.bytes) return BD_ERR_WORKSPACE;
@@ -303,24 +281,22 @@ extern "C" int bd_encoder_forward(const bd_dino_weights* w, const void* images, 
 
     // K1+K2: normalise + im2col, then the patch-embed GEMM scattering rows b*P+p -> b*tpi+n_prefix+p and
     // adding the (pre-resampled) positional table  (vision_transformer.py:213-232, patch_embed.py:65-75)
+    const int c_pe = lin_class(prec, w->promote_misc, BD_PROMOTE_PATCH_EMBED);
     BD_TRY(bd_im2col_images(images, img_dtype, e.a_patch, (int64_t)Mp * w->kpad, n_images, size, w->patch, w->kpad,
-                            prec, stream));
+                            c_pe, stream));
     {
         bd_gemm_args g = gemm_args(e.a_patch, w->kpad, (int64_t)Mp * w->kpad, w->patch_embed, w->kpad, D, e.blk.x, D, 0,
                                    1, Mp, w->kpad, BD_ACT_NONE);
         g.addtab = w->pos_patch; g.tab_rows = P;
         g.rpg_in = P; g.rpg_out = tpi; g.row_off = w->n_prefix;
-        BD_TRY(bd_gemm(&g, prec, stream));
+        BD_TRY(bd_gemm(&g, c_pe, stream));
     }
     BD_TRY(bd_write_prefix_tokens(e.blk.x, w->prefix_tokens, n_images, tpi, w->n_prefix, D, stream));
-    if (hipMemsetAsync(e.blk.ln_sync, 0, e.blk.ln_sync_bytes, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
-    bool ln1_ready = false;
     for (int i = 0; i < w->depth; ++i)
-        BD_TRY(run_block(w->blocks[i], i + 1 < w->depth ? &w->blocks[i + 1] : nullptr, ln1_ready, e.blk, Md, n_images, tpi, D, w->heads,
-                         w->ln_eps, 0.f, wprec, stream));
-    // final LayerNorm on the patch tokens only (vision_transformer.py:263-267)
+        BD_TRY(run_block(w->blocks[i], e.blk, Md, n_images, tpi, D, w->heads, w->ln_eps, 0.f, wprec, stream));
+    // final LayerNorm on the patch tokens only (vision_transformer.py:263-267); feats16 in the class the consumer's first Linear reads
     BD_TRY(bd_layernorm(e.blk.x, D, w->norm_w, w->norm_b, w->ln_eps, feats16, feats16_plane, feats32, D, Mp, D, P, tpi,
-                        w->n_prefix, prec, stream));
+                        w->n_prefix, feats_prec, stream));
     return BD_OK;
 }
 
@@ -346,40 +322,42 @@ extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_fea
     const int Mb = B * T * P, Mq = B * P;
     const int64_t pD = (int64_t)Mb * D;
 
-    // K6 adapter: LN_noaffine(fc2(gelu(fc1(feat))))  (betr.py:313-317)
+    // operand classes of the Linears outside the blocks (F16C8 family: per-Linear promotion, include/boxdreamer_hip.h)
+    const int pmisc = (w->promote_misc & BD_PROMOTE_ADAPTER_FC1) ? (w->promote_misc | BD_PROMOTE_ADAPTER_FC2) : w->promote_misc;
+    const int c_a1 = lin_class(prec, pmisc, BD_PROMOTE_ADAPTER_FC1), c_a2 = lin_class(prec, pmisc, BD_PROMOTE_ADAPTER_FC2);
+    const int c_be = lin_class(prec, pmisc, BD_PROMOTE_BBOX_EMB), c_bp = lin_class(prec, pmisc, BD_PROMOTE_BBOX_PROJ);
+    // K6 adapter: LN_noaffine(fc2(gelu(fc1(feat))))  (betr.py:313-317); feats16 arrives in the class of adapter fc1
     {
-        bd_gemm_args g = gemm_args(feats16, D, feats16_plane, w->adapter_fc1, D, D, d.t1, D, pD, 0, Mb, D, BD_ACT_GELU);
-        BD_TRY(bd_gemm(&g, prec, stream));
+        bd_gemm_args g = gemm_args(feats16, D, feats16_plane, w->adapter_fc1, D, D, d.t1, D, pD, handoff_kind(c_a1, c_a2), Mb, D, BD_ACT_GELU);
+        BD_TRY(bd_gemm(&g, c_a1, stream));
     }
     {
         bd_gemm_args g = gemm_args(d.t1, D, pD, w->adapter_fc2, D, D, d.t2, D, 0, 1, Mb, D, BD_ACT_NONE);
-        BD_TRY(bd_gemm(&g, prec, stream));
+        BD_TRY(bd_gemm(&g, c_a2, stream));
     }
     BD_TRY(bd_layernorm(d.t2, D, nullptr, nullptr, w->adapter_ln_eps, nullptr, 0, d.rgb, D, Mb, D, 0, 0, 0, prec, stream));
     // K7+K8: heatmap patch embedding fused with  + rgb + pos  (betr.py:324-329, 367-399)
     BD_TRY(bd_patchify_heatmaps(bbox_feat, in_dtype, d.a_heat, (int64_t)Mb * w->kpad, B * T, w->box_dim, size, w->patch,
-                                w->kpad, prec, stream));
+                                w->kpad, c_be, stream));
     {
         bd_gemm_args g = gemm_args(d.a_heat, w->kpad, (int64_t)Mb * w->kpad, w->bbox_emb, w->kpad, D, d.blk.x, D, 0, 1,
                                    Mb, w->kpad, BD_ACT_NONE);
         g.addtab = w->pos_table; g.tab_rows = P;
         g.resid = d.rgb; g.ldr = D;
-        BD_TRY(bd_gemm(&g, prec, stream));
+        BD_TRY(bd_gemm(&g, c_be, stream));
     }
     BD_TRY(bd_query_substitute(d.blk.x, d.rgb, w->pos_table, w->query_token, query_idx, B, T, P, D, stream));
     // K9: joint self-attention over all T*P tokens of a sample
-    if (hipMemsetAsync(d.blk.ln_sync, 0, d.blk.ln_sync_bytes, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
-    bool ln1_ready = false;
     for (int i = 0; i + 1 < w->depth; ++i)
-        BD_TRY(run_block(w->blocks[i], &w->blocks[i + 1], ln1_ready, d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, wprec, stream));
+        BD_TRY(run_block(w->blocks[i], d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, wprec, stream));
     // last block: query-view rows only past the K/V projection; d.t2 (dead since the adapter) holds the compact stream
-    BD_TRY(run_last_block_query_only(w->blocks[w->depth - 1], ln1_ready, d.blk, d.t2, query_idx, B, T, P, D, w->heads,
+    BD_TRY(run_last_block_query_only(w->blocks[w->depth - 1], d.blk, d.t2, query_idx, B, T, P, D, w->heads,
                                      w->ln_eps, w->rms_eps, wprec, stream));
     // K10: head on the query view's tokens (no final norm, betr.py:298-306)
-    BD_TRY(bd_gather_query_tokens(d.t2, nullptr, d.qtok, (int64_t)Mq * D, B, 1, P, D, prec, stream));
+    BD_TRY(bd_gather_query_tokens(d.t2, nullptr, d.qtok, (int64_t)Mq * D, B, 1, P, D, c_bp, stream));
     {
         bd_gemm_args g = gemm_args(d.qtok, D, (int64_t)Mq * D, w->bbox_proj, D, F, d.proj, F, 0, 1, Mq, D, BD_ACT_NONE);
-        BD_TRY(bd_gemm(&g, prec, stream));
+        BD_TRY(bd_gemm(&g, c_bp, stream));
     }
     BD_TRY(bd_unpatchify_sigmoid(d.proj, logits, heat, B, w->box_dim, size, w->patch, stream));
     return BD_OK;

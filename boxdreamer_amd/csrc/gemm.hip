@@ -22,20 +22,8 @@
 // Experiments that did NOT pay (deeper LDS-DMA rings, mid-slab barriers, ping-pong wave groups, 256x128 tiles at one or
 // two workgroups per CU, a persistent tile loop with the epilogue overlapped, pinned fragment prefetch) and the counters
 // behind the choices: profiles/r1_gemm_experiments.md, profiles/r1_gemm_pmc.md.
-#ifndef BD_STORE_NT
-#define BD_STORE_NT 1   // non-temporal 16/8-bit epilogue stores (bd_common.h: store_cvt)
-#endif
-#ifndef BD_EXP_NOSTORE
-#define BD_EXP_NOSTORE 0 // measurement builds only: 1 drops the 16-bit epilogue stores (invalid results) to time the rest
-#endif
-// Compile-time kernel-selection policy, for A/B builds loaded through BOXDREAMER_HIP_LIB (never an environment switch):
-// 0 = one-tile-per-workgroup kernels only (round 1), 1 = persistent producer/consumer kernel with 256x192 tiles where they
-// fit and fill the CUs' rounds (default).
-#ifndef BD_GEMM_POLICY
-#define BD_GEMM_POLICY 1
-#endif
-
 #include "bd_common.h"
+#include <type_traits>
 
 #ifdef BD_GEMM_PROBE
 // Measurement build only (tools/gemm_phase_probe.py; never part of libboxdreamer_hip.so): per-wave shader-clock stamps of
@@ -109,7 +97,7 @@ __device__ __forceinline__ unsigned lds_offset_of(const void* p) {
 }
 
 // out_f32 codes
-enum { OUT_OPERAND = 0, OUT_F32 = 1, OUT_F16 = 2, OUT_BF16 = 3, OUT_BF16X2 = 4 };
+enum { OUT_OPERAND = 0, OUT_F32 = 1, OUT_F16 = 2, OUT_BF16 = 3, OUT_BF16X2 = 4, OUT_F16X2 = 5 };
 
 // Accumulator start values and where the epilogue terms enter -- ONE convention for every kernel, so that a row's result
 // does not depend on the tile shape that computed it (the property tests compare a sample run alone with the same sample
@@ -300,13 +288,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 
         const int c8 = lane % LPR, rsub = lane / LPR;
         const int out_mode = p.out_f32;
         auto store8 = [&](int64_t orow, int gc, const float (&v)[8]) {
-            if (BD_EXP_NOSTORE) return;
             if (out_mode == OUT_F16) {            // f16 single plane (optional f16 attention of the strict mode)
                 store_cvt<_Float16, 8>((_Float16*)p.out + orow * ldo + gc, v);
             } else if (out_mode == OUT_BF16) {    // bf16 single plane (fp8 mode: attention operands stay bf16)
                 store_cvt<__bf16, 8>((__bf16*)p.out + orow * ldo + gc, v);
             } else if (out_mode == OUT_BF16X2) {  // split-bf16 planes (F16C8 mode: DINOv2's split-bf16 attention)
                 store_operand8<__bf16, 2>((__bf16*)p.out, out_plane, orow * ldo + gc, v);
+            } else if (out_mode == OUT_F16X2) {   // split-f16 planes (an F16C8 Linear feeding a promoted, split-f16 one)
+                store_operand8<_Float16, 2>((_Float16*)p.out, out_plane, orow * ldo + gc, v);
             } else {
                 store_operand8<T, NS>((T*)p.out, out_plane, orow * ldo + gc, v);
             }
@@ -596,9 +585,7 @@ __device__ __forceinline__ float quad_sum(float x) {
 //   rmsw: q weights at [0, 96), k weights at [256, 352)
 //   wcol: first column of the wave tile inside the workgroup tile;  (wm0, wn0): its global origin
 //   next: the wave tile origin of this workgroup's next tile (EP 3 pre-loads its residual), has_next = there is one
-// WT: the fp32 rows leave as WRITE-THROUGH (sc1) 16-byte stores -- the payload of the fused LayerNorm's inter-workgroup hand-off
-// (fused_panel_layernorm): visible device-wide once the storing wave's vmcnt drains, without an L2 write-back fence.
-template <class T, int NS, int EP, int OUTK, bool GELU, int MI = 2, bool WT = false>
+template <class T, int NS, int EP, int OUTK, bool GELU, int MI = 2>
 __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)[MI][3], float* sc, const float* colp, const float* colp_next,
                                             const float* rmsw, int wcol, int wm0, int wn0, int lane, bool has_next, int nwm0, int nwn0) {
     constexpr int COLS = 96;
@@ -661,8 +648,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
                     float* op = (float*)p.out + (int64_t)gr * p.ldo + wn0 + c4 * 4;
 #pragma unroll
                     for (int cb = 0; cb < 3; ++cb) {
-                        if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(op + cb * 32), "v"(v[cb]) : "memory");
-                        else *(f32x4*)(op + cb * 32) = v[cb];
+                        *(f32x4*)(op + cb * 32) = v[cb];
                     }
                 }
             }
@@ -705,25 +691,18 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
                 rb[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x07060302u); rb[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x07060302u);
                 const int gr = wm0 + i * 32 + 2 * prow;
                 T* op = (T*)p.out + (int64_t)gr * p.ldo + wn0 + cg * 8;
-                if (!BD_EXP_NOSTORE) {
-#if defined(BD_STORE_NT) && BD_STORE_NT
-                    if (gr < M) __builtin_nontemporal_store(ra, (u128*)op);
-                    if (gr + 1 < M) __builtin_nontemporal_store(rb, (u128*)(op + p.ldo));
-#else
-                    if (gr < M) *(u128*)op = ra;
-                    if (gr + 1 < M) *(u128*)(op + p.ldo) = rb;
-#endif
-                }
+                if (gr < M) __builtin_nontemporal_store(ra, (u128*)op);
+                if (gr + 1 < M) __builtin_nontemporal_store(rb, (u128*)(op + p.ldo));
             }
         }
     } else {
         // 16-bit rows: 4 lanes x 16 bytes per row and 32-column block, 16 rows per pass
         const int c8 = lane & 3, rsub = lane >> 2;
         auto store8 = [&](int64_t e, const float (&v)[8]) {
-            if (BD_EXP_NOSTORE) return;
             if constexpr (OUTK == OUT_F16) store_cvt<_Float16, 8>((_Float16*)p.out + e, v);
             else if constexpr (OUTK == OUT_BF16) store_cvt<__bf16, 8>((__bf16*)p.out + e, v);
             else if constexpr (OUTK == OUT_BF16X2) store_operand8<__bf16, 2>((__bf16*)p.out, p.out_plane, e, v);
+            else if constexpr (OUTK == OUT_F16X2) store_operand8<_Float16, 2>((_Float16*)p.out, p.out_plane, e, v);
             else store_operand8<T, NS>((T*)p.out, p.out_plane, e, v);
         };
         float wv[EP == 2 ? 3 : 1][8];
@@ -785,50 +764,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
     }
 }
 
-// Fused LayerNorm of a finished row panel (LNF kernels, EP 3: the fp32 result IS the residual stream).  Called by every consumer wave
-// after its epilogue.  Inter-workgroup hand-off in its counter form, placement-independent (cdna_hip_programming.md G16): every wave
-// drains its stores, which are WRITE-THROUGH (sc1: pc_epilogue WT), so no release fence is needed (an agent-scope release is a
-// write-back of the whole L2: one per wave measured 3.7x on the whole GEMM, one per workgroup tile still 3.4x); workgroup barrier Y1
-// (the producers take part: they idle there instead of at the next tile's first slab barrier); one lane counts the tile in on the
-// panel's counter (relaxed, agent scope), learning whether it was the panel's last column tile; barrier
-// Y2 hands that flag to all waves through one LDS word; the last workgroup's consumer waves then normalise the panel, reading its
-// rows with device-coherent (sc1) loads -- no acquire fence: buffer_inv sc1 empties the XCD's L2 under every other CU's GEMM --
-// rows split over the waves, TWO rows in flight per wave, each row by one wave exactly as norm.hip does (ln_row_*: same bits).  The counter goes back to zero for the next launch.  The drain costs nothing
-// extra: an EP-3 consumer already waits for its stores at the first MFMA of the next tile (in-order vmcnt behind the residual
-// pre-loads).
-template <class T, int NS, int NCW, int TBM>
-__device__ __forceinline__ void fused_panel_layernorm(const bd_gemm_args& p, unsigned* flag_lds, int m0, int tilesN, int wid, int lane) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    pc_barrier();                                  // Y1: every consumer wave's part of the tile has reached the L2
-    if (wid == 0) {
-        if (lane == 0) {
-            int* cnt = p.ln_sync + m0 / TBM;
-            const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned last = old == tilesN - 1;
-            if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *(volatile unsigned*)flag_lds = last;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (pc_barrier is a bare s_barrier: the LDS word must have landed)
-        }
-    }
-    pc_barrier();                                  // Y2
-    if (*(volatile unsigned*)flag_lds) {
-        constexpr int RPW = TBM / NCW;             // rows per consumer wave
-        const float* x = (const float*)p.out;
-        const int r0 = m0 + wid * RPW;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < RPW; k += 2) {
-            const int ra = r0 + k, rb = r0 + k + 1;
-            f32x4 ta[4] = {z, z, z, z}, tb[4] = {z, z, z, z};
-            if (ra < p.M) ln_row_load_sc1(x + (int64_t)ra * p.ldo, p.N, lane, ta);
-            if (rb < p.M) ln_row_load_sc1(x + (int64_t)rb * p.ldo, p.N, lane, tb);
-            ln_rows_wait(ta, tb);
-            if (ra < p.M) ln_row_finish<T, NS>(ta, p.ln_gamma, p.ln_beta, p.ln_eps, (T*)p.ln_out, p.ln_out_plane, nullptr, (int64_t)ra, p.N, lane);
-            if (rb < p.M) ln_row_finish<T, NS>(tb, p.ln_gamma, p.ln_beta, p.ln_eps, (T*)p.ln_out, p.ln_out_plane, nullptr, (int64_t)rb, p.N, lane);
-        }
-    }
-}
-
-template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NPW, int EP, int OUTK, bool GELU, bool LNF = false>
+template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NPW, int EP, int OUTK, bool GELU>
 __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const bd_gemm_args p) {
     bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 frag_t;
@@ -846,7 +782,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
     static_assert(PA % NPW == 0 && PW % NPW == 0, "pieces split evenly over the producer waves");
     constexpr int SR = (EP == 0 && NCW * 32 * NI * 32 * 4 <= STAGE_BYTES) ? 32 : 16;      // LDS-staged epilogue: scratch rows per pass
     static_assert(NCW * SR * NI * 32 * 4 <= STAGE_BYTES, "the epilogue scratch must fit one stage");
-    static_assert(EP == 0 || ((MI == 2 || MI == 4) && NI == 3 && SR == 16 && TBN <= 256), "pc_epilogue is written for 96-column wave tiles");
+    static_assert(EP == 0 || (MI == 2 && NI == 3 && SR == 16 && TBN <= 256), "pc_epilogue is written for 96-column wave tiles");
     // side buffer behind the ring: per-column vectors of the current / next tile (2 x [bias 1 KiB | weight scale 1 KiB]) and
     // the q / k RMSNorm weights (2 x 1 KiB)
     constexpr int AUX_COLP = 2 * STAGE_BYTES, AUX_RMS = AUX_COLP + 4096, AUX_BYTES = EP == 0 ? 0 : 6144;
@@ -965,7 +901,6 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 ++g;
             }
             pc_barrier();                              // X: every consumer is done with the tile's last slab
-            if constexpr (LNF) { pc_barrier(); pc_barrier(); }      // Y1, Y2 of fused_panel_layernorm
         }
 #ifdef BD_GEMM_PROBE
         if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * 16 + wid) * 64 + lane] = probe_ts;
@@ -1017,36 +952,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                \
                     LOAD_ONE(b[slot][s2][j], base + NS * A_BYTES + s2 * W_BYTES, wn * (NI * 32) + j * 32 + lrow, ks) \
             }
-            if constexpr (NS == 1 && MI == 4) {
-                // 128 x 96 wave tile (ONE consumer wave per SIMD, four per workgroup: the vendor GEMM's shape -- 7 fragment reads feed 12
-                // MFMAs per k-step, 0.58 LDS reads per MFMA against 0.83 for the 64 x 96 tile; profiles/r2_hipblaslt_reference.md).
-                // 192 accumulator registers leave room for ONE set of A fragments and two of W fragments, so MFMAs go row by row
-                // (i outer): after the three MFMAs of row i its A fragment is dead and the NEXT k-step's A fragment of that row is
-                // loaded into the same registers; the next W fragments ride under the first three MFMAs.  Order pinned as below.
-                static_assert(NI == 3, "row-major MFMA order below is written for 3 column tiles");
-                frag_t a1[MI], b2[2][NI];
-                LOAD_ONE(a1[0], base, wm * (MI * 32) + lrow, 0)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) LOAD_ONE(b2[0][j], base + NS * A_BYTES, wn * (NI * 32) + j * 32 + lrow, 0)
-#pragma unroll
-                for (int i = 1; i < MI; ++i) LOAD_ONE(a1[i], base, wm * (MI * 32) + i * 32 + lrow, 0)
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const int cur = ks & 1;
-                    const bool more = ks + 1 < KS;
-#pragma unroll
-                    for (int q = 0; q < MI * NI; ++q) {
-                        const int i = q / NI, j = q % NI;
-                        acc[i][j] = Op16<T>::mfma(a1[i], b2[cur][j], acc[i][j]);
-                        if (more) {
-                            if (q < NI) LOAD_ONE(b2[cur ^ 1][q], base + NS * A_BYTES, wn * (NI * 32) + q * 32 + lrow, ks + 1)
-                            if (j == NI - 1) LOAD_ONE(a1[i], base, wm * (MI * 32) + i * 32 + lrow, ks + 1)
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            } else if constexpr (NS == 1) {
+            if constexpr (NS == 1) {
                 // Software pipeline inside the slab, order PINNED (sched_barrier(0) after every MFMA / ds_read pair): the
                 // fragment reads of k-step ks+1 are interleaved one-for-one with the MFMAs of k-step ks, so a consumer wave
                 // keeps its matrix pipe fed on its own.  (With producers doing the DMA, both consumer waves of a SIMD leave the
@@ -1151,13 +1057,9 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 const bool has_next = t + stride < t_end;
                 int nm0 = 0, nn0 = 0;
                 if (has_next) tile_origin(t + stride, nm0, nn0);
-                pc_epilogue<T, NS, EP, OUTK, GELU, MI, LNF>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
+                pc_epilogue<T, NS, EP, OUTK, GELU, MI>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
                                                   (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
                                                   lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
-                if constexpr (LNF) {
-                    static_assert(!LNF || EP == 3, "the fused LayerNorm follows the fp32 residual epilogue");
-                    fused_panel_layernorm<T, NS, NCW, TBM>(p, (unsigned*)(lds + AUX_RMS), m0, tilesN, wid, lane);
-                }
             }
         }
         BD_PROBE_IF(g == nk, 62)
@@ -1187,7 +1089,7 @@ inline bool wide_epilogue_ok(const bd_gemm_args& p, int ns) {
 //     slab in this operand class, is off the critical path.  NSTAGE = 2 (scratch separate) serves the other K.
 //   * the e4m3 image q8 of an f16 fragment derived in registers (v_cvt_scalef32_pk_fp8_f16, 4 per fragment), so the
 //     correction pass costs one extra ds_read_b128 per 32-row fragment pair instead of two.
-template <int NSTAGE, int EP, int OUTK, bool GELU, bool LNF = false>
+template <int NSTAGE, int EP, int OUTK, bool GELU>
 __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_args p) {
     constexpr int WM = 4, WN = 2, MI = 2, NI = 3, NPW = 4, NCW = WM * WN;
     constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32, BK = 32;
@@ -1310,7 +1212,6 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
                 ++g;
             }
             pc_barrier();                                 // X: consumers are done with the tile's last slab (scratch = stage 2 ..)
-            if constexpr (LNF) { pc_barrier(); pc_barrier(); }         // Y1, Y2 of fused_panel_layernorm
         }
 #ifdef BD_GEMM_PROBE
         if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * 16 + wid) * 64 + lane] = probe_ts;
@@ -1431,13 +1332,9 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
             const bool has_next = t + stride < t_end;
             int nm0 = 0, nn0 = 0;
             if (has_next) tile_origin(t + stride, nm0, nn0);
-            pc_epilogue<f16c8, 2, EP, OUTK, GELU, 2, LNF>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
+            pc_epilogue<f16c8, 2, EP, OUTK, GELU, 2>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
                                                  (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
                                                  lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
-            if constexpr (LNF) {
-                static_assert(!LNF || EP == 3, "the fused LayerNorm follows the fp32 residual epilogue");
-                fused_panel_layernorm<f16c8, 2, NCW, TBM>(p, (unsigned*)(lds + AUX_RMS), m0, tilesN, wid, lane);
-            }
         }
         BD_PROBE_IF(g == nk, 62)
     }
@@ -1461,17 +1358,12 @@ template <class T, int NS> int pc_epilogue_kind(const bd_gemm_args& a, int& outk
     if (a.resid) return 0;
     if (a.wscale && (sizeof(T) != 1 || ((uintptr_t)a.wscale & 15))) return 0;
     // output kinds instantiated per operand class: native everywhere; f16 from split-bf16 (strict f16 attention), bf16 from e4m3
-    const bool outk_ok = outk == OUT_OPERAND || (outk == OUT_F16 && NS == 2 && sizeof(T) == 2) || (outk == OUT_BF16 && sizeof(T) == 1);
+    const bool outk_ok = outk == OUT_OPERAND || (outk == OUT_F16 && NS == 2 && sizeof(T) == 2) || (outk == OUT_BF16 && sizeof(T) == 1) ||
+                         (outk == OUT_BF16X2 && NS == 2 && std::is_same<T, _Float16>::value);   // split-f16 QKV feeding split-bf16 attention
     if (!outk_ok) return 0;
     if (a.rms_wq) return gelu ? 0 : 2;
+    if (gelu && outk != OUT_OPERAND) return 0;
     return 1;
-}
-
-// a fused LayerNorm needs: the fp32 residual result over complete rows of <= 1024 columns in 192-column tiles, identity row map
-inline bool ln_geometry_ok(const bd_gemm_args& a) {
-    return a.ln_out && a.ln_sync && a.out_f32 == OUT_F32 && a.act == BD_ACT_NONE && !a.addtab && a.rpg_in <= 0 && !a.rms_wq &&
-           a.N % 192 == 0 && a.N <= 1024 && a.ldo == a.N && (a.ln_out_plane % 8) == 0 &&
-           (((uintptr_t)a.ln_out | (uintptr_t)a.ln_gamma | (uintptr_t)a.ln_beta) & 15) == 0 && ((uintptr_t)a.ln_sync & 3) == 0;
 }
 
 template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_pc(const bd_gemm_args& a, hipStream_t s, int cus) {
@@ -1485,10 +1377,12 @@ template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_p
     const int ep = (a.N % TBN == 0) ? pc_epilogue_kind<T, NS>(a, outk, gelu) : 0;
 #define BD_PC_LAUNCH(EP_, OUTK_, GELU_) hipLaunchKernelGGL((gemm_kernel_pc<T, NS, BK, WM, WN, MI, NI, NPW, EP_, OUTK_, GELU_>), g, b, 0, s, a)
     constexpr int ALT = (NS == 2 && sizeof(T) == 2) ? OUT_F16 : (sizeof(T) == 1 ? OUT_BF16 : OUT_OPERAND);   // the one non-native 16-bit kind
-    if (ep == 3 && a.ln_out) hipLaunchKernelGGL((gemm_kernel_pc<T, NS, BK, WM, WN, MI, NI, NPW, 3, OUT_F32, false, true>), g, b, 0, s, a);
-    else if (ep == 3) BD_PC_LAUNCH(3, OUT_F32, false);
+    constexpr bool X2 = NS == 2 && std::is_same<T, _Float16>::value;     // split-f16 also emits split-bf16 planes (attention input)
+    if (ep == 3) BD_PC_LAUNCH(3, OUT_F32, false);
+    else if (ep == 2 && outk == OUT_BF16X2) { if constexpr (X2) BD_PC_LAUNCH(2, OUT_BF16X2, false); }
     else if (ep == 2) { if (outk == OUT_OPERAND) BD_PC_LAUNCH(2, OUT_OPERAND, false); else BD_PC_LAUNCH(2, ALT, false); }
     else if (ep == 1 && gelu && outk == OUT_OPERAND) BD_PC_LAUNCH(1, OUT_OPERAND, true);
+    else if (ep == 1 && !gelu && outk == OUT_BF16X2) { if constexpr (X2) BD_PC_LAUNCH(1, OUT_BF16X2, false); }
     else if (ep == 1 && !gelu) { if (outk == OUT_OPERAND) BD_PC_LAUNCH(1, OUT_OPERAND, false); else BD_PC_LAUNCH(1, ALT, false); }
     else BD_PC_LAUNCH(0, OUT_OPERAND, false);
 #undef BD_PC_LAUNCH
@@ -1529,7 +1423,7 @@ template <class T> bd_gemm_args row_slice(const bd_gemm_args& a, int64_t row0, i
 
 // does this problem go to the persistent 256 x 192 kernel (every wave tile = 96 consecutive output columns)?
 inline bool pc192_possible(const bd_gemm_args& a, int ns, int esz) {
-    return BD_GEMM_POLICY == 1 && wide_epilogue_ok(a, ns) && 256 * a.lda * esz < ((int64_t)1 << 31) && 256 * a.ldw * esz < ((int64_t)1 << 31);
+    return wide_epilogue_ok(a, ns) && 256 * a.lda * esz < ((int64_t)1 << 31) && 256 * a.ldw * esz < ((int64_t)1 << 31);
 }
 inline bool uses_pc192(const bd_gemm_args& a, int ns, int esz, int cus) {
     if (!pc192_possible(a, ns, esz)) return false;
@@ -1551,66 +1445,17 @@ inline bool rms_geometry_ok(const bd_gemm_args& a) {
            a.N % (a.rms_parts == 2 ? 2 : 3) == 0 && (a.N / (a.rms_parts == 2 ? 2 : 3)) % 96 == 0 && a.N % 192 == 0 && (((uintptr_t)a.rms_wq | (uintptr_t)a.rms_wk) & 3) == 0;
 }
 
-// does bd_gemm run the fused LayerNorm for these arguments (persistent kernel + fp32 residual epilogue)?
-template <class T, int NS> bool fuses_ln(const bd_gemm_args& a, int cus) {
-#ifdef BD_EXP_PC_HYBRID
-    return false;                    // (A/B builds with the row split: a panel's tiles would come from two launches)
-#endif
-    if (!ln_geometry_ok(a) || !uses_pc192(a, NS, OpGeom<T>::ESZ, cus)) return false;
-    int outk = 0;
-    bool gelu = false;
-    return pc_epilogue_kind<T, NS>(a, outk, gelu) == 3;
-}
-inline bool f16c8_ep3_ok(const bd_gemm_args& a) {
-    return wide_epilogue_ok(a, 2) && 256 * a.lda * 2 < ((int64_t)1 << 31) && 256 * a.ldw * 2 < ((int64_t)1 << 31) && !a.addtab &&
-           a.rpg_in <= 0 && !a.wscale && a.N % 192 == 0 && a.K >= 128 && !(a.bias && ((uintptr_t)a.bias & 15)) &&
-           a.out_f32 == OUT_F32 && a.act != BD_ACT_GELU && !a.rms_wq;
-}
-
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {
     const int kCUs = cu_count();
     if (a.rms_wq && !(rms_geometry_ok(a) && pc192_possible(a, NS, OpGeom<T>::ESZ))) return BD_ERR_SHAPE;
-    if (a.ln_out && !fuses_ln<T, NS>(a, kCUs)) return BD_ERR_SHAPE;
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
-    // the producer wave of gemm_kernel_pc addresses a tile's operand rows with 32-bit byte offsets from the tile origin
     constexpr int ESZ_ = OpGeom<T>::ESZ;
-    const bool pc_ok = BD_GEMM_POLICY != 0 && wide_epilogue_ok(a, NS) && 256 * a.lda * ESZ_ < ((int64_t)1 << 31) &&
-                       256 * a.ldw * ESZ_ < ((int64_t)1 << 31);
     {
         // 256 x 192 tiles (8 consumer waves of 64 x 96: 96 accumulator + 2 x 20 fragment registers fit the 168-VGPR budget
         // of three waves per SIMD with the fragment double-buffering intact) whenever they tile N exactly -- every Linear of
         // both stacks except the head (N = 2304, 3072, 768 are multiples of 192).
         if (uses_pc192(a, NS, ESZ_, kCUs)) {
-            // A ragged last round (DINOv2: M = 50112 = 195.75 row tiles; N = 768 -> 784 tiles = 3 rounds + 16 tiles) costs a whole
-            // tile time on a few CUs.  Row split: the row tiles that make FULL rounds go to the persistent kernel, the remaining
-            // rows to one partial round of small one-tile workgroups (a row's arithmetic does not depend on the tile shape).
-            int64_t rows_pc = a.M;
-#ifdef BD_EXP_PC_HYBRID
-            if (!a.rms_wq && a.rpg_in <= 0 && !a.addtab) {
-                const int ncol = a.N / 192;
-                const int64_t mt = (a.M + 255) / 256, t = mt * ncol, full = t / kCUs, rem = t % kCUs;
-                if (full >= 1 && rem > 0 && rem * BD_EXP_PC_HYBRID < kCUs) {
-                    const int64_t mt_full = full * kCUs / ncol;                 // row tiles inside the full rounds
-                    if (mt_full * 256 < a.M) rows_pc = mt_full * 256;
-                }
-            }
-#endif
-            if (rows_pc < a.M) {
-                launch_pc<T, NS, BK, 4, 2, 2, 3>(row_slice<T>(a, 0, (int)rows_pc), s, kCUs);
-                const bd_gemm_args rest = row_slice<T>(a, rows_pc, (int)(a.M - rows_pc));
-#if defined(BD_EXP_PC_HYBRID_64)
-                launch_glds<T, NS, BK, 2, 2, 1, 1>(rest, s);
-#else
-                launch_glds<T, NS, BK, 2, 2, 2, 2>(rest, s);
-#endif
-            } else {
-#if defined(BD_PC_WAVES4)      // A/B build: four consumer waves of 128 x 96 (one per SIMD) instead of eight of 64 x 96
-                if constexpr (NS == 1 && sizeof(T) == 2) launch_pc<T, NS, BK, 2, 2, 4, 3>(a, s, kCUs);
-                else launch_pc<T, NS, BK, 4, 2, 2, 3>(a, s, kCUs);
-#else
-                launch_pc<T, NS, BK, 4, 2, 2, 3>(a, s, kCUs);
-#endif
-            }
+            launch_pc<T, NS, BK, 4, 2, 2, 3>(a, s, kCUs);
             bd_trace_close(s, slot);
             BD_CHECK_LAUNCH();
             return BD_OK;
@@ -1687,16 +1532,11 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
             // Sparse launches (small batch: every tile gets its own workgroup slot at once, so the launch lasts one tile's chain of
             // slab latencies): the 4-stage ring form of the same tile (three slabs in flight; 128 / 64 KiB of LDS: one / two per CU).
             const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128), t64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
-#ifdef BD_EXP_NO_DEEP_RING
-            const bool deep_ok = false;
-#else
-            const bool deep_ok = true;
-#endif
             if (e128 >= e64) {
-                if (deep_ok && t128 <= kCUs) launch_glds<T, NS, BK, 2, 2, 2, 2, 4>(a, s);
+                if (t128 <= kCUs) launch_glds<T, NS, BK, 2, 2, 2, 2, 4>(a, s);
                 else launch_glds<T, NS, BK, 2, 2, 2, 2>(a, s);    // 128 x 128, 2 workgroups / CU
             } else {
-                if (deep_ok && t64 <= 2 * kCUs) launch_glds<T, NS, BK, 2, 2, 1, 1, 4>(a, s);
+                if (t64 <= 2 * kCUs) launch_glds<T, NS, BK, 2, 2, 1, 1, 4>(a, s);
                 else launch_glds<T, NS, BK, 2, 2, 1, 1>(a, s);    // 64 x 64 (latency mode: batch 1, M = 1536)
             }
         }
@@ -1713,7 +1553,6 @@ int launch_f16c8(const bd_gemm_args& a, hipStream_t s) {
     if (a.out_f32 == OUT_OPERAND && (a.ldo % 32)) return BD_ERR_SHAPE;
     if (a.w_qexp + BD_F16C8_D < -100 || a.w_qexp + BD_F16C8_D > 120) return BD_ERR_SHAPE;
     if (a.rms_wq && !rms_geometry_ok(a)) return BD_ERR_SHAPE;
-    if (a.ln_out && !(ln_geometry_ok(a) && f16c8_ep3_ok(a))) return BD_ERR_SHAPE;
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     const int cus = cu_count();
     const int tiles = ((a.M + 255) / 256) * ((a.N + 191) / 192);
@@ -1731,11 +1570,7 @@ int launch_f16c8(const bd_gemm_args& a, hipStream_t s) {
 #define BD_C8_LAUNCH(EP_, OUTK_, GELU_)                                                                     \
     { if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_>), g, b, 0, s, a);                 \
       else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, EP_, OUTK_, GELU_>), g, b, 0, s, a); }
-    if (ep == 3 && a.ln_out) {
-        if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 3, OUT_F32, false, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, 3, OUT_F32, false, true>), g, b, 0, s, a);
-    }
-    else if (ep == 3) BD_C8_LAUNCH(3, OUT_F32, false)
+    if (ep == 3) BD_C8_LAUNCH(3, OUT_F32, false)
     else if (ep == 2 && outk == OUT_OPERAND) BD_C8_LAUNCH(2, OUT_OPERAND, false)
     else if (ep == 2 && outk == OUT_F16) BD_C8_LAUNCH(2, OUT_F16, false)
     else if (ep == 2) BD_C8_LAUNCH(2, OUT_BF16X2, false)
@@ -1754,39 +1589,11 @@ int launch_f16c8(const bd_gemm_args& a, hipStream_t s) {
 
 extern "C" int bd_gemm_fuses_qk_rmsnorm(const bd_gemm_args* args, int prec) {
     if (!args || !rms_geometry_ok(*args)) return 0;
-#ifdef BD_EXP_NO_RMS_FUSE      // A/B build only (tools/_probe): the separate bd_qk_rmsnorm kernel runs instead
-    return 0;
-#endif
     switch (prec) {
         case BD_PREC_BF16: case BD_PREC_F16: return pc192_possible(*args, 1, 2) ? 1 : 0;
-        case BD_PREC_BF16X3: return pc192_possible(*args, 2, 2) ? 1 : 0;
+        case BD_PREC_BF16X3: case BD_PREC_F16X3: return pc192_possible(*args, 2, 2) ? 1 : 0;
         case BD_PREC_FP8: return pc192_possible(*args, 1, 1) ? 1 : 0;
         case BD_PREC_F16C8: return wide_epilogue_ok(*args, 2) ? 1 : 0;
-        default: return 0;
-    }
-}
-
-// BD_LN_FUSE (compile-time policy, default 0): 1 lets the whole-path entry points run LayerNorm inside the residual GEMMs.  The fused
-// form is correct (bit-identical, tests/test_gpu_ops.py) but measured SLOWER than the separate kernel on MI355X in every hand-off
-// variant (profiles/r3_layernorm_fusion.md): the panel's last workgroup spends 40-60 us of MFMA-dead time per panel.  bd_gemm itself
-// still honours ln_out for callers that ask for it explicitly (bd_gemm_fuses_layernorm_supported).
-#ifndef BD_LN_FUSE
-#define BD_LN_FUSE 0
-#endif
-static int ln_fusion_supported(const bd_gemm_args* args, int prec);
-extern "C" int bd_gemm_fuses_layernorm(const bd_gemm_args* args, int prec) {
-    return BD_LN_FUSE ? ln_fusion_supported(args, prec) : 0;
-}
-extern "C" int bd_gemm_fuses_layernorm_supported(const bd_gemm_args* args, int prec) { return ln_fusion_supported(args, prec); }
-static int ln_fusion_supported(const bd_gemm_args* args, int prec) {
-    if (!args) return 0;
-    const int cus = cu_count();
-    switch (prec) {
-        case BD_PREC_BF16: return fuses_ln<__bf16, 1>(*args, cus) ? 1 : 0;
-        case BD_PREC_F16: return fuses_ln<_Float16, 1>(*args, cus) ? 1 : 0;
-        case BD_PREC_BF16X3: return fuses_ln<__bf16, 2>(*args, cus) ? 1 : 0;
-        case BD_PREC_FP8: return fuses_ln<fp8e4, 1>(*args, cus) ? 1 : 0;
-        case BD_PREC_F16C8: return (ln_geometry_ok(*args) && f16c8_ep3_ok(*args) && (args->K % 32) == 0 && (args->lda % 32) == 0 && (args->ldw % 32) == 0) ? 1 : 0;
         default: return 0;
     }
 }
@@ -1798,10 +1605,10 @@ extern "C" int bd_gemm(const bd_gemm_args* args, int prec, void* stream) {
     const int esz = prec == BD_PREC_FP8 ? 1 : 2;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % kmult) != 0) return BD_ERR_SHAPE;
     if (((a.lda * esz) % 16) || ((a.ldw * esz) % 16) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15)) return BD_ERR_ALIGN;
-    if ((prec == BD_PREC_BF16X3 || prec == BD_PREC_F16C8) && ((a.a_plane % 8) || (a.w_plane % 8))) return BD_ERR_ALIGN;
+    if ((prec == BD_PREC_BF16X3 || prec == BD_PREC_F16X3 || prec == BD_PREC_F16C8) && ((a.a_plane % 8) || (a.w_plane % 8))) return BD_ERR_ALIGN;
     if (a.addtab && a.tab_rows <= 0) return BD_ERR_SHAPE;
-    if (a.out_f32 < 0 || a.out_f32 > 4) return BD_ERR_DTYPE;
-    if (a.out_f32 == 4 && (a.out_plane % 8)) return BD_ERR_ALIGN;
+    if (a.out_f32 < 0 || a.out_f32 > 5) return BD_ERR_DTYPE;
+    if (a.out_f32 >= 4 && (a.out_plane % 8)) return BD_ERR_ALIGN;
     // the single-plane 16-bit outputs and every fp8-mode output exist only in the wide (16-byte) epilogue
     const bool needs_wide = a.out_f32 >= 2 || (prec == BD_PREC_FP8 && a.out_f32 == 0);
     if (needs_wide && ((a.N % 8) || (a.ldo % 8) || ((uintptr_t)a.out & 15))) return BD_ERR_ALIGN;
@@ -1811,6 +1618,7 @@ extern "C" int bd_gemm(const bd_gemm_args* args, int prec, void* stream) {
         case BD_PREC_BF16: return launch<__bf16, 1, 64>(a, s);
         case BD_PREC_F16: return launch<_Float16, 1, 64>(a, s);
         case BD_PREC_BF16X3: return launch<__bf16, 2, 32>(a, s);
+        case BD_PREC_F16X3: return launch<_Float16, 2, 32>(a, s);
         case BD_PREC_FP8: return launch<fp8e4, 1, 128>(a, s);
         case BD_PREC_F16C8: return launch_f16c8(a, s);
         default: return BD_ERR_DTYPE;

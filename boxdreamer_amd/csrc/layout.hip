@@ -300,6 +300,7 @@ inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
         case BD_PREC_BF16: hipLaunchKernelGGL((FN<__bf16, 1>), __VA_ARGS__); break;    \
         case BD_PREC_F16: hipLaunchKernelGGL((FN<_Float16, 1>), __VA_ARGS__); break;   \
         case BD_PREC_BF16X3: hipLaunchKernelGGL((FN<__bf16, 2>), __VA_ARGS__); break;  \
+        case BD_PREC_F16X3: hipLaunchKernelGGL((FN<_Float16, 2>), __VA_ARGS__); break; \
         case BD_PREC_FP8: hipLaunchKernelGGL((FN<fp8e4, 1>), __VA_ARGS__); break;      \
         case BD_PREC_F16C8: hipLaunchKernelGGL((FN<f16c8, 2>), __VA_ARGS__); break;    \
         default: return BD_ERR_DTYPE;                                                  \

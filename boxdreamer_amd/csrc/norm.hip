@@ -166,6 +166,7 @@ extern "C" int bd_layernorm(const float* x, int64_t ldx, const float* gamma, con
         case BD_PREC_BF16: return launch_ln<__bf16, 1>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
         case BD_PREC_F16: return launch_ln<_Float16, 1>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
         case BD_PREC_BF16X3: return launch_ln<__bf16, 2>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
+        case BD_PREC_F16X3: return launch_ln<_Float16, 2>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
         case BD_PREC_FP8: return launch_ln<fp8e4, 1>(x, ldx, gamma, beta, eps, out16, out16_plane, out32, ldo, rows, cols, rpg_in, rpg_out, row_off, s);
         case BD_PREC_F16C8:
             if (out16 && cols % 32) return BD_ERR_SHAPE;      // the lo8 plane is laid out in 32-element blocks
@@ -183,6 +184,7 @@ extern "C" int bd_qk_rmsnorm(void* qkv, int64_t plane, const float* wq, const fl
         case BD_PREC_BF16: return launch_rms<__bf16, 1>(qkv, plane, wq, wk, eps, rows, heads, head_dim, s);
         case BD_PREC_F16: return launch_rms<_Float16, 1>(qkv, plane, wq, wk, eps, rows, heads, head_dim, s);
         case BD_PREC_BF16X3: return launch_rms<__bf16, 2>(qkv, plane, wq, wk, eps, rows, heads, head_dim, s);
+        case BD_PREC_F16X3: return launch_rms<_Float16, 2>(qkv, plane, wq, wk, eps, rows, heads, head_dim, s);
         default: return BD_ERR_DTYPE;
     }
 }

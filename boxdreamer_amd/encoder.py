@@ -43,12 +43,18 @@ class DinoV2Encoder:
     """DINOv2 ViT-*/14 + 4 registers, inference only, on the HIP library."""
 
     def __init__(self, state_dict: dict, heads: int, patch: int = 14, prec=_lib.DEFAULT_PREC):
-        self.sd = {k: v.detach().float() for k, v in state_dict.items()}
+        # own copies: synth's seeded state dicts are cached per process and `.float()` of an fp32 tensor shares its storage
+        self.sd = {k: v.detach().float().clone() for k, v in state_dict.items()}
         self.heads, self.patch, self.prec = heads, patch, prec
         self.device = torch.device("cpu")
         self._packed = {}       # (device, operand class, img_size) -> pack.Packed
         self._ws = None
         self._frozen_by = weakref.WeakSet()  # live GraphedPaths that captured raw pointers into _packed / _ws (graph.py)
+        depth = 1 + max(int(k.split(".")[1]) for k in self.sd if k.startswith("blocks."))
+        # per-Linear promotion of the F16C8 family to split-bf16 (include/boxdreamer_hip.h: BD_PROMOTE_*), set by calibrate.py
+        self.promote = [0] * depth
+        self.promote_misc = 0
+        self.feats_prec = 0          # 0: feats16 in the class of `prec`; PREC_F16X3 when the decoder's adapter fc1 is promoted
 
     def _check_not_frozen(self, what: str):
         if len(self._frozen_by):
@@ -78,7 +84,18 @@ class DinoV2Encoder:
         key = (str(self.device), _lib.operand_prec(prec), size)
         if key not in self._packed:
             self._packed[key] = pack.pack_dino(self.sd, _lib.operand_prec(prec), self.device, self.heads, self.patch, size)
-        return self._packed[key]
+        pk = self._packed[key]
+        if _lib.operand_prec(prec) == _lib.PREC_F16C8:
+            want = (tuple(m | _lib.PROMOTE_FC2 if m & _lib.PROMOTE_FC1 else m for m in self.promote), self.promote_misc, self.feats_prec)
+            if pk.promote != want:
+                self._check_not_frozen("changing the per-Linear promotion")
+                pk.set_promote(self.promote, self.promote_misc, self.feats_prec)
+        return pk
+
+    def feats_class(self, prec=None) -> int:
+        """Operand class of the 16-bit feature copy `patch_tokens` hands to the decoder."""
+        cls = _lib.operand_prec(self.prec if prec is None else prec)
+        return self.feats_prec if (cls == _lib.PREC_F16C8 and self.feats_prec) else cls
 
     @torch.no_grad()
     def patch_tokens(self, images: torch.Tensor, prec=None):
@@ -97,8 +114,9 @@ class DinoV2Encoder:
         P, D = w.grid * w.grid, w.dim
         ws = self._workspace(lib.bd_encoder_workspace_bytes(w, n, _lib.prec_id(prec)), images.device)
         feats32 = torch.empty((n, P, D), dtype=torch.float32, device=images.device)
-        np_ = _lib.planes(prec)
-        feats16 = torch.empty((np_, n * P, D) if np_ == 2 else (n * P, D), dtype=_lib.op_dtype(prec),
+        fcls = self.feats_class(prec)
+        np_ = _lib.planes(fcls)
+        feats16 = torch.empty((np_, n * P, D) if np_ == 2 else (n * P, D), dtype=_lib.op_dtype(fcls),
                               device=images.device)
         _lib.check(lib.bd_encoder_forward(w, _lib.ptr(images), _lib.dtype_id(images), n, size, _lib.ptr(feats32),
                                           _lib.ptr(feats16), n * P * D if np_ == 2 else 0, _lib.ptr(ws),
@@ -171,4 +189,4 @@ class DinoV2Wrapper(PretrainedModelWrapper):
         with torch.no_grad():
             feats32, feats16 = self.model.patch_tokens(input_tensor, self.prec)
             ret = feats32.view(B, T, *feats32.shape[1:]) if flag else feats32
-            return features.attach(ret, feats16, _lib.operand_prec(self.prec))   # explicit hand-off to BETR (features.py)
+            return features.attach(ret, feats16, self.model.feats_class(self.prec))   # explicit hand-off to BETR (features.py)

@@ -89,6 +89,8 @@ def to_operand(x: torch.Tensor, prec) -> torch.Tensor:
         return f16c8_encode(x, 0, False)
     if prec_id(prec) == _lib.PREC_FP8:
         return x.float().clamp(-448.0, 448.0).to(dt).contiguous()
+    if dt == torch.float16:
+        x = x.float().clamp(-65504.0, 65504.0)             # the kernels' f16 conversions saturate (bd_common.h: RANGE)
     hi = x.to(dt)
     if planes(prec) == 1:
         return hi.contiguous()
@@ -105,18 +107,8 @@ def from_operand(t: torch.Tensor, prec) -> torch.Tensor:
 _OUT_DTYPES = {2: torch.float16, 3: torch.bfloat16}      # 4: split-bf16 planes [2, rows, N]
 
 
-def gemm_fuses_layernorm(M, N, K, prec) -> bool:
-    """Can a residual Linear of this shape run its LayerNorm inside the launch (persistent kernel)?  (Capability, not the policy
-    of the whole-path entry points: that is bd_gemm_fuses_layernorm, 0 in the default build.)"""
-    lib = _lib.load()
-    g = _lib.GemmArgs()
-    g.M, g.N, g.K, g.lda, g.ldw, g.ldo, g.ldr, g.out_f32 = M, N, K, K, K, N, N, 1
-    g.A = g.W = g.out = g.resid = g.ln_out = g.ln_sync = 256          # aligned dummies: only geometry is looked at
-    return bool(lib.bd_gemm_fuses_layernorm_supported(C.byref(g), prec_id(prec)))
-
-
 def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, addtab=None, out=None,
-         out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0), wscale=None, out_mode=None, w_qexp=0, rms=None, ln=None):
+         out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0), wscale=None, out_mode=None, w_qexp=0, rms=None):
     """out[map(r)] = act(wscale * (A W^T) + bias) + addtab[r % rows(addtab)] + resid[map(r)].
     out_mode: None -> operand dtype (or fp32 with out_f32), 2 -> f16 single plane, 3 -> bf16 single plane."""
     lib = _lib.load()
@@ -152,9 +144,6 @@ def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, add
         g.rms_parts = int(rms[3]) if len(rms) > 3 else 0
     g.M, g.N, g.K, g.act = M, N, K, act
     g.rpg_in, g.rpg_out, g.row_off = rpg
-    if ln is not None:                       # (gamma | None, beta | None, eps, ln_out operand tensor, int32 panel counters): fused LayerNorm
-        g.ln_gamma, g.ln_beta, g.ln_eps = ptr(ln[0]), ptr(ln[1]), float(ln[2])
-        g.ln_out, g.ln_out_plane, g.ln_sync = ptr(ln[3]), _plane(ln[3], prec), ptr(ln[4])
     check(lib.bd_gemm(C.byref(g), prec_id(prec), stream()), "bd_gemm")
     return out
 

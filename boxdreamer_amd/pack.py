@@ -32,6 +32,8 @@ def split_planes(w: torch.Tensor, prec) -> torch.Tensor:
     dt = _lib.op_dtype(prec)
     if _lib.prec_id(prec) == _lib.PREC_FP8:
         return w.clamp(-E4M3_MAX, E4M3_MAX).to(dt).contiguous()
+    if dt == torch.float16:
+        w = w.clamp(-65504.0, 65504.0)
     hi = w.to(dt)
     if _lib.planes(prec) == 1:
         return hi.contiguous()
@@ -113,12 +115,22 @@ def dino_pos_tables(pos_embed: torch.Tensor, cls_token: torch.Tensor, register_t
 
 
 class Packed:
-    """Owns the device tensors behind a ctypes weight struct (keeps them alive)."""
+    """Owns the device tensors behind a ctypes weight struct (keeps them alive).
 
-    def __init__(self):
+    Linears are packed per operand CLASS on demand and cached (`linear_of`), so that the per-Linear promotion of the F16C8 family
+    (include/boxdreamer_hip.h: BD_PROMOTE_*; boxdreamer_amd/calibrate.py) only swaps pointers in the struct (`set_promote`)."""
+
+    def __init__(self, base_prec=None, device=None):
         self.tensors = []
         self.struct = None
         self.blocks = None
+        self.base = None if base_prec is None else _lib.prec_id(base_prec)
+        self.device = device
+        self._src = {}        # linear name -> (weight, bias, row_scale, kpad)
+        self._cache = {}      # (linear name, operand class) -> _lib.Linear
+        self.block_names = [] # per block: prefix of its four Linears' names
+        self.promote = None   # (per-block masks, misc mask, feats_prec) currently written into the struct
+        self.named = {}       # introspection (tests): "pos_table" / (linear name, class) -> the device tensor behind the pointer
 
     def keep(self, t: torch.Tensor, device) -> C.c_void_p:
         t = t.to(device).contiguous()
@@ -135,6 +147,54 @@ class Packed:
         ws = self.keep(scale, device) if scale is not None else C.c_void_p(0)
         return _lib.Linear(self.keep(w, device), self.keep(b, device), ws, qexp)
 
+    def register(self, name: str, weight, bias, row_scale=None, kpad=None) -> None:
+        self._src[name] = (weight, bias, row_scale, kpad)
+
+    def linear_of(self, name: str, cls=None) -> _lib.Linear:
+        """The Linear `name` packed in operand class `cls` (default: the base class); packed once per class."""
+        cls = self.base if cls is None else _lib.prec_id(cls)
+        key = (name, cls)
+        if key not in self._cache:
+            w, b, rs, kpad = self._src[name]
+            self._cache[key] = self.linear(pack_linear_weight(w, cls, kpad=kpad, row_scale=rs, return_scale=True), pack_bias(b, rs),
+                                           self.device)
+            self.named[key] = next(t for t in self.tensors[::-1] if t.dim() >= 2)        # the packed weight just kept
+        return self._cache[key]
+
+    def set_promote(self, masks=None, misc: int = 0, feats_prec: int = 0) -> None:
+        """Write the per-Linear operand classes into the struct: bit set -> that Linear's weight in split-bf16 planes."""
+        depth = len(self.block_names)
+        masks = [0] * depth if masks is None else [int(m) for m in masks]
+        if len(masks) != depth:
+            raise ValueError(f"{len(masks)} promotion masks for {depth} blocks")
+        masks = [m | _lib.PROMOTE_FC2 if m & _lib.PROMOTE_FC1 else m for m in masks]
+        if misc & _lib.PROMOTE_ADAPTER_FC1 and "adapter_fc1" in self._src:
+            misc |= _lib.PROMOTE_ADAPTER_FC2
+        state = (tuple(masks), int(misc), int(feats_prec))
+        if state == self.promote:
+            return
+        if (any(masks) or misc or feats_prec) and self.base != _lib.PREC_F16C8:
+            raise ValueError("per-Linear promotion exists for the F16C8 family only")
+        x3 = _lib.PREC_F16X3
+        for i, (bw, pre) in enumerate(zip(self.blocks, self.block_names)):
+            m = masks[i]
+            bw.qkv = self.linear_of(pre + "qkv", x3 if m & _lib.PROMOTE_QKV else None)
+            bw.proj = self.linear_of(pre + "proj", x3 if m & _lib.PROMOTE_PROJ else None)
+            bw.fc1 = self.linear_of(pre + "fc1", x3 if m & _lib.PROMOTE_FC1 else None)
+            bw.fc2 = self.linear_of(pre + "fc2", x3 if m & _lib.PROMOTE_FC2 else None)
+            bw.promote = m
+        w = self.struct
+        if "patch_embed" in self._src:
+            w.patch_embed = self.linear_of("patch_embed", x3 if misc & _lib.PROMOTE_PATCH_EMBED else None)
+            w.feats_prec = int(feats_prec)
+        else:
+            w.adapter_fc1 = self.linear_of("adapter_fc1", x3 if misc & _lib.PROMOTE_ADAPTER_FC1 else None)
+            w.adapter_fc2 = self.linear_of("adapter_fc2", x3 if misc & _lib.PROMOTE_ADAPTER_FC2 else None)
+            w.bbox_emb = self.linear_of("bbox_emb", x3 if misc & _lib.PROMOTE_BBOX_EMB else None)
+            w.bbox_proj = self.linear_of("bbox_proj", x3 if misc & _lib.PROMOTE_BBOX_PROJ else None)
+        w.promote_misc = int(misc)
+        self.promote = state
+
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.tensors)
 
@@ -147,12 +207,11 @@ def _pack_block(pk: Packed, sd: dict, p: str, prec, device, ls: bool, qk_norm: b
     bw.ln1_b = pk.keep(sd[p + "norm1.bias"].float(), device)
     bw.ln2_w = pk.keep(sd[p + "norm2.weight"].float(), device)
     bw.ln2_b = pk.keep(sd[p + "norm2.bias"].float(), device)
-    bw.qkv = pk.linear(pack_linear_weight(sd[p + "attn.qkv.weight"], prec, return_scale=True), pack_bias(sd[p + "attn.qkv.bias"]), device)
-    bw.proj = pk.linear(pack_linear_weight(sd[p + "attn.proj.weight"], prec, row_scale=g1, return_scale=True),
-                        pack_bias(sd[p + "attn.proj.bias"], g1), device)
-    bw.fc1 = pk.linear(pack_linear_weight(sd[p + "mlp.fc1.weight"], prec, return_scale=True), pack_bias(sd[p + "mlp.fc1.bias"]), device)
-    bw.fc2 = pk.linear(pack_linear_weight(sd[p + "mlp.fc2.weight"], prec, row_scale=g2, return_scale=True),
-                       pack_bias(sd[p + "mlp.fc2.bias"], g2), device)
+    pk.register(p + "qkv", sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
+    pk.register(p + "proj", sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], g1)
+    pk.register(p + "fc1", sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
+    pk.register(p + "fc2", sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], g2)
+    pk.block_names.append(p)
     if qk_norm:
         bw.q_norm_w = pk.keep(sd[p + "attn.q_norm.weight"].float(), device)
         bw.k_norm_w = pk.keep(sd[p + "attn.k_norm.weight"].float(), device)
@@ -163,7 +222,7 @@ def _pack_block(pk: Packed, sd: dict, p: str, prec, device, ls: bool, qk_norm: b
 
 def pack_dino(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int = 224) -> Packed:
     """DINOv2 ViT state_dict (hub key names) -> bd_dino_weights."""
-    pk = Packed()
+    pk = Packed(prec, device)
     dim = sd["cls_token"].shape[-1]
     depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
     grid = img_size // patch
@@ -177,20 +236,20 @@ def pack_dino(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int
     w.depth, w.dim, w.heads, w.n_prefix = depth, dim, heads, prefix.shape[0]
     w.grid, w.patch, w.kpad = grid, patch, kpad
     w.ln_eps = 1e-6                                              # vision_transformer.py:95
-    w.patch_embed = pk.linear(pack_linear_weight(sd["patch_embed.proj.weight"], prec, kpad=kpad, return_scale=True),
-                              pack_bias(sd["patch_embed.proj.bias"]), device)
+    pk.register("patch_embed", sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], None, kpad)
     w.pos_patch = pk.keep(pos_patch, device)
     w.prefix_tokens = pk.keep(prefix, device)
     w.norm_w = pk.keep(sd["norm.weight"].float(), device)
     w.norm_b = pk.keep(sd["norm.bias"].float(), device)
     w.blocks = C.cast(blocks, C.POINTER(_lib.BlockWeights))
     pk.struct, pk.blocks = w, blocks
+    pk.set_promote()
     return pk
 
 
 def pack_betr(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int = 224, box_dim: int = 8) -> Packed:
     """BETR state_dict (reference key names, no 'decoder.' prefix) -> bd_betr_weights."""
-    pk = Packed()
+    pk = Packed(prec, device)
     dim = sd["bbox_learnable_query"].shape[-1]
     depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("attn."))
     grid = img_size // patch
@@ -203,14 +262,14 @@ def pack_betr(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int
     w.ln_eps = 1e-5              # get_layernorm ignores its eps argument: blocks.py:805
     w.adapter_ln_eps = 1e-6      # betr.py:161
     w.rms_eps = 1e-6             # blocks.py:45
-    w.adapter_fc1 = pk.linear(pack_linear_weight(sd["input_transform.fc1.weight"], prec, return_scale=True),
-                              pack_bias(sd["input_transform.fc1.bias"]), device)
-    w.adapter_fc2 = pk.linear(pack_linear_weight(sd["input_transform.fc2.weight"], prec, return_scale=True),
-                              pack_bias(sd["input_transform.fc2.bias"]), device)
-    w.bbox_emb = pk.linear(pack_linear_weight(sd["bbox_emb.weight"], prec, kpad=kpad, return_scale=True), pack_bias(sd["bbox_emb.bias"]), device)
-    w.bbox_proj = pk.linear(pack_linear_weight(sd["bbox_proj.weight"], prec, return_scale=True), pack_bias(sd["bbox_proj.bias"]), device)
+    pk.register("adapter_fc1", sd["input_transform.fc1.weight"], sd["input_transform.fc1.bias"])
+    pk.register("adapter_fc2", sd["input_transform.fc2.weight"], sd["input_transform.fc2.bias"])
+    pk.register("bbox_emb", sd["bbox_emb.weight"], sd["bbox_emb.bias"], None, kpad)
+    pk.register("bbox_proj", sd["bbox_proj.weight"], sd["bbox_proj.bias"])
     w.pos_table = pk.keep(sincos_table(dim, grid), device)
+    pk.named["pos_table"] = pk.tensors[-1]
     w.query_token = pk.keep(sd["bbox_learnable_query"].float().reshape(-1), device)
     w.blocks = C.cast(blocks, C.POINTER(_lib.BlockWeights))
     pk.struct, pk.blocks = w, blocks
+    pk.set_promote()
     return pk

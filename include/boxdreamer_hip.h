@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define BD_ABI_VERSION 4
+#define BD_ABI_VERSION 5
 
 #define BD_DTYPE_BF16 0
 #define BD_DTYPE_F16 1
@@ -89,6 +89,22 @@ extern "C" {
  *                            right away and consumed through a softmax -- cost 2e-5.  1.33 pass-equivalents for that Linear
  *                            instead of 1 (QKV16) or 2 (F16C8), logits error 1.9e-4 instead of 5.9e-4.  Needs bd_block_weights.qkv16. */
 #define BD_PREC_F16C8_QK16 13
+/* Split-f16 (round 4): hi = f16(x), lo = f16(x - hi), three f16 MFMA passes (hi*hi + hi*lo + lo*hi) like BD_PREC_BF16X3 but with
+ * 11 + 11 mantissa bits instead of 8 + 8: products are fp32-faithful (~2^-22) for |x| up to f16's 65504 (conversions saturate), and
+ * lose only absolute 6e-8 steps where a lo falls into f16's subnormals.  Measured / simulated 4x closer to the fp32 forward than
+ * split-bf16 on trained-like outlier weights at the same cost (oracle/numerics_sim.py): it is the class the per-Linear PROMOTION
+ * of the F16C8 family moves a Linear to (bd_block_weights.promote), and a whole-path mode of its own:
+ *   BD_PREC_F16X3            Linears split-f16; attention as BD_PREC_BF16X3 (one f16 pass where q, k are RMS-normalised, split-bf16
+ *                            elsewhere: probabilities and unnormalised q.k^T need bf16's range);
+ *   BD_PREC_F16X3_ATTN_X3    whole-path only: split-bf16 attention everywhere -- the most precise GPU mode, the reference of the
+ *                            load-time self-check.
+ * Storage: two f16 planes (hi, then lo at +plane elements), exactly as BD_PREC_BF16X3.  Accepted by bd_gemm, bd_layernorm,
+ * bd_im2col_images, bd_patchify_heatmaps, bd_gather_query_tokens and the whole-path entry points; attention EMITS the class through
+ * BD_PREC_F16_OUT_F16X3 / BD_PREC_BF16X3_OUT_F16X3. */
+#define BD_PREC_F16X3 14
+#define BD_PREC_F16X3_ATTN_X3 15
+#define BD_PREC_F16_OUT_F16X3 16    /* bd_attention[_q] only: f16 qkv (one plane) in, one f16 MFMA pass, split-f16 (hi, lo) planes out */
+#define BD_PREC_BF16X3_OUT_F16X3 17 /* bd_attention[_q] only: split-bf16 qkv planes in, split-bf16 attention, split-f16 planes out */
 #define BD_PREC_F16_OUT_F16C8 9     /* bd_attention[_q] only: f16 qkv (one plane) in, one f16 MFMA pass, F16C8 operand out */
 #define BD_PREC_BF16X3_OUT_F16C8 10 /* bd_attention[_q] only: split-bf16 qkv planes in, split-bf16 attention, F16C8 operand out */
 
@@ -127,7 +143,8 @@ typedef struct bd_gemm_args {
     const float* addtab; int tab_rows;             /* fp32 [tab_rows, N] or NULL */
     void* out; int64_t ldo; int64_t out_plane;     /* 16-bit (operand dtype of `prec`) or fp32 */
     int out_f32;                                   /* 0: operand-dtype output (planes per `prec`), 1: fp32, 2: f16 single plane,
-                                                      3: bf16 single plane, 4: split-bf16 (hi, lo) planes at out_plane */
+                                                      3: bf16 single plane, 4: split-bf16 (hi, lo) planes at out_plane,
+                                                      5: split-f16 (hi, lo) planes at out_plane */
     int M, N, K;
     int act;
     int rpg_in, rpg_out, row_off;
@@ -139,26 +156,10 @@ typedef struct bd_gemm_args {
     const float* rms_wq; const float* rms_wk; float rms_eps;
     int rms_parts;                                 /* with rms_wq: 0 or 3 = output columns are [q | k | v] (v untouched); 2 = [q | k] only
                                                       (a QKV Linear split into a q,k launch and a v launch, BD_PREC_F16C8_QK16) */
-    /* Fused LayerNorm of the RESULT rows (round 3): for a Linear whose fp32 output is the residual stream (out_f32 == 1, identity row
-     * map, N == the full row, ldo == N), the launch also writes ln_out = LayerNorm(out row; ln_gamma, ln_beta, ln_eps) in the operand
-     * class `prec` (planes ln_out_plane apart) -- the next Linear's A operand -- so that no separate bd_layernorm pass re-reads the
-     * stream from HBM.  The workgroup that completes a 256-row panel (its N / 192 column tiles arrive on ln_sync[panel], int32
-     * counters the caller zeroes once; the kernel leaves them zero) normalises the panel's rows out of the L2; same arithmetic, same
-     * bits as bd_layernorm.  Only where the launch takes the persistent 256 x 192 kernel: ask bd_gemm_fuses_layernorm first
-     * (bd_gemm returns BD_ERR_SHAPE otherwise).  ln_gamma / ln_beta may be NULL (no affine). */
-    const float* ln_gamma; const float* ln_beta; float ln_eps;
-    void* ln_out; int64_t ln_out_plane;
-    int* ln_sync;
 } bd_gemm_args;
 int bd_gemm(const bd_gemm_args* args /*[host]*/, int prec, void* stream);
 /* 1 if bd_gemm(args, prec) with args->rms_wq set would fuse the q/k RMSNorm (tile shape and head geometry fit), else 0. */
 int bd_gemm_fuses_qk_rmsnorm(const bd_gemm_args* args /*[host]*/, int prec);
-/* bd_gemm_fuses_layernorm_supported: 1 if bd_gemm(args, prec) with args->ln_out set can run the fused LayerNorm (persistent kernel,
- * geometry fits), else 0; ln_sync must hold (M + 255) / 256 int32 counters.  bd_gemm_fuses_layernorm: the POLICY the whole-path
- * entry points follow -- the same answer in a build with -DBD_LN_FUSE=1, 0 in the default build: the fused form is bit-identical
- * but measured slower than the separate kernel on MI355X (profiles/r3_layernorm_fusion.md). */
-int bd_gemm_fuses_layernorm(const bd_gemm_args* args /*[host]*/, int prec);
-int bd_gemm_fuses_layernorm_supported(const bd_gemm_args* args /*[host]*/, int prec);
 
 /* LayerNorm over the last dim (fp32 statistics), optional affine, fp32 input rows gathered by
  * in_row(r) = r if rpg_in == 0 else (r / rpg_in) * rpg_out + r % rpg_in + row_off.
@@ -266,11 +267,31 @@ typedef struct bd_linear {
     int w_qexp;          /* BD_PREC_F16C8: exponent E of the weight's e4m3 planes (q8 = e4m3(w * 2^E)) */
 } bd_linear;
 
+/* Per-Linear PROMOTION of the F16C8 family (round 4).  The F16C8 operand class keeps ~15 significant bits of every product; on
+ * checkpoints with massive-activation channels / LayerNorm gain outliers a few Linears (found at load time by measurement,
+ * boxdreamer_amd/calibrate.py) need the ~22 bits of the split-f16 class (BD_PREC_F16X3) to keep the heatmap logits inside 1e-3.  A set bit means:
+ * THIS Linear's weight (`bd_linear.w`) is packed as BD_PREC_F16X3 planes and the whole-path entry points run it as a split-f16
+ * product; the producer of its A operand (LayerNorm, attention, the fc1 epilogue) emits split-f16 planes instead of the F16C8
+ * operand.  Honoured only when `prec` is BD_PREC_F16C8 / _QKV16 / _QK16 (ignored otherwise).  With every bit set the path is
+ * bit-identical to BD_PREC_F16X3_ATTN_X3. */
+#define BD_PROMOTE_QKV 1
+#define BD_PROMOTE_PROJ 2
+#define BD_PROMOTE_FC1 4   /* implies BD_PROMOTE_FC2 (a split-f16 fc1 cannot emit the F16C8 operand) */
+#define BD_PROMOTE_FC2 8
+#define BD_PROMOTE_ATTN 16 /* blocks with q / k RMSNorm only: split-bf16 attention instead of the one-pass f16 attention */
+/* bd_betr_weights.promote_misc / bd_dino_weights.promote_misc */
+#define BD_PROMOTE_ADAPTER_FC1 1 /* BETR: feats16 must then be BD_PREC_F16X3 planes (bd_dino_weights.feats_prec); implies _FC2 */
+#define BD_PROMOTE_ADAPTER_FC2 2
+#define BD_PROMOTE_BBOX_EMB 4
+#define BD_PROMOTE_BBOX_PROJ 8
+#define BD_PROMOTE_PATCH_EMBED 1 /* DINOv2 */
+
 typedef struct bd_block_weights {
     const float* ln1_w; const float* ln1_b; const float* ln2_w; const float* ln2_b;
     bd_linear qkv, proj, fc1, fc2;   /* DINO: LayerScale gamma pre-folded into proj / fc2 */
     const float* q_norm_w; const float* k_norm_w;   /* [head_dim]; NULL for DINOv2 */
     bd_linear qkv16;                                /* f16 single-plane copy of qkv (BD_PREC_BF16X3_QKV16) or {NULL} */
+    int promote;                                    /* BD_PROMOTE_* bits (F16C8 family only) */
 } bd_block_weights;
 
 typedef struct bd_dino_weights {
@@ -281,6 +302,9 @@ typedef struct bd_dino_weights {
     const float* prefix_tokens;      /* fp32 [n_prefix, dim]: cls+pos[0], registers */
     const float* norm_w; const float* norm_b;
     const bd_block_weights* blocks;  /* [host] array of `depth` */
+    int promote_misc;                /* BD_PROMOTE_PATCH_EMBED (F16C8 family only) */
+    int feats_prec;                  /* operand class of feats16: 0 = the class of `prec`; BD_PREC_F16X3 (F16C8 family only) when the
+                                        consumer's first Linear is promoted (BD_PROMOTE_ADAPTER_FC1) */
 } bd_dino_weights;
 
 typedef struct bd_betr_weights {
@@ -290,6 +314,7 @@ typedef struct bd_betr_weights {
     const float* pos_table;          /* fp32 [grid*grid, dim] 2-D sincos */
     const float* query_token;        /* fp32 [dim] */
     const bd_block_weights* blocks;  /* [host] */
+    int promote_misc;                /* BD_PROMOTE_ADAPTER_FC1 | _ADAPTER_FC2 | _BBOX_EMB | _BBOX_PROJ (F16C8 family only) */
 } bd_betr_weights;
 
 /* DinoV2Wrapper.predict (encoder/dinov2.py:45-60): images [n_images, 3, size, size] in [0,1]

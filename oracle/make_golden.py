@@ -190,6 +190,9 @@ def robustness_cases():
     # trained-like outliers at half gain: logits rms 1.9 / max 9.5; the reference's and the oracle's fp32 forwards differ by their own
     # re-association noise there, so the restatement is pinned at 5e-4 instead of 2e-5
     run_case("outliers_g0.5_T2", 1, 2, 12, 12, 11, False, weights="outliers_g0.5", tol=5e-4)
+    # round 4: the same grafts at a quarter and at three quarters of the gain
+    run_case("outliers_g0.25_T2", 1, 2, 12, 12, 11, False, weights="outliers_g0.25", tol=5e-4)
+    run_case("outliers_g0.75_T2", 1, 2, 12, 12, 11, False, weights="outliers_g0.75", tol=1e-3)
 
 
 def main():

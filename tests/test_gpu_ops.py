@@ -253,58 +253,6 @@ def test_gemm_fused_qk_rmsnorm(hip, prec, out_mode, M):
     assert err < 2 * eps * max(1.0, ref.abs().max().item()) + 1e-4, (prec, out_mode, err)
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp16", "bf16x3", "f16c8", "fp8"])
-@pytest.mark.parametrize("M,K", [(49152, 768), (50112, 3072), (12000, 768)])
-def test_gemm_fused_layernorm_matches_separate_kernel(hip, prec, M, K):
-    """Round 3: the residual Linears (proj, fc2: x += A W^T + b, fp32, in place) run the LayerNorm of their result rows inside the
-    launch -- the workgroup that completes a 256-row panel normalises it (bd_gemm_args.ln_*) -- instead of a separate bd_layernorm
-    pass over the stream.  Same arithmetic per row, so BIT-identical to: the same GEMM without the fusion, then bd_layernorm.
-    Ragged last panel (50112 = 195.75 tiles), a size whose last CU round is ragged, counters left at zero, two launches back to
-    back on the same counters."""
-    from boxdreamer_amd import _lib
-    N = 768
-    if not hip_ops.gemm_fuses_layernorm(M, N, K, prec):
-        pytest.skip("this shape does not take the persistent kernel on this device")
-    a, w, b = _rand("a", (M, K)), _rand("w", (N, K), 0.03), _rand("b", (N,), 0.1)
-    gam, bet = (_rand("g", (N,), 0.1) + 1).cuda(), _rand("be", (N,), 0.1).cuda()
-    x0 = _rand("x", (M, N)).cuda()
-    e = hip_ops.f16c8_qexp(w) if prec == "f16c8" else 0
-    a16 = hip_ops.to_operand(a.cuda(), prec)
-    w16 = hip_ops.f16c8_encode(w.cuda(), e, True) if prec == "f16c8" else hip_ops.to_operand(w.cuda(), prec)
-    ws = (torch.rand(N, generator=torch.Generator().manual_seed(5)) + 0.5).cuda() if prec == "fp8" else None
-    # reference: unfused launch + the stand-alone kernel
-    x_ref = x0.clone()
-    hip_ops.gemm(a16, w16, b.cuda(), prec=prec, resid=x_ref, out=x_ref, out_f32=True, w_qexp=e, wscale=ws)
-    xn_ref, _ = hip_ops.layernorm(x_ref, gam, bet, 1e-5, prec=prec)
-    sync = torch.zeros((M + 255) // 256, dtype=torch.int32, device="cuda")
-    for rep in range(2):
-        x = x0.clone()
-        xn = torch.full_like(xn_ref.view(torch.uint8), 0x5A).view(xn_ref.dtype)       # poison: every element must be written
-        if prec == "f16c8":      # (the unused half of plane 1 is never written by either path)
-            xn.view(torch.uint8).reshape(2, -1)[1, M * N:] = xn_ref.view(torch.uint8).reshape(2, -1)[1, M * N:]
-        hip_ops.gemm(a16, w16, b.cuda(), prec=prec, resid=x, out=x, out_f32=True, w_qexp=e, wscale=ws, ln=(gam, bet, 1e-5, xn, sync))
-        torch.cuda.synchronize()
-        assert torch.equal(x, x_ref), (prec, rep)
-        assert torch.equal(xn.view(torch.uint8), xn_ref.view(torch.uint8)), (prec, rep)
-        assert int(sync.abs().max()) == 0
-    # a shape the persistent kernel does not take must be REFUSED, never silently unfused (F16C8 always takes it: must be right)
-    small = hip_ops.to_operand(a[:300].cuda(), prec)
-    xs = x0[:300].clone()
-    if hip_ops.gemm_fuses_layernorm(300, N, K, prec):
-        xns = hip_ops.to_operand(torch.zeros(300, N, device="cuda"), prec)
-        hip_ops.gemm(small, w16, b.cuda(), prec=prec, resid=xs, out=xs, out_f32=True, w_qexp=e, wscale=ws, ln=(gam, bet, 1e-5, xns, sync))
-        assert torch.equal(xs, x_ref[:300])
-        np_ = _lib.planes(prec)
-        for pl in range(np_):
-            got = (xns[pl] if np_ == 2 else xns).view(torch.uint8).reshape(-1)[: 300 * N * (1 if (prec == "f16c8" and pl == 1) else xns.element_size())]
-            ref = (xn_ref[pl] if np_ == 2 else xn_ref).view(torch.uint8).reshape(-1)[: got.numel()]
-            assert torch.equal(got, ref)
-    else:
-        with pytest.raises(_lib.HipLibraryError, match="BD_ERR_SHAPE"):
-            hip_ops.gemm(small, w16, b.cuda(), prec=prec, resid=xs, out=xs, out_f32=True, w_qexp=e, wscale=ws,
-                         ln=(gam, bet, 1e-5, xn_ref.clone(), sync))
-
-
 @pytest.mark.parametrize("M", [300, 6144])
 def test_gemm_fused_qk_rmsnorm_two_parts(hip, M):
     """rms_parts = 2: the q, k launch of a column-split QKV Linear (BD_PREC_F16C8_QK16): N = 2 x heads x 96 output columns, BOTH halves

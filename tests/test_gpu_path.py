@@ -23,9 +23,9 @@ from boxdreamer_amd.encoder import DinoV2Wrapper
 from oracle import boxdreamer_oracle as orc
 
 pytestmark = pytest.mark.gpu
-LOGIT_TOL = {"f16c8_qk16": 1e-3, "f16c8_qkv16": 1e-3, "f16c8": 1e-3, "bf16x3_qkv16": 1e-3, "bf16x3": 1e-3, "bf16x3_attn_x3": 1e-3, "fp16": 2.5e-2, "bf16": 1e-1}
-FEAT_TOL = {"f16c8_qk16": 1e-3, "f16c8_qkv16": 1e-3, "f16c8": 1e-3, "bf16x3_qkv16": 1e-3, "bf16x3": 1e-3, "bf16x3_attn_x3": 1e-3, "fp16": 2.5e-2, "bf16": 1e-1}
-STRICT = ("f16c8_qk16", "f16c8_qkv16", "f16c8", "bf16x3_qkv16", "bf16x3", "bf16x3_attn_x3")
+LOGIT_TOL = {"f16x3": 1e-3, "f16x3_attn_x3": 1e-3, "f16c8_qk16": 1e-3, "f16c8_qkv16": 1e-3, "f16c8": 1e-3, "bf16x3_qkv16": 1e-3, "bf16x3": 1e-3, "bf16x3_attn_x3": 1e-3, "fp16": 2.5e-2, "bf16": 1e-1}
+FEAT_TOL = {"f16x3": 1e-3, "f16x3_attn_x3": 1e-3, "f16c8_qk16": 1e-3, "f16c8_qkv16": 1e-3, "f16c8": 1e-3, "bf16x3_qkv16": 1e-3, "bf16x3": 1e-3, "bf16x3_attn_x3": 1e-3, "fp16": 2.5e-2, "bf16": 1e-1}
+STRICT = ("f16x3", "f16x3_attn_x3", "f16c8_qk16", "f16c8_qkv16", "f16c8", "bf16x3_qkv16", "bf16x3", "bf16x3_attn_x3")
 REPORT = {}
 
 
@@ -63,7 +63,7 @@ def _oracle(data, dino_depth, betr_depth):
     return _ORACLE[key]
 
 
-@pytest.mark.parametrize("prec", ["f16c8_qk16", "f16c8_qkv16", "f16c8", "bf16x3_qkv16", "bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["f16c8_qk16", "f16c8_qkv16", "f16c8", "f16x3", "f16x3_attn_x3", "bf16x3_qkv16", "bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("case", ["tiny_d2_T2", "tiny_d2_T3_B2", "full_T2", "full_T6"])
 def test_path_vs_oracle_and_golden(hip, golden_dir, prec, case):
     g = np.load(os.path.join(golden_dir, f"case_{case}.npz"))

@@ -180,7 +180,7 @@ def test_c_abi_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.bd_abi_version() == 4 and lib.bd_target_arch() == b"gfx950"
+    assert lib.bd_abi_version() == 5 and lib.bd_target_arch() == b"gfx950"
     # argument validation happens before any launch: NULL / bad shapes are rejected on a GPU-less box
     g = _lib.GemmArgs()
     assert lib.bd_gemm(ctypes.byref(g), 0, None) == -5
@@ -224,16 +224,15 @@ def test_packed_weights_follow_a_checkpoint_loaded_through_the_parent_module():
     dec = m.decoder
     p0 = dec._weights("cpu", "bf16")
     assert dec._weights("cpu", "bf16") is p0                                    # unchanged content: cache hit
-    w_old = p0.tensors[-2].clone()                                               # the sincos table: content-independent
+    w_old = p0.named["pos_table"].clone()                                        # the sincos table: content-independent
     sd = {"decoder." + k: v for k, v in synth.betr_state_dict(99, 1).items()}
     m.load_state_dict(sd, strict=True)                                           # parent-module load
     p1 = dec._weights("cpu", "bf16")
     assert p1 is not p0
-    q_old = [t for t in p0.tensors if t.dtype == torch.bfloat16][0]
-    q_new = [t for t in p1.tensors if t.dtype == torch.bfloat16][0]
+    q_old, q_new = p0.named[("attn.0.qkv", _lib.PREC_BF16)], p1.named[("attn.0.qkv", _lib.PREC_BF16)]
     assert q_old.shape == q_new.shape and not torch.equal(q_old, q_new)
     assert torch.equal(q_new, sd["decoder.attn.0.attn.qkv.weight"].to(torch.bfloat16))
-    assert torch.equal(p1.tensors[-2], w_old)
+    assert torch.equal(p1.named["pos_table"], w_old)
     with torch.no_grad():
         dec.bbox_learnable_query.add_(1.0)                                       # in-place edit bumps the version counter
     assert dec._weights("cpu", "bf16") is not p1
@@ -317,9 +316,16 @@ def test_precision_ids():
     assert _lib.operand_prec("bf16x3_qkv16") == _lib.PREC_BF16X3
     hdr = open(os.path.join(ROOT, "include", "boxdreamer_hip.h")).read()
     for name, val in (("BD_PREC_BF16X3_ATTN_X3", 6), ("BD_PREC_BF16X3_ATTN_F16", 7), ("BD_PREC_F16C8", 8), ("BD_PREC_BF16X3_QKV16", 11),
-                      ("BD_PREC_F16C8_QKV16", 12), ("BD_PREC_F16C8_QK16", 13), ("BD_ABI_VERSION", 4)):
+                      ("BD_PREC_F16C8_QKV16", 12), ("BD_PREC_F16C8_QK16", 13), ("BD_ABI_VERSION", 5),
+                      ("BD_PROMOTE_QKV", _lib.PROMOTE_QKV), ("BD_PROMOTE_PROJ", _lib.PROMOTE_PROJ), ("BD_PROMOTE_FC1", _lib.PROMOTE_FC1),
+                      ("BD_PROMOTE_FC2", _lib.PROMOTE_FC2), ("BD_PROMOTE_ATTN", _lib.PROMOTE_ATTN),
+                      ("BD_PROMOTE_ADAPTER_FC1", _lib.PROMOTE_ADAPTER_FC1), ("BD_PROMOTE_ADAPTER_FC2", _lib.PROMOTE_ADAPTER_FC2),
+                      ("BD_PROMOTE_BBOX_EMB", _lib.PROMOTE_BBOX_EMB), ("BD_PROMOTE_BBOX_PROJ", _lib.PROMOTE_BBOX_PROJ),
+                      ("BD_PROMOTE_PATCH_EMBED", _lib.PROMOTE_PATCH_EMBED)):
         assert re.search(rf"#define {name} {val}\b", hdr), name
-    # the library keeps no environment switches: nothing under csrc/ reads the environment
+    # the library keeps no environment switches and no measured-negative A/B branches
     for f in os.listdir(os.path.join(ROOT, "boxdreamer_amd", "csrc")):
         if f.endswith((".hip", ".h")):
-            assert "getenv" not in open(os.path.join(ROOT, "boxdreamer_amd", "csrc", f)).read(), f
+            src = open(os.path.join(ROOT, "boxdreamer_amd", "csrc", f)).read()
+            assert "getenv" not in src, f
+            assert "BD_EXP_" not in src, f
