@@ -47,11 +47,13 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_16BIT, PEAK_MFMA_FP8 = 2500.0, 5000.0      # TFLOP/s; every mode but "fp8" is priced against the 16-bit peak
 PEAK_HBM_GBS = 8000.0
 DINO_FLOP_PER_IMAGE = 47_078_313_984          # BASELINE.md §4 / SURVEY.md §8(d)
+TRAINED_LIKE = "outliers_g0.5"                  # the trained-like weight set of the strict_trained_like leg (tests/golden/case_outliers_g0.5_T2.npz)
 STRICT_PREC = "f16c8_qk16"                      # the package default: meets the 1e-3 bar with a 4x margin
 DTYPE_LABEL = {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3", "bf16x3_attn_x3": "bf16x3", "bf16x3_attn_f16": "bf16x3 (attention: f16)",
                "bf16x3_qkv16": "bf16x3 (BETR QKV: f16)", "f16c8": "f16 + e4m3 corrections",
-               "f16c8_qkv16": "f16 + e4m3 corrections (BETR QKV: f16)", "f16c8_qk16": "f16 + e4m3 corrections (BETR q, k columns: f16)", "fp8": "fp8-e4m3 (Linears) + bf16 (attention)"}
-MFMA_PASSES = {"bf16x3": 3.0, "bf16x3_attn_x3": 3.0, "bf16x3_attn_f16": 3.0, "bf16x3_qkv16": 2.75, "f16c8": 2.0, "f16c8_qkv16": 1.9, "f16c8_qk16": 1.93}
+               "f16c8_qkv16": "f16 + e4m3 corrections (BETR QKV: f16)", "f16c8_qk16": "f16 + e4m3 corrections (BETR q, k columns: f16)", "fp8": "fp8-e4m3 (Linears) + bf16 (attention)",
+               "f16x3": "f16x3 (split-f16 Linears)", "f16x3_attn_x3": "f16x3 (split-f16 Linears, split-bf16 attention)"}
+MFMA_PASSES = {"f16x3": 3.0, "f16x3_attn_x3": 3.0, "bf16x3": 3.0, "bf16x3_attn_x3": 3.0, "bf16x3_attn_f16": 3.0, "bf16x3_qkv16": 2.75, "f16c8": 2.0, "f16c8_qkv16": 1.9, "f16c8_qk16": 1.93}
 _PRECS = tuple(DTYPE_LABEL)
 
 
@@ -64,16 +66,25 @@ def flops_per_pose(T: int) -> int:
     return T * DINO_FLOP_PER_IMAGE + betr_flops(T)
 
 
-def build_models(prec, device):
+def state_dicts(weights: str = "plain"):
+    """(betr_sd, dino_sd) of the bench: "plain" = seeded random init; "outliers_g<gain>" = the trained-like grafts (synth.py)."""
     from boxdreamer_amd import synth
+    if weights.startswith("outliers_g"):
+        g = float(weights[len("outliers_g"):])
+        return synth.betr_state_dict_outliers(1234, 12, g), synth.dino_state_dict_outliers(4321, 12, g)
+    return synth.betr_state_dict(seed=1234, depth=12), synth.dino_state_dict(seed=4321, depth=12)
+
+
+def build_models(prec, device, weights: str = "plain"):
     from boxdreamer_amd.betr import BETR
     from boxdreamer_amd.encoder import DinoV2Wrapper
-    enc = DinoV2Wrapper(None, {"model_type": "dinov2_vitb14_reg", "synthetic_seed": 4321, "hip_precision": prec})
+    bsd, dsd = state_dicts(weights)
+    enc = DinoV2Wrapper(None, {"model_type": "dinov2_vitb14_reg", "state_dict": dsd, "hip_precision": prec})
     enc.to_device(device)
     dec = BETR(d_model=768, nhead=8, num_decoder_layers=12, decoder_only=True, patch_size=14, img_size=224,
                diff_emb=False, nvs_supervision=False, ray_supervision=True, use_mask=False, use_pretrained=True,
                patchify_rays=True, pose_representation="bb8", bbox_representation="heatmap", hip_precision=prec)
-    dec.load_state_dict(synth.betr_state_dict(seed=1234, depth=12), strict=True)
+    dec.load_state_dict(bsd, strict=True)
     dec.validate_inputs = False         # the one-hot mask check is a device sync per forward: not inside a timed step
     return enc, dec.to(device).eval()
 
@@ -126,12 +137,12 @@ def cpu_baseline(T: int, budget_s: float = 24.0) -> dict:
                       f"{torch.get_num_threads()} threads"}
 
 
-def parity_probe(prec, T: int, device, models=None) -> dict:
+def parity_probe(prec, T: int, device, models=None, weights: str = "plain") -> dict:
     """Max-abs error of the heatmap logits vs the CPU oracle on full-depth poses (outside the timed region): B = 2 samples
     with different inputs, the same weights as the timed step."""
     from boxdreamer_amd import hip_ops, synth
     from oracle import boxdreamer_oracle as orc
-    enc, dec = models if models is not None else build_models(prec, device)
+    enc, dec = models if models is not None else build_models(prec, device, weights)
     B = 2
     data = synth.make_batch(seed=11, B=B, T=T)
     mask = torch.zeros(B, T, dtype=torch.bool); mask[:, T - 1] = True
@@ -139,14 +150,15 @@ def parity_probe(prec, T: int, device, models=None) -> dict:
     heat = dec(bf, img, mask.to(device), enc.predict(img), None)
     kp, _, idx = hip_ops.decode_topk(heat)
     with torch.no_grad():
-        o = orc.boxdreamer_forward(data, synth.betr_state_dict(1234, 12), synth.dino_state_dict(4321, 12))
+        o = orc.boxdreamer_forward(data, *state_dicts(weights))
     same = (idx.cpu().long().sort(-1)[0] == o["topk_idx"].sort(-1)[0]).all(-1).float().mean().item()
     return {"mode": prec, "logits_max_abs_err": float((dec.last_logits.cpu() - o["logits"]).abs().max()),
             "heat_max_abs_err": float((heat.cpu() - o["heat"]).abs().max()),
             "top20_sets_equal_frac": same,
             "corner_px_max_err": float((kp.cpu() - o["corners_px"]).abs().max()),
             "tolerance": 1e-3, "meets_tolerance": bool((dec.last_logits.cpu() - o["logits"]).abs().max() <= 1e-3),
-            "case": f"B={B},T={T} full depth vs CPU oracle (fp32), random-init weights"}
+            "case": f"B={B},T={T} full depth vs CPU oracle (fp32), " + ("random-init weights" if weights == "plain" else
+                    f"trained-like outlier weights ({weights}: logits max {float(o['logits'].abs().max()):.1f})")}
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -462,7 +474,7 @@ def measure_counters(args) -> None:
     import collections, csv
     prec, B, T = args.prec, args.batch, args.views
     child = ["--prec", prec, "--batch", str(B), "--views", str(T), "--steps", "2", "--warmup", "1", "--no-graph", "--in-flight", "1",
-             "--no-strict", "--no-fp8", "--no-cpu-baseline", "--no-parity", "--no-pnp", "--no-h2d"]
+             "--no-strict", "--no-fp8", "--no-cpu-baseline", "--no-parity", "--no-pnp", "--no-h2d", "--no-trained-like"]
     acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES") + LDS_COUNTERS}
     launches, dur_ns, steps_seen = collections.defaultdict(int), collections.defaultdict(float), 0
     lds_group = _available_counters(LDS_COUNTERS)          # one more pass: where the LDS time of the mainloops goes
@@ -541,8 +553,8 @@ def load_counters(prec: str, B: int, T: int):
 class ModeRun:
     """Everything needed to time one precision mode on this rank: models, resident inputs, the (graphed) step."""
 
-    def __init__(self, prec, args, device, world, rank, dist, images, bbox, mask):
-        from boxdreamer_amd import hip_ops
+    def __init__(self, prec, args, device, world, rank, dist, images, bbox, mask, weights: str = "plain"):
+        from boxdreamer_amd import calibrate, hip_ops
         from boxdreamer_amd.dist import gather_corners
         self.prec, self.args, self.device, self.world, self.rank, self.dist = prec, args, device, world, rank, dist
         self.images, self.bbox, self.mask = images, bbox, mask
@@ -553,7 +565,13 @@ class ModeRun:
                 dist.all_gather(parts, kp.detach().cpu())
                 return torch.cat(parts, 0).to(kp.device)
             self.gather = host_staged_gather
-        self.enc, self.dec = build_models(prec, device)
+        self.enc, self.dec = build_models(prec, device, weights)
+        # what a maintainer's first forward does (boxdreamer_amd/model.py): the load-time self-check of the mode on the batch's first
+        # sample, promoting the Linears that need it -- BEFORE anything is captured or timed; a no-op outside the f16c8 family
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            self.calibration = calibrate.calibrate(self.enc, self.dec, images, bbox, mask)
         self.B, self.T = images.shape[:2]
         self.kp_all = torch.empty((self.B, 8, 2), dtype=torch.float32, device=device)
         self.graphed = None
@@ -579,7 +597,9 @@ class ModeRun:
             self.lanes.append({"g": self.graphed, "s": torch.cuda.Stream(device=device), "done": torch.cuda.Event(), "free": torch.cuda.Event()})
             for li in range(1, max(1, args.in_flight)):
                 try:
-                    enc2, dec2 = build_models(prec, device)
+                    enc2, dec2 = build_models(prec, device, weights)
+                    if self.calibration.get("state"):
+                        calibrate.set_state(enc2, dec2, self.calibration["state"])
                     g2 = GraphedPath(enc2, dec2, self.B, self.T, 224, torch.bfloat16, device)
                     # the lane's own batch: B more distinct samples (another seed), so K steps really are K x B different-or-
                     # repeated-per-lane poses, not one batch fed to both lanes
@@ -694,15 +714,24 @@ def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, coun
     return r
 
 
-def measure_mode(prec, args, device, world, rank, dist, images, bbox, mask):
+def calibration_summary(rep: dict) -> dict:
+    if not rep.get("applicable"):
+        return {"applicable": False}
+    return {"applicable": True, "self_check_unpromoted_max_abs_dlogits": rep["delta_unpromoted"], "self_check_final": rep["delta_final"],
+            "budget": rep["budget"], "ok": rep["ok"], "promoted_units": len(rep["promoted"]), "units": rep["units"],
+            "promoted_work_frac": rep["promoted_cost_frac"], "forwards": rep["forwards"], "reference": rep["reference"]}
+
+
+def measure_mode(prec, args, device, world, rank, dist, images, bbox, mask, weights: str = "plain"):
     from boxdreamer_amd import _lib
     lib = _lib.load()
-    run = ModeRun(prec, args, device, world, rank, dist, images, bbox, mask)
+    run = ModeRun(prec, args, device, world, rank, dist, images, bbox, mask, weights)
     sync = torch.cuda.synchronize if world == 1 else interruptible_sync(device)
     dt, per_rank, out = timed_steps(run.step, args.steps, args.warmup, world, dist, sync, device)
     B, T = run.B, run.T
     assert out.shape[0] == B * world and torch.isfinite(out).all()
-    res = {"dt": dt, "per_rank": per_rank, "out": out, "run": run, "in_flight": max(1, len(run.lanes))}
+    res = {"dt": dt, "per_rank": per_rank, "out": out, "run": run, "in_flight": max(1, len(run.lanes)),
+           "calibration": calibration_summary(run.calibration)}
     if len(run.lanes) > 1:        # the same K steps one batch at a time on one stream, for the record
         dt1, _, out1 = timed_steps(run.step_single, args.steps, 1, world, dist, sync, device)
         assert out1.shape == out.shape and torch.isfinite(out1).all()     # (lanes hold different batches: values differ by design)
@@ -713,6 +742,8 @@ def measure_mode(prec, args, device, world, rank, dist, images, bbox, mask):
         value = B * world * args.steps / dt
         fpp = flops_per_pose(T) if not args.cache_refs else DINO_FLOP_PER_IMAGE + betr_flops(T)
         counters, why = (None, "reference features cached: other algorithmic traffic") if args.cache_refs else load_counters(prec, B, T)
+        if weights != "plain" and run.calibration.get("promoted"):
+            counters, why = None, "promoted Linears: the counter file describes the unpromoted mode"
         res.update(value=value, fpp=fpp, ms_per_step=dt / args.steps * 1e3,
                    roofline=roofline_block(prec, recs, dt / args.steps * 1e3, TRACE, value / world, fpp, counters, why))
     return res
@@ -859,6 +890,7 @@ def main():
                     help="batches in flight in graph mode: 2 = two captured copies of the path replayed alternately on two streams "
                          "(default), 1 = one batch at a time")
     ap.add_argument("--no-strict", action="store_true", help="skip the second (strict-mode) timing")
+    ap.add_argument("--no-trained-like", action="store_true", help="skip the strict-mode leg on the trained-like outlier weights")
     ap.add_argument("--no-fp8", action="store_true", help="skip the configs[4] leg (fp8 Linears, batch 64) of the default single-GPU run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -945,9 +977,15 @@ def run(args):
 
     main_res = measure_mode(prec, args, device, world, rank, dist, images, bbox, mask)
     line = None
+    rank_devices = None
+    if world > 1:              # every rank reports the device it ran on (an object collective: all ranks take part)
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, f"rank {rank}: {torch.cuda.get_device_name(device)} (cuda:{device.index})")
     if rank == 0:
         value, fpp = main_res["value"], main_res["fpp"]
         metric = "poses/s/GPU (5-ref, 224×224, bf16); heatmap max-abs err vs CPU ref"     # BASELINE.json's metric string
+        if prec != "bf16" or T != 6:      # another mode / view count: say so in the metric itself
+            metric = f"poses/s/GPU ({T - 1}-ref, 224×224, {DTYPE_LABEL[prec]}); heatmap max-abs err vs CPU ref"
         if args.cache_refs:
             metric = "poses/s with reference features cached across queries (SURVEY 8f1; encoder on the query crop only)"
         line = {"metric": metric,
@@ -963,9 +1001,18 @@ def run(args):
                 "poses_per_s_per_gpu": round(value / world, 2),
                 "value_is": "whole-job aggregate over n_gpus (bench contract); the per-GPU figure of the metric is poses_per_s_per_gpu",
                 "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in main_res["per_rank"]],
+                "value_mode": prec, "package_default_mode": STRICT_PREC,
                 "roofline": main_res["roofline"]}
+        if main_res["calibration"].get("applicable"):
+            line["calibration"] = main_res["calibration"]
         if "single_stream" in main_res:
             line["single_stream"] = main_res["single_stream"]
+            line["value_single_stream"] = main_res["single_stream"]["value"]       # one batch of configs[1]'s 32 at a time
+        if world > 1:          # what the collective layer itself saw (not the CLI argument): the first SCALE record must prove N ranks
+            names = rank_devices
+            line["distributed"] = {"backend": dist.get_backend(), "world_size_seen_by_the_collective": dist.get_world_size(),
+                                   "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None,
+                                   "devices": names}
         PROGRESS["line"] = dict(line)
     PROGRESS["stage"] = "corner all-gather latency"
     if world > 1:
@@ -979,6 +1026,8 @@ def run(args):
         run = main_res["run"]
         if not args.no_parity:
             line["parity"] = parity_probe(prec, T, device, (run.enc, run.dec) if B >= 2 else None)   # a captured B = 1 path is frozen
+            line["parity_meets_tolerance"] = line["parity"]["meets_tolerance"]
+            line["logits_max_abs_err"] = line["parity"]["logits_max_abs_err"]
         if world == 1 and not args.no_h2d and not args.cache_refs:
             line["h2d_inclusive"] = h2d_inclusive(run, max(4, args.steps))
         if world == 1 and not args.no_pnp:
@@ -1005,12 +1054,39 @@ def run(args):
                               "poses_per_s_per_gpu": round(sres["value"] / world, 2),
                               "ms_per_step": round(sres["ms_per_step"], 3), "dtype": DTYPE_LABEL[STRICT_PREC],
                               "roofline": sres["roofline"], "batches_in_flight": sres["in_flight"]}
+            line["strict"]["calibration"] = sres["calibration"]
+            # the figures of record where the driver's `parsed` shows them
+            line["value_meeting_parity"] = line["strict"]["value"]
+            line["value_meeting_parity_mode"] = STRICT_PREC
             if "single_stream" in sres:
                 line["strict"]["single_stream"] = sres["single_stream"]
+                line["value_meeting_parity_single_stream"] = sres["single_stream"]["value"]
             if not args.no_parity:
                 line["strict"]["parity"] = parity_probe(STRICT_PREC, T, device, (srun.enc, srun.dec) if B >= 2 else None)
+                line["value_meeting_parity_logits_max_abs_err"] = line["strict"]["parity"]["logits_max_abs_err"]
+                line["value_meeting_parity_meets_tolerance"] = line["strict"]["parity"]["meets_tolerance"]
         sres["run"].close()
         del sres
+    # ---- what the default mode costs on a checkpoint with outlier channels: the same step on the trained-like weight set, after the
+    # load-time calibration promoted what it had to (one batch at a time; single GPU, default workload only)
+    PROGRESS["stage"] = "strict mode on trained-like outlier weights"
+    if rank == 0:
+        PROGRESS["line"] = dict(line)
+    if world == 1 and not args.no_strict and not args.no_trained_like and not args.cache_refs and prec != STRICT_PREC and B == 32 and T == 6:
+        torch.cuda.empty_cache()
+        argsT = argparse.Namespace(**{**vars(args), "in_flight": 1})
+        tres = measure_mode(STRICT_PREC, argsT, device, world, rank, dist, images, bbox, mask, weights=TRAINED_LIKE)
+        base = line.get("strict", {}).get("single_stream", {}).get("value")
+        line["strict_trained_like"] = {"weights": TRAINED_LIKE + " (synth.*_state_dict_outliers: massive-activation channels, LayerNorm gain outliers, "
+                                                  "MLP hidden units in the hundreds)", "mode": STRICT_PREC,
+                                       "value": round(tres["value"], 2), "unit": "poses/s", "ms_per_step": round(tres["ms_per_step"], 3),
+                                       "batches_in_flight": 1, "calibration": tres["calibration"],
+                                       "throughput_vs_unpromoted_single_stream": round(tres["value"] / base, 4) if base else None,
+                                       "roofline": {k: tres["roofline"][k] for k in ("achieved", "frac", "whole_path_achieved") if k in tres["roofline"]}}
+        if not args.no_parity:
+            line["strict_trained_like"]["parity"] = parity_probe(STRICT_PREC, T, device, (tres["run"].enc, tres["run"].dec), weights=TRAINED_LIKE)
+        tres["run"].close()
+        del tres
     # ---- BASELINE configs[4]: fp8 (e4m3) Linears + bf16 attention at batch 64, single GPU, default workload only (its tolerance is
     # RESTATED: 3 mantissa bits cannot meet 1e-3) -- reported in the same line so the driver's run covers it
     PROGRESS["stage"] = "fp8 leg (configs[4])"

@@ -101,7 +101,7 @@ EXPORTS = [
     "bd_gather_query_tokens", "bd_unpatchify_sigmoid", "bd_decode_topk",
     "bd_encoder_workspace_bytes", "bd_encoder_forward", "bd_decoder_workspace_bytes", "bd_decoder_forward",
     "bd_trace_begin", "bd_trace_end", "bd_render_corner_heatmaps", "bd_attention_q", "bd_gather_query_rows_f32",
-    "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm",
+    "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm", "bd_solve_pnp_host",
 ]
 
 _lib = None
@@ -150,6 +150,7 @@ def load() -> C.CDLL:
     lib.bd_dino_match_scores.argtypes = [vp, vp, i, vp, i, i, i, i, i, i, f, vp, vp, vp, vp]
     lib.bd_topk_mask.argtypes = [vp, i, i, i, vp, vp]
     lib.bd_solve_pnp.argtypes = [vp, vp, vp, i, i, i, vp, vp]
+    lib.bd_solve_pnp_host.argtypes = [vp, vp, vp, i, i, i, vp, i]
     lib.bd_trace_begin.argtypes = [i]
     lib.bd_trace_end.argtypes = [C.POINTER(TraceRecord), i]
     if lib.bd_abi_version() != 5:

@@ -7,13 +7,19 @@
 // made to spread one pose over a wavefront.  PARITY against OpenCV is un-pinned (no cv2 in the image); the kernel is
 // tested against the numpy form, which it follows step by step.
 #include "bd_common.h"
+#include <cmath>
+#include <thread>
+#include <vector>
 
 namespace {
 
 constexpr int MAXPTS = 64;
 
+// (isfinite is a __device__-only overload in HIP's headers: a portable test for the code shared by the GPU and the host threads)
+__host__ __device__ inline bool finite_d(double v) { return v - v == 0.0; }
+
 // cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (row-major, destroyed); V columns = eigenvectors
-template <int N> __device__ void jacobi_eig(double* A, double* V, double* w) {
+template <int N> __host__ __device__ void jacobi_eig(double* A, double* V, double* w) {
     for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j) V[i * N + j] = i == j ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -50,11 +56,11 @@ template <int N> __device__ void jacobi_eig(double* A, double* V, double* w) {
     for (int i = 0; i < N; ++i) w[i] = A[i * N + i];
 }
 
-__device__ double det3(const double* R) {
+__host__ __device__ double det3(const double* R) {
     return R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
 }
 
-__device__ void rodrigues(const double* rv, double* R) {
+__host__ __device__ void rodrigues(const double* rv, double* R) {
     const double th = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
     if (th < 1e-12) {
         for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
@@ -70,7 +76,7 @@ __device__ void rodrigues(const double* rv, double* R) {
         }
 }
 
-__device__ void rvec_from_R(const double* R, double* rv) {
+__host__ __device__ void rvec_from_R(const double* R, double* rv) {
     double c = (R[0] + R[4] + R[8] - 1.0) / 2.0;
     c = c < -1.0 ? -1.0 : (c > 1.0 ? 1.0 : c);
     const double th = acos(c);
@@ -90,7 +96,7 @@ __device__ void rvec_from_R(const double* R, double* rv) {
 }
 
 // residuals of pose x = (rvec, t) for n points; returns false on a non-finite value
-__device__ bool residuals(const double* x, const double* p3, const double* p2n, int n, double* r) {
+__host__ __device__ bool residuals(const double* x, const double* p3, const double* p2n, int n, double* r) {
     double R[9];
     rodrigues(x, R);
     bool ok = true;
@@ -100,13 +106,13 @@ __device__ bool residuals(const double* x, const double* p3, const double* p2n, 
                      cz = R[6] * X + R[7] * Y + R[8] * Z + x[5];
         r[2 * i] = cx / cz - p2n[2 * i];
         r[2 * i + 1] = cy / cz - p2n[2 * i + 1];
-        ok = ok && isfinite(r[2 * i]) && isfinite(r[2 * i + 1]);
+        ok = ok && finite_d(r[2 * i]) && finite_d(r[2 * i + 1]);
     }
     return ok;
 }
 
 // solve the 6 x 6 system H d = g (partial pivoting); false if singular
-__device__ bool solve6(double* H, double* g, double* d) {
+__host__ __device__ bool solve6(double* H, double* g, double* d) {
     for (int c = 0; c < 6; ++c) {
         int piv = c;
         for (int r = c + 1; r < 6; ++r) if (fabs(H[r * 6 + c]) > fabs(H[piv * 6 + c])) piv = r;
@@ -129,23 +135,19 @@ __device__ bool solve6(double* H, double* g, double* d) {
     return true;
 }
 
-__global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ kp, const float* __restrict__ pts3,
-                                                 const float* __restrict__ Kmat, int N, int n, int iters,
-                                                 float* __restrict__ poses) {
-    const int id = blockIdx.x * 64 + threadIdx.x;
-    if (id >= N) return;
-    float* out = poses + (size_t)id * 16;
+// One pose: kp [n, 2] pixels, pts3 [n, 3], Kp [3, 3] -> out [4, 4] = [R|t; 0 0 0 1], all zeros where the solve fails.  The same code
+// runs per GPU thread (pnp_kernel) and per host worker thread (bd_solve_pnp_host).
+__host__ __device__ void solve_one_pose(const float* kp, const float* pts3, const float* Kp, int n, int iters, float* out) {
     for (int i = 0; i < 16; ++i) out[i] = 0.f;
     double p3[MAXPTS * 3], p2n[MAXPTS * 2];
-    const float* Kp = Kmat + (size_t)id * 9;
     const double fx = Kp[0], fy = Kp[4], cx = Kp[2], cy = Kp[5];
     double mean[3] = {0, 0, 0};
     bool ok = true;
     for (int i = 0; i < n; ++i) {
-        for (int c = 0; c < 3; ++c) { p3[i * 3 + c] = pts3[((size_t)id * n + i) * 3 + c]; mean[c] += p3[i * 3 + c] / n; }
-        p2n[2 * i] = ((double)kp[((size_t)id * n + i) * 2] - cx) / fx;
-        p2n[2 * i + 1] = ((double)kp[((size_t)id * n + i) * 2 + 1] - cy) / fy;
-        ok = ok && isfinite(p2n[2 * i]) && isfinite(p2n[2 * i + 1]);
+        for (int c = 0; c < 3; ++c) { p3[i * 3 + c] = pts3[i * 3 + c]; mean[c] += p3[i * 3 + c] / n; }
+        p2n[2 * i] = ((double)kp[i * 2] - cx) / fx;
+        p2n[2 * i + 1] = ((double)kp[i * 2 + 1] - cy) / fy;
+        ok = ok && finite_d(p2n[2 * i]) && finite_d(p2n[2 * i + 1]);
     }
     if (!ok) return;
     // ---- DLT: null vector of A (2n x 12) = eigenvector of A^T A with the smallest eigenvalue
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ kp, c
             residuals(xd, p3, p2n, n, rn);
             for (int i = 0; i < m; ++i) {
                 const double d = (rn[i] - r[i]) / 1e-6;
-                J[i * 6 + j] = isfinite(d) ? d : 0.0;
+                J[i * 6 + j] = finite_d(d) ? d : 0.0;
             }
         }
         double H[36], g[6], step[6];
@@ -261,7 +263,40 @@ __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ kp, c
     out[15] = 1.f;
 }
 
+__global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ kp, const float* __restrict__ pts3,
+                                                 const float* __restrict__ Kmat, int N, int n, int iters,
+                                                 float* __restrict__ poses) {
+    const int id = blockIdx.x * 64 + threadIdx.x;
+    if (id >= N) return;
+    solve_one_pose(kp + (size_t)id * n * 2, pts3 + (size_t)id * n * 3, Kmat + (size_t)id * 9, n, iters, poses + (size_t)id * 16);
+}
+
 }  // namespace
+
+// The host form ("PnP post-solve stays on the host CPU", north_star): the same per-pose solver on a pool of host threads, poses
+// dealt out in contiguous chunks.  All pointers are HOST pointers.  Replaces the per-sample Python loop around cv2.solvePnP of
+// src/models/utils/box_utils.py:139-199 when OpenCV is not importable (and the single-threaded numpy restatement of round 2:
+// 9 ms per 32 poses).  n_threads <= 0: one thread per 4 poses, at most 16.
+extern "C" int bd_solve_pnp_host(const float* kp_px, const float* pts3, const float* K, int n_poses, int n_points, int iters,
+                                 float* poses, int n_threads) {
+    if (!kp_px || !pts3 || !K || !poses) return BD_ERR_NULL;
+    if (n_poses <= 0 || n_points < 6 || n_points > MAXPTS || iters < 0) return BD_ERR_SHAPE;
+    int nt = n_threads > 0 ? n_threads : (n_poses + 3) / 4;
+    nt = nt > 16 ? 16 : (nt > n_poses ? n_poses : nt);
+    auto work = [=](int t) {
+        const int lo = (int)((int64_t)n_poses * t / nt), hi = (int)((int64_t)n_poses * (t + 1) / nt);
+        for (int i = lo; i < hi; ++i)
+            solve_one_pose(kp_px + (size_t)i * n_points * 2, pts3 + (size_t)i * n_points * 3, K + (size_t)i * 9, n_points, iters,
+                           poses + (size_t)i * 16);
+    };
+    if (nt <= 1) { work(0); return BD_OK; }
+    std::vector<std::thread> pool;
+    pool.reserve(nt - 1);
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    return BD_OK;
+}
 
 extern "C" int bd_solve_pnp(const float* kp_px, const float* pts3, const float* K, int n_poses, int n_points, int iters,
                             float* poses, void* stream) {

@@ -10,8 +10,10 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+import os
+
 from .betr import BETR
-from . import features, pnp
+from . import _lib, calibrate, features, pnp
 from .box_utils import recover_bb8_corners_chw, solve_poses_device, solve_poses_host
 from .cache import merge_cached_features
 from .config import setup_camera_params, validate_model_config
@@ -70,6 +72,33 @@ class BoxDreamer(nn.Module):
             raise NotImplementedError("use_rgb=False (from-scratch embeddings) is outside the hot path")
         dec_cfg = {k: v for k, v in dict(module_configs["decoder"]).items()}
         self.decoder = BETR(**dec_cfg)
+        # Load-time self-check of the precision mode (boxdreamer_amd/calibrate.py): on the first forward the default mode is measured
+        # against the most precise GPU mode on that batch's first sample and the Linears that need it are promoted to split-f16, so
+        # that a real checkpoint's outlier channels cannot silently cost the 1e-3 parity bar.  `hip_calibrate: false` in
+        # config["modules"] only measures and warns.  Re-armed whenever the decoder weights change (a checkpoint load).
+        self.hip_calibrate = bool(module_configs.get("hip_calibrate", True))
+        self._calibrated_for = None
+        self.hip_precision_source = ("config" if "hip_precision" in dec_cfg else
+                                     ("$BOXDREAMER_HIP_PREC" if "BOXDREAMER_HIP_PREC" in os.environ else "package default"))
+
+    def calibrate(self, data) -> dict:
+        """Run the precision self-check / promotion on (the first sample of) a batch dict now (forward() does it once by itself)."""
+        images = data["images"]
+        B, T = images.shape[:2]
+        mask = torch.zeros((B, T), dtype=torch.bool, device=images.device)
+        mask[torch.arange(B, device=images.device), data["query_idx"].to(images.device).long()] = True
+        if images.device != self.rgb_encoder.get_device():
+            self.rgb_encoder.to_device(images.device)
+        rep = calibrate.calibrate(self.rgb_encoder, self.decoder, images, data["bbox_feat"], mask, promote=self.hip_calibrate)
+        self._calibrated_for = self.decoder._signature()
+        return rep
+
+    def _precision_record(self) -> dict:
+        rep = self.decoder.hip_calibration or {}
+        return {"decoder": str(self.decoder.hip_precision), "encoder": str(self.rgb_encoder.prec), "source": self.hip_precision_source,
+                "calibrated": bool(rep.get("applicable")), "promoted_units": len(rep.get("promoted", [])),
+                "self_check_max_abs_dlogits": rep.get("delta_final"), "self_check_unpromoted": rep.get("delta_unpromoted"),
+                "self_check_budget": rep.get("budget"), "self_check_ok": rep.get("ok")}
 
     def forward(self, data):
         images = data["images"]
@@ -82,6 +111,10 @@ class BoxDreamer(nn.Module):
 
         if images.device != self.rgb_encoder.get_device():
             self.rgb_encoder.to_device(images.device)                            # BoxDreamerModel.py:279-282
+        if (self._calibrated_for != self.decoder._signature() and images.is_cuda and not torch.cuda.is_current_stream_capturing()
+                and calibrate.applicable(self.rgb_encoder, self.decoder)):
+            self.calibrate(data)
+        data["hip_precision"] = self._precision_record()
         if "cached_rgb_feat" in data:       # "next" row f1: references encoded once per object (boxdreamer_amd/cache.py)
             rgb_feature = merge_cached_features(self.rgb_encoder, images, data["cached_rgb_feat"],
                                                 data["cached_rgb_mask"])
@@ -134,7 +167,7 @@ class BoxDreamer(nn.Module):
         else:
             poses = torch.from_numpy(solve_poses_host(kp_px.cpu().numpy(), bbox_3d.cpu().numpy(), K.cpu().numpy()))
             data["pose_solver"] = ("host:cv2.solvePnP" if pnp._HAVE_CV2
-                                   else "host:numpy DLT + LM restatement (parity vs OpenCV un-pinned)")
+                                   else "host:bd_solve_pnp_host (native threads, DLT + LM; parity vs OpenCV un-pinned)")
         pred_poses[camera_mask] = poses.to(pred_poses.device).to(pred_poses.dtype)
         data["regression_boxes"] = data["bbox_proj_crop"].clone()
         data["regression_boxes"][camera_mask] = norm_kp.to(data["regression_boxes"].dtype)

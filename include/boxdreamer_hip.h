@@ -243,6 +243,11 @@ int bd_render_corner_heatmaps(const float* corners, int n_groups, int group, int
  * all zeros where the solve fails.  6 <= n_points <= 64. */
 int bd_solve_pnp(const float* kp_px, const float* pts3, const float* K, int n_poses, int n_points, int iters,
                  float* poses, void* stream);
+/* The same solver on the HOST (all pointers are host pointers, no GPU work): `n_threads` worker threads share the poses
+ * (<= 0: one per 4 poses, at most 16).  The default pose solver of the facade when OpenCV is not importable -- the PnP post-solve
+ * stays on the host CPU (north_star), without the per-sample Python loop of src/models/utils/box_utils.py:139-199. */
+int bd_solve_pnp_host(const float* kp_px /*[host]*/, const float* pts3 /*[host]*/, const float* K /*[host]*/, int n_poses, int n_points,
+                      int iters, float* poses /*[host]*/, int n_threads);
 
 /* Dense-reference mode ("next" row f4): DINO-feature reference selection, src/models/utils/matching.py:64-174
  * (`dino_matching`, called from process_dense_input, src/models/utils/data_processing.py:179-225).

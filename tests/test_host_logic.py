@@ -166,9 +166,17 @@ def test_pnp_batched_equals_scalar_form():
         o, Rs, ts = pnp.solve_pnp_iterative(p3[i], p2[i], K[i])
         assert o and np.abs(Rb[i] - Rs).max() < 1e-7 and np.abs(tb[i] - ts).max() < 1e-7
         assert np.abs(Rb[i] - Rt[i]).max() < 0.05 and np.abs(tb[i] - tt[i]).max() < 0.05     # close to the true pose
-    poses = solve_poses_host(p2.astype(np.float32), p3.astype(np.float32), K.astype(np.float32))
-    assert poses.shape == (N, 4, 4) and (poses[5] == 0).all() and poses[0, 3, 3] == 1.0
-    assert np.abs(poses[0, :3, :3] - Rb[0]).max() < 1e-4
+    # the facade's host solver: the NATIVE threaded form of the same algorithm (csrc/pnp.hip: bd_solve_pnp_host, a host function of
+    # the library -- no GPU involved), against the numpy form on every pose, for 1 / 3 / 8 worker threads (chunking must not matter)
+    ref = None
+    for workers in (1, 3, 8):
+        poses = solve_poses_host(p2.astype(np.float32), p3.astype(np.float32), K.astype(np.float32), workers=workers)
+        assert poses.shape == (N, 4, 4) and (poses[5] == 0).all() and poses[0, 3, 3] == 1.0
+        for i in range(N):
+            if i != 5:
+                assert np.abs(poses[i, :3, :3] - Rb[i]).max() < 1e-4 and np.abs(poses[i, :3, 3] - tb[i]).max() < 1e-4, i
+        assert ref is None or np.array_equal(ref, poses)
+        ref = poses
 
 
 def test_c_abi_loads_and_exports_every_declared_symbol():
