@@ -52,6 +52,7 @@ STRICT_PREC = "f16c8_qk16"                      # the package default: meets the
 DTYPE_LABEL = {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3", "bf16x3_attn_x3": "bf16x3", "bf16x3_attn_f16": "bf16x3 (attention: f16)",
                "bf16x3_qkv16": "bf16x3 (BETR QKV: f16)", "f16c8": "f16 + e4m3 corrections",
                "f16c8_qkv16": "f16 + e4m3 corrections (BETR QKV: f16)", "f16c8_qk16": "f16 + e4m3 corrections (BETR q, k columns: f16)", "fp8": "fp8-e4m3 (Linears) + bf16 (attention)",
+               "fp8_mixed": "fp8-e4m3 (MLPs, DINOv2 QKV) + bf16 (proj, BETR QKV, adapter, head, attention)",
                "f16x3": "f16x3 (split-f16 Linears)", "f16x3_attn_x3": "f16x3 (split-f16 Linears, split-bf16 attention)"}
 MFMA_PASSES = {"f16x3": 3.0, "f16x3_attn_x3": 3.0, "bf16x3": 3.0, "bf16x3_attn_x3": 3.0, "bf16x3_attn_f16": 3.0, "bf16x3_qkv16": 2.75, "f16c8": 2.0, "f16c8_qkv16": 1.9, "f16c8_qk16": 1.93}
 _PRECS = tuple(DTYPE_LABEL)
@@ -447,6 +448,12 @@ LDS_COUNTERS = ("SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_LD
                 "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F16")
 
 
+# stall pass: where the waves' cycles go (MI355X_MICROARCH.md: WAIT_ANY = parked at s_waitcnt / barrier, WAIT_INST_ANY = issue stall,
+# ACTIVE_INST_ANY = issuing; the three are disjoint and add up to ~WAVE_CYCLES)
+STALL_COUNTERS = ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_MISC",
+                  "SQ_INSTS_MFMA", "SQ_VALU_MFMA_COEXEC_CYCLES")
+
+
 def _available_counters(names):
     """The subset of `names` this rocprofv3 / device lists (`rocprofv3 -L`); [] when the listing itself fails."""
     import subprocess
@@ -475,15 +482,21 @@ def measure_counters(args) -> None:
     prec, B, T = args.prec, args.batch, args.views
     child = ["--prec", prec, "--batch", str(B), "--views", str(T), "--steps", "2", "--warmup", "1", "--no-graph", "--in-flight", "1",
              "--no-strict", "--no-fp8", "--no-cpu-baseline", "--no-parity", "--no-pnp", "--no-h2d", "--no-trained-like"]
-    acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES") + LDS_COUNTERS}
+    acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES") + LDS_COUNTERS + STALL_COUNTERS}
+    acc["stall:SQ_WAVE_CYCLES"] = collections.defaultdict(float)      # (SQ_WAVE_CYCLES is collected in both SQ passes: keep them apart)
     launches, dur_ns, steps_seen = collections.defaultdict(int), collections.defaultdict(float), 0
     lds_group = _available_counters(LDS_COUNTERS)          # one more pass: where the LDS time of the mainloops goes
-    groups = [("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")] + ([tuple(lds_group)] if lds_group else [])
-    for group in groups:
+    stall_group = _available_counters(STALL_COUNTERS)
+    groups = ([("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")] + ([tuple(lds_group)] if lds_group else [])
+              + ([tuple(stall_group)] if stall_group else []))
+    for gi, group in enumerate(groups):
         path = _rocprof_pass(group, child)
         first = group[0]
+        is_stall = stall_group and tuple(group) == tuple(stall_group)
         for r in csv.DictReader(open(path)):
             c, k = r["Counter_Name"], _kclass(r["Kernel_Name"])
+            if is_stall and c == "SQ_WAVE_CYCLES":
+                c = "stall:SQ_WAVE_CYCLES"
             if c in acc:
                 acc[c][k] += float(r["Counter_Value"])
             if c == first and group[0] == "SQ_VALU_MFMA_BUSY_CYCLES":
@@ -514,6 +527,15 @@ def measure_counters(args) -> None:
             per[k]["lds"]["bank_conflict_over_idx_active"] = round(acc["SQ_LDS_BANK_CONFLICT"][k] / ia, 4) if ia else None
             # LDS-array busy fraction: IDX_ACTIVE cycles are summed over the CUs' LDS arrays; the class ran `cyc` shader cycles
             per[k]["lds"]["lds_array_busy"] = round(ia / max(cyc * 256.0, 1.0), 4) if ia else None
+        if stall_group:
+            wc = acc["stall:SQ_WAVE_CYCLES"][k]
+            st = {c: round(acc[c][k] / steps_seen) for c in stall_group if c != "SQ_WAVE_CYCLES"}
+            st["SQ_WAVE_CYCLES"] = round(wc / steps_seen)
+            for c, nm in (("SQ_WAIT_ANY", "parked_at_waitcnt_or_barrier"), ("SQ_WAIT_INST_ANY", "issue_stalled"), ("SQ_ACTIVE_INST_ANY", "issuing"),
+                          ("SQ_ACTIVE_INST_VALU", "issuing_valu_incl_mfma"), ("SQ_ACTIVE_INST_MISC", "issuing_misc")):
+                if c in stall_group:
+                    st[nm + "_frac_of_wave_cycles"] = round(acc[c][k] / wc, 4) if wc else None
+            per[k]["stall"] = st
     step_classes = [k for k in launches if not k.startswith("harness")]
     tb = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"][k] for k in step_classes)
     tc = sum(acc["SQ_BUSY_CYCLES"][k] for k in step_classes) / 32.0
@@ -524,7 +546,7 @@ def measure_counters(args) -> None:
            "gemm_algorithmic_bytes_per_call": round(alg_bytes / calls),
            "gemm_traffic_over_algorithmic": round((g.get("fetch_bytes_per_step", 0) + g.get("write_bytes_per_step", 0)) / alg_bytes, 3),
            "mfma_busy_whole_step": round(tb / max(tc * 1024.0, 1.0), 4), "per_kernel_class": per,
-           "lds_counters": list(lds_group),
+           "lds_counters": list(lds_group), "stall_counters": list(stall_group),
            "how": "rocprofv3 --kernel-trace --pmc <one group per pass: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES | the LDS group> over "
                   "`bench.py " + " ".join(child) + "` (one batch at a time, un-graphed); bytes = counter KB x 1024, FETCH_SIZE x 2 (gfx950 "
                   "correction, MI355X_MICROARCH.md HBM section), WRITE_SIZE as is; MFMA busy = MFMA-busy SIMD-cycles / (SQ_BUSY_CYCLES / 32 x "
@@ -865,7 +887,7 @@ def pnp_inclusive(run: "ModeRun", one, steps: int, step_ms: float) -> dict:
     torch.cuda.synchronize()
     ovl = (time.perf_counter() - t0) / steps
     return {"pnp_ms_per_batch": round(pnp_ms, 2),
-            "host": ("cv2.solvePnP" if pnp_mod._HAVE_CV2 else "numpy batched DLT + LM, 1 thread, parity vs OpenCV un-pinned"),
+            "host": ("cv2.solvePnP" if pnp_mod._HAVE_CV2 else "bd_solve_pnp_host: native DLT + LM on 8 host threads (csrc/pnp.hip), parity vs OpenCV un-pinned"),
             "serialised_poses_per_s": round(B / ser, 1), "overlapped_poses_per_s": round(B / ovl, 1),
             "how": f"measured over {steps} batches: serialised = step -> D2H -> solve -> next step; overlapped = solver thread "
                    "on batch i while the GPU runs batch i+1 (pinned D2H + event)"}

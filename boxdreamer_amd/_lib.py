@@ -30,6 +30,24 @@ PREC_NAMES = {"bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16x3": PR
               "bf16x3_qkv16": PREC_BF16X3_QKV16, "f16c8_qkv16": PREC_F16C8_QKV16, "f16c8_qk16": PREC_F16C8_QK16,
               "f16x3": PREC_F16X3, "f16x3_attn_x3": PREC_F16X3_ATTN_X3}
 _F16X3_FAMILY = (PREC_F16X3, PREC_F16X3_ATTN_X3)
+# "fp8_mixed" (configs[4], usable form): the e4m3 class with the precision-critical Linears kept in bf16 through the per-Linear
+# promotion bits -- a POLICY over BD_PREC_FP8, not another library mode (fp8_mixed_policy below; the modules apply it at construction)
+PREC_NAMES["fp8_mixed"] = PREC_FP8
+
+
+def promoted_class(base: int) -> int:
+    """Operand class a promoted Linear runs in (include/boxdreamer_hip.h: BD_PROMOTE_*)."""
+    return PREC_F16X3 if base == PREC_F16C8 else (PREC_BF16 if base == PREC_FP8 else base)
+
+
+def fp8_mixed_policy(depth: int, normed: bool):
+    """(per-block masks, misc mask) of the mixed e4m3 mode.  e4m3 (3 mantissa bits) where the consumer is forgiving -- the MLPs and
+    DINOv2's QKV (2/3 of the Linear FLOPs); bf16 where a rounding lands on the residual stream or the heatmap un-damped: every proj,
+    BETR's QKV (its v columns decide the block's output; q, k are RMS-normalised from the rounded values), the adapter and the head
+    (per-Linear sensitivities: profiles/r3_strict_modes.md section 1, profiles/r4_fp8_mixed.md)."""
+    if normed:      # BETR
+        return [PROMOTE_QKV | PROMOTE_PROJ] * depth, PROMOTE_ADAPTER_FC1 | PROMOTE_ADAPTER_FC2 | PROMOTE_BBOX_PROJ
+    return [PROMOTE_PROJ] * depth, 0
 _X3_FAMILY = (PREC_BF16X3, PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16, 11)
 ACT_NONE, ACT_GELU = 0, 1
 # per-Linear promotion of the F16C8 family to split-bf16 (include/boxdreamer_hip.h: BD_PROMOTE_*)
@@ -101,7 +119,7 @@ EXPORTS = [
     "bd_gather_query_tokens", "bd_unpatchify_sigmoid", "bd_decode_topk",
     "bd_encoder_workspace_bytes", "bd_encoder_forward", "bd_decoder_workspace_bytes", "bd_decoder_forward",
     "bd_trace_begin", "bd_trace_end", "bd_render_corner_heatmaps", "bd_attention_q", "bd_gather_query_rows_f32",
-    "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm", "bd_solve_pnp_host",
+    "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm", "bd_solve_pnp_host", "bd_attention_prefix",
 ]
 
 _lib = None
@@ -145,6 +163,7 @@ def load() -> C.CDLL:
     lib.bd_decoder_workspace_bytes.restype = sz
     lib.bd_decoder_forward.argtypes = [C.POINTER(BetrWeights), vp, i, vp, i64, vp, i, i, i, vp, vp, vp, sz, i, vp]
     lib.bd_attention_q.argtypes = [vp, i64, vp, i64, i, i, i, i, f, vp, i, i, vp]
+    lib.bd_attention_prefix.argtypes = [vp, i64, vp, i64, i, i, i, i, f, i, i, i, vp]
     lib.bd_gather_query_rows_f32.argtypes = [vp, vp, vp, i, i, i, i, vp]
     lib.bd_render_corner_heatmaps.argtypes = [vp, i, i, i, i, vp, i, vp]
     lib.bd_dino_match_scores.argtypes = [vp, vp, i, vp, i, i, i, i, i, i, f, vp, vp, vp, vp]

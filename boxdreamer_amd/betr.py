@@ -86,6 +86,8 @@ class BETR(nn.Module):
         # one for the Linears outside the blocks; all zero until boxdreamer_amd/calibrate.py (or the caller) sets them
         self.hip_promote = [0] * num_decoder_layers
         self.hip_promote_misc = 0
+        if self.hip_precision == "fp8_mixed":
+            self.hip_promote, self.hip_promote_misc = _lib.fp8_mixed_policy(num_decoder_layers, normed=True)
         self.hip_calibration = None   # report of the last calibrate.calibrate() that looked at this decoder
 
         self.attn = nn.Sequential(*[SelfAttentionBlock(d_model, nhead) for _ in range(num_decoder_layers)])
@@ -128,7 +130,7 @@ class BETR(nn.Module):
             hit = (sig, pack.pack_betr(sd, _lib.operand_prec(prec), device, self.nhead, self.patch_size, self.img_size))
             self._packed[key] = hit
         pk = hit[1]
-        if _lib.operand_prec(prec) == _lib.PREC_F16C8:
+        if _lib.operand_prec(prec) in (_lib.PREC_F16C8, _lib.PREC_FP8):
             want = (tuple(m | _lib.PROMOTE_FC2 if m & _lib.PROMOTE_FC1 else m for m in self.hip_promote),
                     self.hip_promote_misc | (_lib.PROMOTE_ADAPTER_FC2 if self.hip_promote_misc & _lib.PROMOTE_ADAPTER_FC1 else 0), 0)
             if pk.promote != want:
@@ -139,7 +141,7 @@ class BETR(nn.Module):
     def feats_class(self, prec=None) -> int:
         """Operand class in which this decoder reads `pretrain_rgb_feat`'s 16-bit copy (the class of its adapter's first Linear)."""
         cls = _lib.operand_prec(self.hip_precision if prec is None else prec)
-        return _lib.PREC_F16X3 if (cls == _lib.PREC_F16C8 and self.hip_promote_misc & _lib.PROMOTE_ADAPTER_FC1) else cls
+        return _lib.promoted_class(cls) if self.hip_promote_misc & _lib.PROMOTE_ADAPTER_FC1 else cls
 
     def _workspace(self, need: int, dev) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:

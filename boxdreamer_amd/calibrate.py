@@ -11,7 +11,8 @@ amplifying channel -- decide the error.  They are found by MEASUREMENT on the de
   e[u]        max |logits - reference| with ONLY unit u left in the default class  (u = a block's QKV / proj / MLP / attention form,
               or one of the Linears outside the blocks)
   choice      units sorted by e[u] per unit of saved work; the longest prefix that may stay in the default class with
-              max |logits - reference| <= budget (5e-4: half the bar; the reference itself is within ~1e-4 of the fp32 forward)
+              max |logits - reference| <= budget (4e-4 on two calibration samples: the reference itself is within 0.5e-4 - 4e-4 of
+              the fp32 forward on the weight sets tried, and other samples of a batch land up to ~1.5x the calibration samples' value)
 
 Everything that is not in that prefix is PROMOTED (bd_block_weights.promote, include/boxdreamer_hip.h).  ~100 batch-1 forwards, about
 a second at load time; nothing here runs in the per-batch path.  Host logic only: the forwards are the HIP path itself.
@@ -24,7 +25,7 @@ import torch
 
 from . import _lib
 
-BUDGET = 5e-4
+BUDGET = 4e-4
 _BLOCK_UNITS = (("qkv", _lib.PROMOTE_QKV), ("proj", _lib.PROMOTE_PROJ), ("mlp", _lib.PROMOTE_FC1 | _lib.PROMOTE_FC2),
                 ("attn", _lib.PROMOTE_ATTN))
 
@@ -99,7 +100,7 @@ def self_check(encoder, decoder, images, bbox_feat, masks) -> float:
 
 
 @torch.no_grad()
-def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUDGET, promote: bool = True, max_samples: int = 1,
+def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUDGET, promote: bool = True, max_samples: int = 2,
               verbose: bool = False) -> dict:
     """Measure the default mode against the all-promoted reference on `max_samples` samples of the given batch and, if it exceeds
     `budget`, promote the cheapest sufficient set of units.  Returns (and stores in `decoder.hip_calibration`) the report; warns when

@@ -39,6 +39,8 @@ struct AttnArgs {
     float scale_log2e;
     const int32_t* q_view;   // optional: queries are rows [q_view[b]*q_len, +q_len) of every sequence, output compact
     int q_len;               // number of query rows per sequence (== seq when q_view is NULL)
+    int q_off;               // (q_view == NULL) first query row inside every sequence: queries are rows [q_off, q_off + q_len)
+    int out_rows;            // rows per sample in `out` (q_len: compact; seq with q_off: the result lands in rows [q_off, q_off + q_len))
 };
 
 constexpr int KT = 64;   // keys per tile
@@ -60,15 +62,8 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return _
 // OUTSPLIT: single-pass f16 attention whose result is written as split-bf16 (hi, lo) planes -- the strict mode's
 // attention (its GEMMs stay split-bf16 x3): q/k are RMS-normalised and P is in [0, 1], so one f16 pass costs ~1e-4 on
 // the logits while the x3 attention kernel is register-bound at one wave per SIMD.
-// RES > 0 (round 3, short sequences: DINOv2's 261 tokens = RES full 64-key tiles + a compact tail of <= 16 keys): the whole K / V of a
-// (batch, head) pair is staged into LDS ONCE -- every global load of the pair in flight together, one barrier -- by ONE workgroup
-// whose NW waves cover all queries; the key loop then runs without barriers or staging work, in 32-key steps (16 score registers
-// instead of 32: the kernel must fit 5 waves per SIMD so that TWO such workgroups share a CU and one's staging hides under the
-// other's MFMAs -- with one workgroup per CU the resident form is 20 % SLOWER than the streaming one, profiles/r3_attention_resident.md).
-// (The streaming form re-stages every tile in each of the pair's three query-block workgroups: ~40 % of its key-tile time is staging
-// work, profiles/r2_attention.md section 8.)
-template <class T, int NS, int HD, int NW, int OUTMODE = 0, int RES = 0>
-__global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) void attn_kernel(const AttnArgs p) {      // (HIP: 2nd argument = min waves per SIMD)
+template <class T, int NS, int HD, int NW, int OUTMODE = 0>
+__global__ __launch_bounds__(NW * 64, NS == 1 && HD == 64 ? 3 : 2) void attn_kernel(const AttnArgs p) {      // (HIP: 2nd argument = min waves per SIMD)
     bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 vec8;
     constexpr int NT = NW * 64;
@@ -85,10 +80,8 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) v
     constexpr int DM = HD / 32;                  // O^T M-tiles
     constexpr int KS = HD / 16;                  // k-steps of S^T
     constexpr int BUF_BYTES = NS * PLANE_BYTES;
-    constexpr int NBUF = RES ? RES : (NS == 1 ? 2 : 1);      // strict mode keeps one buffer (two planes already fill the LDS budget)
-    // RES: RES full 64-key tiles + ONE compact tail tile of <= 16 keys (DINOv2: 261 = 4 x 64 + 5): K rows 16 x KSTRIDE, V^T rows of 16 keys
-    constexpr int TAILK = 16, TAIL_K_BYTES = TAILK * KSTRIDE, TAIL_PLANE = TAIL_K_BYTES + HD * 32;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * BUF_BYTES + (RES ? NS * TAIL_PLANE : 0)];
+    constexpr int NBUF = NS == 1 ? 2 : 1;      // strict mode keeps one buffer (two planes already fill the LDS budget)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * BUF_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #ifdef BD_ATTN_PROBE
@@ -118,78 +111,9 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) v
     const T* vbase = base + 2 * heads * HD;
     const int64_t plane = p.qkv_plane;
 
-    // (RES: the pair's K / V staging loads go out FIRST, before the Q fragments and the accumulators claim their registers)
-    const int nfull = RES ? seq / KT : 0;                     // (RES: host-checked nfull <= RES and seq - nfull * KT <= TAILK)
-    if constexpr (RES > 0) {
-        // flat staging of the whole pair: K chunks and V micro-tiles of the nfull full tiles and of the compact tail spread over every
-        // thread, all loads issued before the first LDS store (registers are free here: the accumulators are not live yet)
-        constexpr int KI = (RES * KCH + NT - 1) / NT, VI = (RES * VMT + NT - 1) / NT;
-        constexpr int TKCH = TAILK * DCH, TVMT = (TAILK / 4) * DCH;          // tail: 128 K chunks, 32 V micro-tiles
-        static_assert(TKCH <= NT && TVMT <= NT, "one tail piece per thread");
-        const bool has_tail = nfull * KT < seq;
-#pragma unroll
-        for (int sp = 0; sp < NS; ++sp) {
-            u128 fk[KI], fv[VI][4], tk, tv[4];
-#pragma unroll
-            for (int i = 0; i < KI; ++i) {
-                const int c = tid + NT * i, tile = c / KCH, cc = c % KCH, row = cc / DCH, col = cc % DCH;
-                if (c < nfull * KCH) fk[i] = *(const u128*)(kbase + sp * plane + (unsigned)((tile * KT + row) * ld + col * 8));
-            }
-#pragma unroll
-            for (int i = 0; i < VI; ++i) {
-                const int vm = tid + NT * i, tile = vm / VMT, v = vm % VMT, kq = v / DCH, dc = v % DCH;
-                if (vm < nfull * VMT) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) fv[i][j] = *(const u128*)(vbase + sp * plane + (unsigned)((tile * KT + kq * 4 + j) * ld + dc * 8));
-                }
-            }
-            if (has_tail && tid < TKCH) {
-                int key = nfull * KT + tid / DCH; key = key < seq ? key : seq - 1;
-                tk = *(const u128*)(kbase + sp * plane + (unsigned)(key * ld + (tid % DCH) * 8));
-            }
-            if (has_tail && tid < TVMT) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int key = nfull * KT + (tid / DCH) * 4 + j; key = key < seq ? key : seq - 1;
-                    tv[j] = *(const u128*)(vbase + sp * plane + (unsigned)(key * ld + (tid % DCH) * 8));
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < KI; ++i) {
-                const int c = tid + NT * i, tile = c / KCH, cc = c % KCH, row = cc / DCH, col = cc % DCH;
-                if (c < nfull * KCH) *(u128*)(lds + tile * BUF_BYTES + sp * PLANE_BYTES + row * KSTRIDE + col * 16) = fk[i];
-            }
-            auto transpose_store = [&](const u128 (&r4)[4], unsigned char* vl, int rstride, int dc, int vd, bool swz) {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const unsigned a0 = r4[0][w], a1 = r4[1][w], a2 = r4[2][w], a3 = r4[3][w];
-                    const int d = dc * 8 + 2 * w;
-                    uint2 lo, hi;
-                    lo.x = pack_lo16(a0, a1); lo.y = pack_lo16(a2, a3);
-                    hi.x = pack_hi16(a0, a1); hi.y = pack_hi16(a2, a3);
-                    *(uint2*)(vl + d * rstride + (vd ^ (swz ? vswz(d) << 4 : 0))) = lo;
-                    *(uint2*)(vl + (d + 1) * rstride + (vd ^ (swz ? vswz(d + 1) << 4 : 0))) = hi;
-                }
-            };
-#pragma unroll
-            for (int i = 0; i < VI; ++i) {
-                const int vm = tid + NT * i, tile = vm / VMT, v = vm % VMT, kq = v / DCH, dc = v % DCH;
-                if (vm < nfull * VMT) {
-                    const int g = kq >> 2, qi = kq & 3, qp = (qi == 1) ? 2 : (qi == 2 ? 1 : qi);
-                    transpose_store(fv[i], lds + tile * BUF_BYTES + sp * PLANE_BYTES + K_BYTES, 128, dc, ((g * 2 + (qp >> 1)) << 4) | ((qp & 1) << 3), true);
-                }
-            }
-            unsigned char* tl = lds + RES * BUF_BYTES + sp * TAIL_PLANE;
-            if (has_tail && tid < TKCH) *(u128*)(tl + (tid / DCH) * KSTRIDE + (tid % DCH) * 16) = tk;
-            if (has_tail && tid < TVMT) {
-                const int qi = tid / DCH, qp = (qi == 1) ? 2 : (qi == 2 ? 1 : qi);        // the one 16-key group, quads 1 and 2 swapped
-                transpose_store(tv, tl + TAIL_K_BYTES, 32, tid % DCH, ((qp >> 1) << 4) | ((qp & 1) << 3), false);
-            }
-        }
-    }
     // ---- Q fragments (B operand of S^T): lane (q, h) holds Q[q][ks*16 + h*8 .. +7]
     const int q0 = qb * QB + wid * 32;                     // local query index (within the query range)
-    const int qbase_row = p.q_view ? p.q_view[b] * q_len : 0;
+    const int qbase_row = p.q_view ? p.q_view[b] * q_len : p.q_off;
     int qrow = q0 + lq; qrow = (qrow < q_len ? qrow : q_len - 1) + qbase_row;
     vec8 qf[NS][KS];
 #pragma unroll
@@ -267,93 +191,6 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) v
     const float sc = p.scale_log2e;
 
     const int nt = (seq + KT - 1) / KT;
-    if constexpr (RES > 0) {
-        __syncthreads();
-        AP(61)
-        // ---- resident key loop: 32 keys per step (one S^T M-tile, two 16-key P.V groups), no barrier, no staging
-        for (int kt = 0; kt < nt; ++kt) {
-            const bool ctail = kt >= nfull;                      // wave-uniform: the compact tail (<= 16 keys)
-            const unsigned char* cur = ctail ? lds + RES * BUF_BYTES : lds + kt * BUF_BYTES;
-            const int pstride = ctail ? TAIL_PLANE : PLANE_BYTES;
-            const bool ragged_tile = (kt + 1) * KT > seq;
-#pragma unroll
-            for (int km = 0; km < 2; ++km) {
-                if (ctail && km == 1) break;
-                f32x16 sa;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sa[r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    vec8 kf[NS];
-#pragma unroll
-                    for (int s = 0; s < NS; ++s)
-                        kf[s] = as_vec8<T>(*(const u128*)(cur + s * pstride + (km * 32 + (ctail ? (lq & (TAILK - 1)) : lq)) * KSTRIDE + (ks * 2 + lh) * 16));
-                    if (NS == 2) {
-                        sa = Op16<T>::mfma(kf[NS - 1], qf[0][ks], sa);
-                        sa = Op16<T>::mfma(kf[0], qf[NS - 1][ks], sa);
-                    }
-                    sa = Op16<T>::mfma(kf[0], qf[0][ks], sa);
-                }
-                if (ragged_tile) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kt * KT + km * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (key >= seq) sa[r] = -INFINITY;
-                    }
-                }
-                float tmax = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sa[r]);
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-                const float m_new = fmaxf(m_run, tmax);
-                if (!__all(m_new == m_run)) {
-                    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
-                    l_run *= alpha;
-#pragma unroll
-                    for (int i = 0; i < DM; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-                    m_run = m_new;
-                }
-                const float mneg = -m_run * sc;
-                float psum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sa[r], sc, mneg));
-                    sa[r] = pv;
-                    psum += pv;
-                }
-                l_run += psum;
-#pragma unroll
-                for (int gg = 0; gg < 2; ++gg) {
-                    const int g = km * 2 + gg;
-                    if (ctail && g > 0) break;
-                    vec8 pf[NS];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float pv = sa[gg * 8 + j];
-                        const T hi = from_f32<T>(pv);
-                        pf[0][j] = hi;
-                        if (NS == 2) pf[NS - 1][j] = from_f32<T>(pv - to_f32<T>(hi));
-                    }
-#pragma unroll
-                    for (int dm = 0; dm < DM; ++dm) {
-                        const int d = dm * 32 + lq;
-                        vec8 vf[NS];
-#pragma unroll
-                        for (int s = 0; s < NS; ++s)
-                            vf[s] = ctail ? as_vec8<T>(*(const u128*)(cur + s * TAIL_PLANE + TAIL_K_BYTES + d * 32 + (lh << 4)))
-                                          : as_vec8<T>(*(const u128*)(cur + s * PLANE_BYTES + K_BYTES + d * 128 + (((g * 2 + lh) ^ vswz(d)) << 4)));
-                        if (NS == 2) {
-                            oacc[dm] = Op16<T>::mfma(vf[NS - 1], pf[0], oacc[dm]);
-                            oacc[dm] = Op16<T>::mfma(vf[0], pf[NS - 1], oacc[dm]);
-                        }
-                        oacc[dm] = Op16<T>::mfma(vf[0], pf[0], oacc[dm]);
-                    }
-                }
-            }
-        }
-    } else {
     LOAD_TILE(0)
     STORE_TILE(0)
     __syncthreads();
@@ -469,7 +306,6 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) v
     };
     for (int kt = 0; kt < nt - (small_tail ? 1 : 0); ++kt) tile(kt, std::integral_constant<int, 0>{});
     if (small_tail) tile(nt - 1, std::integral_constant<int, 2>{});
-    }      // (RES == 0)
 #undef LOAD_TILE
 #undef STORE_TILE
 
@@ -480,7 +316,7 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) v
     const int q = q0 + lq;
     if (q < q_len) {
         if (OUTMODE == 2) {
-            fp8e4* orow = (fp8e4*)p.out + ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
+            fp8e4* orow = (fp8e4*)p.out + ((int64_t)b * p.out_rows + (p.out_rows == q_len ? 0 : p.q_off) + q) * (heads * HD) + head * HD;
 #pragma unroll
             for (int dm = 0; dm < DM; ++dm)
 #pragma unroll
@@ -492,7 +328,7 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) v
                 }
         } else if (OUTMODE == 3) {
             // F16C8 operand (the proj GEMM's A in the round-2 strict mode): f16 hi plane + k-permuted lo8 plane
-            const int64_t e0 = ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
+            const int64_t e0 = ((int64_t)b * p.out_rows + (p.out_rows == q_len ? 0 : p.q_off) + q) * (heads * HD) + head * HD;
 #pragma unroll
             for (int dm = 0; dm < DM; ++dm)
 #pragma unroll
@@ -505,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) v
         } else if (OUTMODE == 1 || OUTMODE == 4) {
             // (hi, lo) planes of ANOTHER 16-bit type than the kernel's operands: 1 = split-bf16, 4 = split-f16 (BD_PREC_F16X3)
             typedef typename std::conditional<OUTMODE == 1, __bf16, _Float16>::type OT;
-            OT* orow = (OT*)p.out + ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
+            OT* orow = (OT*)p.out + ((int64_t)b * p.out_rows + (p.out_rows == q_len ? 0 : p.q_off) + q) * (heads * HD) + head * HD;
 #pragma unroll
             for (int dm = 0; dm < DM; ++dm)
 #pragma unroll
@@ -523,7 +359,7 @@ __global__ __launch_bounds__(NW * 64, RES ? 5 : (NS == 1 && HD == 64 ? 3 : 2)) v
                     *(ovec4*)(orow + p.out_plane + d0) = lo;
                 }
         } else {
-            T* orow = (T*)p.out + ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
+            T* orow = (T*)p.out + ((int64_t)b * p.out_rows + (p.out_rows == q_len ? 0 : p.q_off) + q) * (heads * HD) + head * HD;
 #pragma unroll
             for (int dm = 0; dm < DM; ++dm)
 #pragma unroll
@@ -613,7 +449,7 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
     const T* vbase = base + 2 * heads * HD;
 
     const int q0 = qb * QB + wid * 32;
-    const int qbase_row = p.q_view ? p.q_view[b] * q_len : 0;
+    const int qbase_row = p.q_view ? p.q_view[b] * q_len : p.q_off;
     int qrow = q0 + lq; qrow = (qrow < q_len ? qrow : q_len - 1) + qbase_row;
     vec8 qf[KS];
 #pragma unroll
@@ -847,7 +683,7 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         constexpr int CPR = OROW / 16, HIC = HD / 8;           // 16-byte pieces per row image / of its hi plane
         static_assert((32 * CPR) % 64 == 0, "pieces per wave");
-        const int64_t row0 = (int64_t)b * q_len + q0;
+        const int64_t row0 = (int64_t)b * p.out_rows + (p.out_rows == q_len ? 0 : p.q_off) + q0;
         unsigned char* const out_hi = (unsigned char*)p.out;
         unsigned char* const out_lo = out_hi + 2 * p.out_plane;
 #pragma unroll
@@ -863,7 +699,7 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
     }
     const int q = q0 + lq;
     if (q < q_len) {
-        const int64_t e0 = ((int64_t)b * q_len + q) * (heads * HD) + head * HD;
+        const int64_t e0 = ((int64_t)b * p.out_rows + (p.out_rows == q_len ? 0 : p.q_off) + q) * (heads * HD) + head * HD;
 #pragma unroll
         for (int dm = 0; dm < DM; ++dm)
 #pragma unroll
@@ -899,10 +735,10 @@ template <class T, int HD, int OUTMODE> int launch_pp(const AttnArgs& a, hipStre
     return BD_OK;
 }
 
-template <class T, int NS, int HD, int NW, int OUTMODE = 0, int RES = 0> int launch(const AttnArgs& a, hipStream_t s) {
+template <class T, int NS, int HD, int NW, int OUTMODE = 0> int launch(const AttnArgs& a, hipStream_t s) {
     const int nqb = (a.q_len + NW * 32 - 1) / (NW * 32);
     const int slot = bd_trace_open(s, 1, a.batch * a.heads, a.seq, HD);
-    hipLaunchKernelGGL((attn_kernel<T, NS, HD, NW, OUTMODE, RES>), dim3(nqb * a.heads * a.batch), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((attn_kernel<T, NS, HD, NW, OUTMODE>), dim3(nqb * a.heads * a.batch), dim3(NW * 64), 0, s, a);
     bd_trace_close(s, slot);
     BD_CHECK_LAUNCH();
     return BD_OK;
@@ -917,12 +753,6 @@ template <class T, int NS, int OUTMODE = 0> int dispatch(const AttnArgs& a, int 
         if (head_dim == 96 && a.q_len % 256 == 0) return launch_pp<T, 96, OUTMODE>(a, s);
     }
     if (head_dim == 96) return use3 ? launch<T, NS, 96, 3, OUTMODE>(a, s) : launch<T, NS, 96, 4, OUTMODE>(a, s);
-#if defined(BD_ATTN_RES)       // A/B build (round 3): the pair's whole K / V resident in LDS, one 9-wave workgroup per pair, two per CU
-    if constexpr (NS == 1) {
-        // 4 full tiles + a tail of <= 16 keys, all queries in one 9-wave workgroup (DINOv2 at 224 px: 261 tokens); 74 KB of LDS
-        if (head_dim == 64 && !a.q_view && a.seq >= 256 && a.seq <= 272) return launch<T, NS, 64, 9, OUTMODE, 4>(a, s);
-    }
-#endif
     if (head_dim == 64) return use3 ? launch<T, NS, 64, 3, OUTMODE>(a, s) : launch<T, NS, 64, 4, OUTMODE>(a, s);
     return BD_ERR_SHAPE;
 }
@@ -936,7 +766,7 @@ extern "C" int bd_attention_q(const void* qkv, int64_t qkv_plane, void* out, int
     if (batch <= 0 || seq <= 0 || heads <= 0) return BD_ERR_SHAPE;
     if (q_view ? (q_len <= 0 || q_len > seq || seq % q_len) : (q_len != seq)) return BD_ERR_SHAPE;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return BD_ERR_ALIGN;
-    AttnArgs a{qkv, qkv_plane, out, out_plane, batch, seq, heads, scale * 1.4426950408889634f, q_view, q_len};
+    AttnArgs a{qkv, qkv_plane, out, out_plane, batch, seq, heads, scale * 1.4426950408889634f, q_view, q_len, 0, q_len};
     hipStream_t s = (hipStream_t)stream;
     switch (prec) {
         case BD_PREC_BF16: return dispatch<__bf16, 1>(a, head_dim, s);
@@ -950,6 +780,38 @@ extern "C" int bd_attention_q(const void* qkv, int64_t qkv_plane, void* out, int
         case BD_PREC_BF16X3_OUT_F16X3: return dispatch<__bf16, 2, 4>(a, head_dim, s);
         default: return BD_ERR_DTYPE;
     }
+}
+
+// prec -> (T, NS, OUTMODE) for both the tiled and the prefix kernel
+#define BD_ATTN_PREC_SWITCH(CALL)                                                       \
+    switch (prec) {                                                                     \
+        case BD_PREC_BF16: return CALL(__bf16, 1, 0);                                   \
+        case BD_PREC_F16: return CALL(_Float16, 1, 0);                                  \
+        case BD_PREC_BF16X3: return CALL(__bf16, 2, 0);                                 \
+        case BD_PREC_F16_OUT_BF16X3: return CALL(_Float16, 1, 1);                       \
+        case BD_PREC_BF16_OUT_FP8: return CALL(__bf16, 1, 2);                           \
+        case BD_PREC_F16_OUT_F16C8: return CALL(_Float16, 1, 3);                        \
+        case BD_PREC_BF16X3_OUT_F16C8: return CALL(__bf16, 2, 3);                       \
+        case BD_PREC_F16_OUT_F16X3: return CALL(_Float16, 1, 4);                        \
+        case BD_PREC_BF16X3_OUT_F16X3: return CALL(__bf16, 2, 4);                       \
+        default: return BD_ERR_DTYPE;                                                   \
+    }
+
+extern "C" int bd_attention_prefix(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch, int seq, int heads,
+                                   int head_dim, float scale, int n_prefix, int prefix_queries, int prec, void* stream) {
+    if (!qkv || !out) return BD_ERR_NULL;
+    if (batch <= 0 || seq <= 0 || heads <= 0 || n_prefix <= 0 || n_prefix >= seq) return BD_ERR_SHAPE;
+    // With the prefix queries wanted, one launch over all seq queries IS the fastest form measured (profiles/r4_attention.md: a separate
+    // launch for the prefix rows re-reads the pair's K / V -- 154 MB per DINOv2 launch -- and costs more than the ninth query wave it
+    // saves); without them, the patch queries alone tile exactly.
+    if (prefix_queries) return bd_attention_q(qkv, qkv_plane, out, out_plane, batch, seq, heads, head_dim, scale, nullptr, seq, prec, stream);
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return BD_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    // the seq - n_prefix queries behind the prefix, all keys; result rows [n_prefix, seq) of every sample, the others untouched
+    AttnArgs a{qkv, qkv_plane, out, out_plane, batch, seq, heads, scale * 1.4426950408889634f, nullptr, seq - n_prefix, n_prefix, seq};
+#define BD_CALL_MAIN(T_, NS_, OM_) dispatch<T_, NS_, OM_>(a, head_dim, s)
+    BD_ATTN_PREC_SWITCH(BD_CALL_MAIN)
+#undef BD_CALL_MAIN
 }
 
 extern "C" int bd_attention(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch,

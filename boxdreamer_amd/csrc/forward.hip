@@ -66,12 +66,15 @@ inline bool x3_f16_attention(int prec, bool qk_normed) {
     return prec == BD_PREC_BF16X3_ATTN_F16 || ((prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16X3) && qk_normed);
 }
 inline bool split16(int cls) { return cls == BD_PREC_BF16X3 || cls == BD_PREC_F16X3; }
-// operand class of a Linear of the F16C8 family: split-f16 when its BD_PROMOTE_* bit is set (include/boxdreamer_hip.h)
-inline int lin_class(int base, int promote, int bit) { return (base == BD_PREC_F16C8 && (promote & bit)) ? BD_PREC_F16X3 : base; }
-// fc1 -> fc2 and adapter fc1 -> fc2 hand-offs: a split-f16 GEMM cannot emit the F16C8 operand, so promoting the first promotes the second
+// operand class of a Linear whose BD_PROMOTE_* bit is set (include/boxdreamer_hip.h): F16C8 family -> split-f16, e4m3 -> bf16
+inline int promoted_class(int base) { return base == BD_PREC_F16C8 ? BD_PREC_F16X3 : (base == BD_PREC_FP8 ? BD_PREC_BF16 : base); }
+inline int lin_class(int base, int promote, int bit) { return (promote & bit) ? promoted_class(base) : base; }
+// fc1 -> fc2 and adapter fc1 -> fc2 hand-offs: a promoted GEMM cannot emit the base operand class, so promoting the first promotes the second
 inline int norm_promote(int pm) { return (pm & BD_PROMOTE_FC1) ? (pm | BD_PROMOTE_FC2) : pm; }
 // output kind (bd_gemm_args.out_f32) with which a GEMM of class `from` writes the A operand of a Linear of class `to`
-inline int handoff_kind(int from, int to) { return from == to ? 0 : 5 /* F16C8 GEMM -> split-f16 planes */; }
+inline int handoff_kind(int from, int to) {
+    return from == to ? 0 : (to == BD_PREC_BF16 ? 3 /* e4m3 GEMM -> bf16 plane */ : 5 /* F16C8 GEMM -> split-f16 planes */);
+}
 
 // How one transformer block runs: the operand class of each Linear (F16C8 family: per-Linear promotion to split-bf16), the attention
 // form, and the 16-bit kinds in which producers hand their results on.
@@ -88,7 +91,7 @@ inline BlockPlan plan_block(const bd_block_weights& w, int wprec) {
     BlockPlan p{};
     p.base = gemm_prec(wprec);
     const bool c8 = p.base == BD_PREC_F16C8, f8 = p.base == BD_PREC_FP8, normed = w.q_norm_w != nullptr;
-    const int pm = c8 ? norm_promote(w.promote) : 0;
+    const int pm = (c8 || f8) ? norm_promote(w.promote) : 0;
     p.c_qkv = lin_class(p.base, pm, BD_PROMOTE_QKV);
     p.c_proj = lin_class(p.base, pm, BD_PROMOTE_PROJ);
     p.c_fc1 = lin_class(p.base, pm, BD_PROMOTE_FC1);
@@ -98,12 +101,12 @@ inline BlockPlan plan_block(const bd_block_weights& w, int wprec) {
     p.qk16 = qk_single_f16(wprec) && p.hyb && w.qkv16.w && plain_qkv;
     p.qkv16 = qkv_single_f16(wprec) && p.hyb && w.qkv16.w && plain_qkv;
     if (p.hyb) { p.qkv_out = 2; p.aprec_in = BD_PREC_F16; }                                  // one f16 plane
-    else if (f8) { p.qkv_out = 3; p.aprec_in = BD_PREC_BF16; }                                // one bf16 plane
+    else if (f8) { p.qkv_out = p.c_qkv == BD_PREC_FP8 ? 3 : 0; p.aprec_in = BD_PREC_BF16; }   // one bf16 plane (an e4m3 or a bf16 GEMM's)
     else if (p.c_qkv == BD_PREC_F16C8 || p.c_qkv == BD_PREC_F16X3) { p.qkv_out = 4; p.aprec_in = BD_PREC_BF16X3; }   // split-bf16 planes for
                                                                                               // the split-bf16 attention (range: probabilities)
     else { p.qkv_out = 0; p.aprec_in = p.c_qkv; }                                             // the GEMM's own operand class
     if (p.hyb) p.aprec = p.c_proj == BD_PREC_F16C8 ? BD_PREC_F16_OUT_F16C8 : (p.c_proj == BD_PREC_F16X3 ? BD_PREC_F16_OUT_F16X3 : BD_PREC_F16_OUT_BF16X3);
-    else if (f8) p.aprec = BD_PREC_BF16_OUT_FP8;
+    else if (f8) p.aprec = p.c_proj == BD_PREC_FP8 ? BD_PREC_BF16_OUT_FP8 : BD_PREC_BF16;
     else if (p.aprec_in == BD_PREC_BF16X3)
         p.aprec = p.c_proj == BD_PREC_F16C8 ? BD_PREC_BF16X3_OUT_F16C8 : (p.c_proj == BD_PREC_F16X3 ? BD_PREC_BF16X3_OUT_F16X3 : BD_PREC_BF16X3);
     else p.aprec = p.base;
@@ -182,12 +185,19 @@ int proj_mlp_stage(const bd_block_weights& w, const BlockPlan& p, const BlockBuf
 
 // One pre-LN transformer block: x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x))).
 // BETR: blocks.py:876-886 (+ q/k RMSNorm :257); DINOv2: layers/block.py:89-114 (LayerScale folded).
+// n_prefix > 0 (DINOv2: cls + registers lead every image's tokens) and prefix_queries == false: the block's prefix rows are never read
+// again (last encoder block), so their attention is skipped (bd_attention_prefix) -- proj and the MLP then run on stale attention
+// rows there, whose results nobody consumes (row-wise operators: nothing leaks into the patch rows).
 int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, int seq, int D, int heads, float ln_eps, float rms_eps,
-              int wprec, void* stream) {
+              int wprec, void* stream, int n_prefix = 0, bool prefix_queries = true) {
     const BlockPlan p = plan_block(w, wprec);
     const int hd = D / heads;
     BD_TRY(qkv_stage(w, p, b, M, D, heads, ln_eps, rms_eps, stream));
-    BD_TRY(bd_attention(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)M * D, batch, seq, heads, hd, 1.0f / sqrtf((float)hd), p.aprec, stream));
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (n_prefix > 0 && seq > n_prefix && !prefix_queries)
+        BD_TRY(bd_attention_prefix(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)M * D, batch, seq, heads, hd, scale, n_prefix, 0, p.aprec, stream));
+    else
+        BD_TRY(bd_attention(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)M * D, batch, seq, heads, hd, scale, p.aprec, stream));
     return proj_mlp_stage(w, p, b, b.x, M, D, ln_eps, stream);
 }
 
@@ -271,7 +281,7 @@ extern "C" int bd_encoder_forward(const bd_dino_weights* w, const void* images, 
     if (n_images <= 0 || size != w->grid * w->patch || w->dim % w->heads || w->kpad % 64 ||
         w->kpad < 3 * w->patch * w->patch)
         return BD_ERR_SHAPE;
-    if (w->feats_prec != 0 && !(w->feats_prec == prec || (prec == BD_PREC_F16C8 && w->feats_prec == BD_PREC_F16X3))) return BD_ERR_DTYPE;
+    if (w->feats_prec != 0 && !(w->feats_prec == prec || w->feats_prec == promoted_class(prec))) return BD_ERR_DTYPE;
     const int feats_prec = w->feats_prec ? w->feats_prec : prec;
     if ((uintptr_t)workspace & 255) return BD_ERR_ALIGN;
     const EncBufs e = carve_encoder(w, n_images, prec, workspace);
@@ -281,7 +291,7 @@ extern "C" int bd_encoder_forward(const bd_dino_weights* w, const void* images, 
 
     // K1+K2: normalise + im2col, then the patch-embed GEMM scattering rows b*P+p -> b*tpi+n_prefix+p and
     // adding the (pre-resampled) positional table  (vision_transformer.py:213-232, patch_embed.py:65-75)
-    const int c_pe = lin_class(prec, w->promote_misc, BD_PROMOTE_PATCH_EMBED);
+    const int c_pe = lin_class(prec, (prec == BD_PREC_F16C8 || prec == BD_PREC_FP8) ? w->promote_misc : 0, BD_PROMOTE_PATCH_EMBED);
     BD_TRY(bd_im2col_images(images, img_dtype, e.a_patch, (int64_t)Mp * w->kpad, n_images, size, w->patch, w->kpad,
                             c_pe, stream));
     {
@@ -293,7 +303,7 @@ extern "C" int bd_encoder_forward(const bd_dino_weights* w, const void* images, 
     }
     BD_TRY(bd_write_prefix_tokens(e.blk.x, w->prefix_tokens, n_images, tpi, w->n_prefix, D, stream));
     for (int i = 0; i < w->depth; ++i)
-        BD_TRY(run_block(w->blocks[i], e.blk, Md, n_images, tpi, D, w->heads, w->ln_eps, 0.f, wprec, stream));
+        BD_TRY(run_block(w->blocks[i], e.blk, Md, n_images, tpi, D, w->heads, w->ln_eps, 0.f, wprec, stream, w->n_prefix, i + 1 < w->depth));
     // final LayerNorm on the patch tokens only (vision_transformer.py:263-267); feats16 in the class the consumer's first Linear reads
     BD_TRY(bd_layernorm(e.blk.x, D, w->norm_w, w->norm_b, w->ln_eps, feats16, feats16_plane, feats32, D, Mp, D, P, tpi,
                         w->n_prefix, feats_prec, stream));
@@ -323,7 +333,8 @@ extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_fea
     const int64_t pD = (int64_t)Mb * D;
 
     // operand classes of the Linears outside the blocks (F16C8 family: per-Linear promotion, include/boxdreamer_hip.h)
-    const int pmisc = (w->promote_misc & BD_PROMOTE_ADAPTER_FC1) ? (w->promote_misc | BD_PROMOTE_ADAPTER_FC2) : w->promote_misc;
+    const int pm0 = (prec == BD_PREC_F16C8 || prec == BD_PREC_FP8) ? w->promote_misc : 0;
+    const int pmisc = (pm0 & BD_PROMOTE_ADAPTER_FC1) ? (pm0 | BD_PROMOTE_ADAPTER_FC2) : pm0;
     const int c_a1 = lin_class(prec, pmisc, BD_PROMOTE_ADAPTER_FC1), c_a2 = lin_class(prec, pmisc, BD_PROMOTE_ADAPTER_FC2);
     const int c_be = lin_class(prec, pmisc, BD_PROMOTE_BBOX_EMB), c_bp = lin_class(prec, pmisc, BD_PROMOTE_BBOX_PROJ);
     // K6 adapter: LN_noaffine(fc2(gelu(fc1(feat))))  (betr.py:313-317); feats16 arrives in the class of adapter fc1

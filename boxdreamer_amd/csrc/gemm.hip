@@ -208,8 +208,12 @@ __device__ __forceinline__ void gemm_epilogue(const bd_gemm_args& p, f32x16 (&ac
 // global reads two passes at a time instead of four.
 template <class T, int NS, int MI, int NI, int SR = 32, bool LEAN = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], unsigned char* scratch,
-                                                  int wm0, int wn0, int lane) {
+                                                  int wm0, int wn0, int lane_) {
     constexpr int COLS = NI * 32;                      // wave-tile width (fp32 words per scratch row)
+    int lane = lane_;
+    if constexpr (LEAN) {     // persistent kernels: keep the epilogue's lane-dependent addressing out of the K loop's live ranges (pc_epilogue)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    }
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int M = p.M, N = p.N;
     const float* resid = resid_in_acc(p) ? nullptr : p.resid;      // else already in the accumulators (acc_init)
@@ -587,8 +591,15 @@ __device__ __forceinline__ float quad_sum(float x) {
 //   next: the wave tile origin of this workgroup's next tile (EP 3 pre-loads its residual), has_next = there is one
 template <class T, int NS, int EP, int OUTK, bool GELU, int MI = 2>
 __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)[MI][3], float* sc, const float* colp, const float* colp_next,
-                                            const float* rmsw, int wcol, int wm0, int wn0, int lane, bool has_next, int nwm0, int nwn0) {
+                                            const float* rmsw, int wcol, int wm0, int wn0, int lane_, bool has_next, int nwm0, int nwn0) {
     constexpr int COLS = 96;
+    // The lane id is re-derived HERE from an opaque instruction pair, so that none of the epilogue's lane-dependent addressing can be
+    // hoisted above the K loop, whose register budget (168) is full: hoisted, three of those values were spilled in the F16C8 / e4m3
+    // instances and RELOADED inside the epilogue -- a vector-memory load whose s_waitcnt vmcnt(0) also waited for the 24 residual
+    // pre-loads of the chunk before the first row could be stored (round 4; the build now fails on a spill, boxdreamer_amd/build.py).
+    (void)lane_;
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int M = p.M;
     float bj[3], sj[3];

@@ -54,7 +54,10 @@ class DinoV2Encoder:
         # per-Linear promotion of the F16C8 family to split-bf16 (include/boxdreamer_hip.h: BD_PROMOTE_*), set by calibrate.py
         self.promote = [0] * depth
         self.promote_misc = 0
-        self.feats_prec = 0          # 0: feats16 in the class of `prec`; PREC_F16X3 when the decoder's adapter fc1 is promoted
+        self.feats_prec = 0          # 0: feats16 in the class of `prec`; the promoted class when the decoder's adapter fc1 is promoted
+        if prec == "fp8_mixed":      # (the decoder's mixed policy keeps its adapter in bf16: hand the features over in bf16)
+            self.promote, self.promote_misc = _lib.fp8_mixed_policy(depth, normed=False)
+            self.feats_prec = _lib.PREC_BF16
 
     def _check_not_frozen(self, what: str):
         if len(self._frozen_by):
@@ -85,7 +88,7 @@ class DinoV2Encoder:
         if key not in self._packed:
             self._packed[key] = pack.pack_dino(self.sd, _lib.operand_prec(prec), self.device, self.heads, self.patch, size)
         pk = self._packed[key]
-        if _lib.operand_prec(prec) == _lib.PREC_F16C8:
+        if _lib.operand_prec(prec) in (_lib.PREC_F16C8, _lib.PREC_FP8):
             want = (tuple(m | _lib.PROMOTE_FC2 if m & _lib.PROMOTE_FC1 else m for m in self.promote), self.promote_misc, self.feats_prec)
             if pk.promote != want:
                 self._check_not_frozen("changing the per-Linear promotion")
@@ -95,7 +98,7 @@ class DinoV2Encoder:
     def feats_class(self, prec=None) -> int:
         """Operand class of the 16-bit feature copy `patch_tokens` hands to the decoder."""
         cls = _lib.operand_prec(self.prec if prec is None else prec)
-        return self.feats_prec if (cls == _lib.PREC_F16C8 and self.feats_prec) else cls
+        return self.feats_prec if (cls in (_lib.PREC_F16C8, _lib.PREC_FP8) and self.feats_prec) else cls
 
     @torch.no_grad()
     def patch_tokens(self, images: torch.Tensor, prec=None):

@@ -178,6 +178,16 @@ def attention(qkv16, batch, seq, heads, head_dim, scale, *, prec="bf16"):
     return out
 
 
+def attention_prefix(qkv16, batch, seq, heads, head_dim, scale, n_prefix, *, prec="bf16", prefix_queries=True, out=None):
+    """bd_attention_prefix: patch queries in the tiled kernel, the n_prefix leading queries in a side launch (or skipped)."""
+    lib = _lib.load()
+    if out is None:
+        out = _alloc16(batch * seq, heads * head_dim, prec, qkv16.device)
+    check(lib.bd_attention_prefix(ptr(qkv16), _plane(qkv16, prec), ptr(out), _plane(out, prec), batch, seq, heads, head_dim, scale,
+                                  n_prefix, int(bool(prefix_queries)), prec_id(prec), stream()), "bd_attention_prefix")
+    return out
+
+
 def attention_q(qkv16, batch, seq, heads, head_dim, scale, q_view, q_len, *, prec="bf16"):
     """Attention with queries restricted to rows [q_view[b]*q_len, +q_len) of each sequence; compact output."""
     lib = _lib.load()

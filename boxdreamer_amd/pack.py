@@ -173,9 +173,9 @@ class Packed:
         state = (tuple(masks), int(misc), int(feats_prec))
         if state == self.promote:
             return
-        if (any(masks) or misc or feats_prec) and self.base != _lib.PREC_F16C8:
-            raise ValueError("per-Linear promotion exists for the F16C8 family only")
-        x3 = _lib.PREC_F16X3
+        if (any(masks) or misc or feats_prec) and self.base not in (_lib.PREC_F16C8, _lib.PREC_FP8):
+            raise ValueError("per-Linear promotion exists for the F16C8 family (-> split-f16) and for fp8 (-> bf16) only")
+        x3 = _lib.promoted_class(self.base)
         for i, (bw, pre) in enumerate(zip(self.blocks, self.block_names)):
             m = masks[i]
             bw.qkv = self.linear_of(pre + "qkv", x3 if m & _lib.PROMOTE_QKV else None)

@@ -189,6 +189,14 @@ int bd_attention(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plan
 int bd_attention_q(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch, int seq,
                    int heads, int head_dim, float scale, const int32_t* q_view, int q_len, int prec, void* stream);
 
+/* bd_attention for a sequence whose first n_prefix tokens are not patch tokens (DINOv2: cls + registers,
+ * vision_transformer.py:219-230).  prefix_queries != 0: exactly bd_attention (one launch over all queries: measured faster than any
+ * split, profiles/r4_attention.md).  prefix_queries == 0: only the seq - n_prefix patch queries are computed (all keys; exact query
+ * tiles) and rows [0, n_prefix) of every sample in `out` are left untouched -- the LAST encoder block, whose prefix rows
+ * x_norm_patchtokens drops (vision_transformer.py:263-267).  Patch rows are bit-identical between the two forms. */
+int bd_attention_prefix(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch, int seq, int heads,
+                        int head_dim, float scale, int n_prefix, int prefix_queries, int prec, void* stream);
+
 /* (x - mean_c) / std_c, then 14x14 patches -> A operand rows [n*grid*grid, kpad], k = c*p*p + py*p + px,
  * zero-padded to kpad.  Replaces encoder/dinov2.py:45-46,56 + the unfold inside the patch-embed conv. */
 int bd_im2col_images(const void* images, int img_dtype, void* out16, int64_t out_plane, int n_images,
@@ -277,7 +285,9 @@ typedef struct bd_linear {
  * boxdreamer_amd/calibrate.py) need the ~22 bits of the split-f16 class (BD_PREC_F16X3) to keep the heatmap logits inside 1e-3.  A set bit means:
  * THIS Linear's weight (`bd_linear.w`) is packed as BD_PREC_F16X3 planes and the whole-path entry points run it as a split-f16
  * product; the producer of its A operand (LayerNorm, attention, the fc1 epilogue) emits split-f16 planes instead of the F16C8
- * operand.  Honoured only when `prec` is BD_PREC_F16C8 / _QKV16 / _QK16 (ignored otherwise).  With every bit set the path is
+ * operand.  Honoured when `prec` is BD_PREC_F16C8 / _QKV16 / _QK16, and -- the same bits, the same hand-offs -- when it is BD_PREC_FP8,
+ * where a set bit moves the Linear from e4m3 to BD_PREC_BF16 (the mixed e4m3 policy of configs[4]: "fp8_mixed" in
+ * boxdreamer_amd/_lib.py); ignored otherwise.  With every bit set the path is
  * bit-identical to BD_PREC_F16X3_ATTN_X3. */
 #define BD_PROMOTE_QKV 1
 #define BD_PROMOTE_PROJ 2

@@ -408,6 +408,90 @@ def test_attention_f16c8_output_variants(hip, variant, batch, seq, heads, hd):
     assert (hi.cpu().reshape(batch, seq, heads, hd) - got).abs().max().item() <= 2.0 ** -11 * max(1.0, got.abs().max().item())
 
 
+_PREFIX_VARIANTS = {   # name -> (input operand class, attention code, how to read the result)
+    "bf16": ("bf16", "PREC_BF16", "native"), "fp16": ("fp16", "PREC_F16", "native"), "bf16x3": ("bf16x3", "PREC_BF16X3", "planes"),
+    "f16_out_bf16x3": ("fp16", "PREC_F16_OUT_BF16X3", "planes_bf16"), "bf16_out_fp8": ("bf16", "PREC_BF16_OUT_FP8", "fp8"),
+    "f16_out_f16c8": ("fp16", "PREC_F16_OUT_F16C8", "f16c8"), "bf16x3_out_f16c8": ("bf16x3", "PREC_BF16X3_OUT_F16C8", "f16c8"),
+    "f16_out_f16x3": ("fp16", "PREC_F16_OUT_F16X3", "planes_f16"), "bf16x3_out_f16x3": ("bf16x3", "PREC_BF16X3_OUT_F16X3", "planes_f16")}
+
+
+@pytest.mark.parametrize("variant", sorted(_PREFIX_VARIANTS))
+@pytest.mark.parametrize("batch,seq,heads,npre", [(3, 261, 12, 5), (2, 70, 2, 1), (1, 320, 3, 8), (1, 517, 2, 5)])
+def test_attention_prefix_split(hip, variant, batch, seq, heads, npre):
+    """bd_attention_prefix (round 4): with prefix_queries = 0 only the patch queries run (exact tiles; the last DINOv2 block), their rows
+    bit-identical to bd_attention's and the prefix rows of `out` untouched; with prefix_queries = 1 it is bd_attention.  Every attention
+    code the whole-path entry points use, against fp64 torch on the operands as stored."""
+    from boxdreamer_amd import _lib
+    hd = 64
+    in_prec, code, kind = _PREFIX_VARIANTS[variant]
+    pid = getattr(_lib, code)
+    qkv = _rand("attp", (batch, seq, 3, heads, hd), 1.0)
+    qkv[:, :, 0] *= 1.7
+    qkv[:, min(150, seq - 1), 1] = qkv[:, 3, 0] * 3.0
+    qkv[:, 0, 0] *= 2.5                                             # a peaked prefix query
+    t = hip_ops.to_operand(qkv.reshape(batch * seq, -1).cuda(), in_prec)
+    src = _q(qkv.reshape(batch * seq, -1), in_prec).reshape(batch, seq, 3, heads, hd).double()
+    q, k, v = (src[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = (((q @ k.transpose(-1, -2)) * hd ** -0.5).softmax(-1) @ v).permute(0, 2, 1, 3).float()
+    lib = _lib.load()
+    qkv_plane = t[0].numel() if in_prec == "bf16x3" else 0
+
+    def alloc():
+        if kind == "native":
+            return torch.full((batch * seq, heads * hd), 7.0, dtype=_lib.op_dtype(in_prec), device="cuda")
+        if kind == "fp8":
+            return torch.full((batch * seq, heads * hd), 7.0, device="cuda").to(torch.float8_e4m3fn)
+        dt = torch.bfloat16 if kind in ("planes", "planes_bf16") else torch.float16
+        return torch.full((2, batch * seq, heads * hd), 7.0, dtype=dt, device="cuda")
+
+    def read(o):
+        if kind in ("native", "fp8"):
+            return o.float().cpu().reshape(batch, seq, heads, hd)
+        if kind == "f16c8":
+            hi, lo, _ = hip_ops.f16c8_decode(o)
+            return (hi + lo).cpu().reshape(batch, seq, heads, hd)
+        return (o[0].float() + o[1].float()).cpu().reshape(batch, seq, heads, hd)
+
+    plane = lambda o: 0 if kind in ("native", "fp8") else o[0].numel()
+    one = alloc()
+    _lib.check(lib.bd_attention(_lib.ptr(t), qkv_plane, _lib.ptr(one), plane(one), batch, seq, heads, hd, hd ** -0.5, pid, _lib.stream()),
+               "bd_attention")
+    two = alloc()
+    _lib.check(lib.bd_attention_prefix(_lib.ptr(t), qkv_plane, _lib.ptr(two), plane(two), batch, seq, heads, hd, hd ** -0.5, npre, 1, pid,
+                                       _lib.stream()), "bd_attention_prefix")
+    skip = alloc()
+    keep = skip.clone()
+    _lib.check(lib.bd_attention_prefix(_lib.ptr(t), qkv_plane, _lib.ptr(skip), plane(skip), batch, seq, heads, hd, hd ** -0.5, npre, 0, pid,
+                                       _lib.stream()), "bd_attention_prefix")
+    torch.cuda.synchronize()
+    g1, g2, g3 = read(one), read(two), read(skip)
+    in_eps = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11, "bf16x3": 2.0 ** -15}[in_prec]
+    scale = max(1.0, ref.abs().max().item())
+    if kind == "fp8":
+        tol = ref.abs() * 2.0 ** -4 + 2.0 ** -10 + 6 * 2.0 ** -8
+        assert ((g2 - ref).abs() <= tol).all()
+    else:
+        out_eps = {"native": in_eps, "planes": 2.0 ** -15, "planes_bf16": 2.0 ** -15, "planes_f16": 2.0 ** -20, "f16c8": 2.0 ** -15}[kind]
+        err = (g2 - ref).abs().max().item()
+        assert err < 6 * max(in_eps, out_eps) * scale + 2e-5, (variant, err)
+    assert torch.equal(g2[:, :npre], g1[:, :npre])                  # prefix_queries = 1 IS bd_attention
+    # patch rows: same kernel, same tiles' arithmetic as the one-launch form (query blocks are cut differently: not bit-identical by
+    # construction only where a block boundary changes which lanes share an online-softmax rescale -- it does not: per-row arithmetic)
+    assert torch.equal(g2[:, npre:], g1[:, npre:])
+    assert torch.equal(g3[:, npre:], g2[:, npre:])
+    # skipped prefix queries: every byte of those rows is as the caller left it (F16C8's lo8 plane is packed row-wise into the plane's
+    # first half: compare the hi plane rows and the packed lo8 rows)
+    if kind in ("native", "fp8"):
+        rows = lambda o: o.view(torch.uint8).reshape(batch, seq, -1)[:, :npre]
+        assert torch.equal(rows(skip), rows(keep))
+    elif kind == "f16c8":
+        assert torch.equal(skip[0].reshape(batch, seq, -1)[:, :npre], keep[0].reshape(batch, seq, -1)[:, :npre])
+        lo8 = lambda o: o[1].view(torch.uint8).reshape(-1)[: batch * seq * heads * hd].reshape(batch, seq, -1)[:, :npre]
+        assert torch.equal(lo8(skip), lo8(keep))
+    else:
+        assert torch.equal(skip.reshape(2, batch, seq, -1)[:, :, :npre], keep.reshape(2, batch, seq, -1)[:, :, :npre])
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_im2col_and_patchify(hip, prec):
     data = synth.make_batch(seed=21, B=1, T=2)

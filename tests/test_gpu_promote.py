@@ -120,7 +120,7 @@ def test_plain_weights_need_no_promotion(hip):
     assert rep["ok"] and rep["promoted"] == [] and rep["delta_unpromoted"] <= calibrate.BUDGET
     assert not any(enc.model.promote) and not any(dec.hip_promote) and enc.model.feats_prec == 0
     assert torch.equal(_logits(enc, dec, img, bf, mask), before)
-    assert calibrate.self_check(enc, dec, img[:1], bf[:1], mask[:1]) == pytest.approx(rep["delta_unpromoted"], abs=1e-6)
+    assert calibrate.self_check(enc, dec, img[:2], bf[:2], mask[:2]) == pytest.approx(rep["delta_unpromoted"], abs=1e-6)
     # modes outside the F16C8 family: nothing to do, said so
     enc2, dec2 = _pair("bf16", 2, 2)
     assert calibrate.calibrate(enc2, dec2, img, bf, mask)["applicable"] is False

@@ -337,3 +337,20 @@ def test_precision_ids():
             src = open(os.path.join(ROOT, "boxdreamer_amd", "csrc", f)).read()
             assert "getenv" not in src, f
             assert "BD_EXP_" not in src, f
+
+
+def test_build_recorded_no_register_spills_in_the_tuned_kernels():
+    """the hand-tuned MFMA kernels run at the edge of their register budgets (168 / 256 VGPRs); a hipcc change that makes one
+    of them spill would cost 10-40 % silently.  boxdreamer_amd/build.py records every kernel's resources from hipcc's own remarks and
+    FAILS the build on a spill outside its documented allow-list; this checks the record that belongs to the shipped library."""
+    import json
+    from boxdreamer_amd import build
+    path = build.RESOURCES
+    assert os.path.exists(path), "build the library with boxdreamer_amd.build (it writes csrc/_obj/resources.json)"
+    res = json.load(open(path))
+    assert len(res) > 100 and any("gemm_kernel_pc" in k for k in res) and any("attn_kernel_pp" in k for k in res)
+    assert build.check_spills(res) == {}
+    # the specialised epilogues of the persistent GEMMs (every block Linear) are spill-free outright
+    for k, v in res.items():
+        if "gemm_kernel_pc" in k and not re.search(r"Li0ELi0ELb0EE", k):
+            assert v.get("ScratchSize", 0) == 0, (k, v)
