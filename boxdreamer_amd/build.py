@@ -21,7 +21,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJDIR = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libboxdreamer_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "layout.hip", "decode.hip", "match.hip", "pnp.hip", "forward.hip", "trace.hip"]
+SOURCES = ["gemm.hip", "gemm_f16c8.hip", "attention.hip", "norm.hip", "layout.hip", "decode.hip", "match.hip", "pnp.hip", "forward.hip", "trace.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 RESOURCES = os.path.join(OBJDIR, "resources.json")      # per kernel: VGPRs, scratch bytes, LDS, occupancy (hipcc's own remarks)
 # MFMA kernel families whose register budgets are hand-tuned: a scratch spill there is a silent 10-40 % regression (a spill reload is a

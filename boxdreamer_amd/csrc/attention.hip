@@ -351,9 +351,10 @@ __global__ __launch_bounds__(NW * 64, NS == 1 && HD == 64 ? 3 : 2) void attn_ker
                     ovec4 hi, lo;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float v = oacc[dm][rq * 4 + j] * inv;
-                        hi[j] = from_f32<OT>(v);
-                        lo[j] = from_f32<OT>(v - to_f32<OT>(hi[j]));
+                        float h, l;
+                        split_hi_lo<OT>(oacc[dm][rq * 4 + j] * inv, h, l);
+                        hi[j] = from_f32<OT>(h);
+                        lo[j] = from_f32<OT>(l);
                     }
                     *(ovec4*)(orow + d0) = hi;
                     *(ovec4*)(orow + p.out_plane + d0) = lo;
@@ -369,9 +370,14 @@ __global__ __launch_bounds__(NW * 64, NS == 1 && HD == 64 ? 3 : 2) void attn_ker
                     vec4 hi, lo;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float v = oacc[dm][rq * 4 + j] * inv;
-                        hi[j] = from_f32<T>(v);
-                        if (NS == 2) lo[j] = from_f32<T>(v - to_f32<T>(hi[j]));
+                        if (NS == 2) {
+                            float h, l;
+                            split_hi_lo<T>(oacc[dm][rq * 4 + j] * inv, h, l);
+                            hi[j] = from_f32<T>(h);
+                            lo[j] = from_f32<T>(l);
+                        } else {
+                            hi[j] = from_f32<T>(oacc[dm][rq * 4 + j] * inv);
+                        }
                     }
                     *(vec4*)(orow + d0) = hi;
                     if (NS == 2) *(vec4*)(orow + p.out_plane + d0) = lo;
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
                     typedef typename std::conditional<OUTMODE == 1, __bf16, _Float16>::type OT;
                     float hi4[4], lo4[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { hi4[j] = to_f32<OT>(from_f32<OT>(v4[j])); lo4[j] = v4[j] - hi4[j]; }
+                    for (int j = 0; j < 4; ++j) split_hi_lo<OT>(v4[j], hi4[j], lo4[j]);
                     store_cvt<OT, 4>((OT*)p.out + e, hi4);
                     store_cvt<OT, 4>((OT*)p.out + p.out_plane + e, lo4);
                 } else {

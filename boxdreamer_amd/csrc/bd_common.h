@@ -228,13 +228,24 @@ template <bool FAST> __device__ __forceinline__ float gelu_sel(float x) { return
 
 // ---- 8 consecutive elements of a GEMM A-operand from fp32 (every producer: LayerNorm, GEMM epilogue, attention output,
 // im2col / patchify / gather): base = plane 0, e = element index (multiple of 8), plane = 2-byte units between the planes
+// (hi, lo) of a split 16-bit class: hi = T(v), lo = v - hi, both as fp32.  The value is made opaque first (as in store_cvt): hi must
+// be the rounding of the SAME fp32 number lo is taken against.  Left alone, hipcc folds the producer's last multiply into the f16
+// conversion (v_fma_mix*: one rounding) at one use and not at the other, and in near-tie cases the stored hi and the hi that lo was
+// computed against differ by an f16 ulp (found by tests/test_gpu_ops.py::test_attention_prefix_split, round 4; bf16 has no such
+// instruction and is unaffected).
+template <class T> __device__ __forceinline__ void split_hi_lo(float v, float& hi, float& lo) {
+    asm("" : "+v"(v));
+    hi = to_f32<T>(from_f32<T>(v));
+    asm("" : "+v"(hi));
+    lo = v - hi;
+}
 template <class T, int NS>
 __device__ __forceinline__ void store_operand8(T* base, int64_t plane, int64_t e, const float (&v)[8]) {
     T* dst = base + e;
     if constexpr (NS == 2) {
         float hi8[8], lo8[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { hi8[j] = to_f32<T>(from_f32<T>(v[j])); lo8[j] = v[j] - hi8[j]; }
+        for (int j = 0; j < 8; ++j) split_hi_lo<T>(v[j], hi8[j], lo8[j]);
         store_cvt<T, 8>(dst, hi8);
         store_cvt<T, 8>(dst + plane, lo8);
     } else {
@@ -366,7 +377,7 @@ __device__ __forceinline__ void ln_row_finish(const f32x4 (&t)[4], const float* 
                 } else if constexpr (NS == 2) {
                     float hi4[4], lo4[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { hi4[j] = to_f32<T>(from_f32<T>(y[j])); lo4[j] = y[j] - hi4[j]; }
+                    for (int j = 0; j < 4; ++j) split_hi_lo<T>(y[j], hi4[j], lo4[j]);
                     store_cvt<T, 4>(out16 + orow * cols + c, hi4);
                     store_cvt<T, 4>(out16 + out16_plane + orow * cols + c, lo4);
                 } else {

@@ -1,0 +1,607 @@
+// Shared pieces of the GEMM kernels (gemm.hip: the 16-bit, split and e4m3 operand classes; gemm_f16c8.hip: the F16C8 class): tile
+// coordinates, LDS-DMA wrappers, the accumulator-start convention, every epilogue and the launch-geometry predicates.
+// Header-only; included by exactly those two translation units.
+#pragma once
+#include "bd_common.h"
+#include <type_traits>
+
+#ifdef BD_GEMM_PROBE
+// Measurement build only (tools/gemm_phase_probe.py; never part of libboxdreamer_hip.so): per-wave shader-clock stamps of the
+// mainloop phases, kept in the lanes of one VGPR (lane i = stamp i) and written out once at kernel end.  One buffer pointer per
+// translation unit (no relocatable device code): bd_gemm_probe_set / bd_gemm_f16c8_probe_set.
+static __device__ unsigned* bd_probe_buf = nullptr;
+#define BD_PROBE(idx) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((idx) < 64) probe_ts = (lane == (idx)) ? (unsigned)t__ : probe_ts; }
+#define BD_PROBE_IF(c, idx) { if (c) BD_PROBE(idx) }
+#define BD_PROBE_RT(idx) { const unsigned long long t__ = __builtin_amdgcn_s_memrealtime(); probe_ts = (lane == (idx)) ? (unsigned)t__ : probe_ts; }
+#else
+#define BD_PROBE(idx)
+#define BD_PROBE_IF(c, idx)
+#define BD_PROBE_RT(idx)
+#endif
+
+
+namespace {
+
+
+// chunk swizzle for a tile whose rows hold CH 16-byte chunks: rows that share a 256-byte LDS bank row are separated
+template <int CH> __device__ __forceinline__ int swz_chunk(int row, int c) {
+    constexpr int RPB = 16 / CH;          // tile rows per 256-byte LDS bank row
+    return c ^ ((row / RPB) & (CH - 1));
+}
+
+// Workgroup -> output tile.  (1) XCD-aware bijective remap: XCD x (= blockIdx % 8, private 4 MiB L2) owns a contiguous
+// run of logical ids.  (2) Grouped raster inside that run: ids walk group_m M-tiles down, then step one N-tile across,
+// so the workgroups resident on an XCD cover a compact patch whose A row-panels and W tiles stay L2-resident.
+template <int BM_, int BN_>
+__device__ __forceinline__ void tile_coords_t(int M, int N, int group_m, int& m0, int& n0) {
+    const int tilesM = (M + BM_ - 1) / BM_, tilesN = (N + BN_ - 1) / BN_;
+    const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int per_group = group_m * tilesN;
+    const int g = wg / per_group, in_g = wg % per_group;
+    const int gm0 = g * group_m;
+    const int gh = (tilesM - gm0) < group_m ? (tilesM - gm0) : group_m;
+    m0 = (gm0 + in_g % gh) * BM_;
+    n0 = (in_g / gh) * BN_;
+}
+
+// LDS-DMA from inline asm.  With the builtin, hipcc's waitcnt pass sees an LDS write it cannot place: it then (a) puts
+// s_waitcnt vmcnt(0) in front of the first ds_read that follows a pending DMA in the same block (the prefetch latency is
+// exposed every slab) and (b) degrades every ds_read wait to lgkmcnt(0) (no counted waits, so the fragment reads of the
+// next k-step cannot stay in flight under the MFMAs of this one).  Hidden from the compiler the prefetch flies under the
+// slab's MFMAs, fragment waits are counted, and slab_barrier() does the one wait that is really needed.
+// (M0 has no other user in these kernels: gfx9+ DS ops do not read it.)
+__device__ __forceinline__ void glds16(const unsigned char* g, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_off) : "memory");
+}
+
+__device__ __forceinline__ void slab_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces (and earlier stores) have landed
+    __builtin_amdgcn_s_barrier();                         // ... and everyone else's; the other buffer is free
+    asm volatile("" ::: "memory");
+}
+// LDS-DMA with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: the producer wave of
+// gemm_kernel_pc keeps one offset VGPR per piece and advances K on the scalar side.
+__device__ __forceinline__ void glds16_s(unsigned voff, const unsigned char* sbase, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
+// workgroup barrier without any counter wait of its own (consumers have nothing outstanding that matters; the producer waits
+// for its DMA explicitly): a raw s_barrier fenced against compiler motion of LDS accesses
+__device__ __forceinline__ void pc_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p);
+}
+
+// out_f32 codes
+enum { OUT_OPERAND = 0, OUT_F32 = 1, OUT_F16 = 2, OUT_BF16 = 3, OUT_BF16X2 = 4, OUT_F16X2 = 5 };
+
+// Accumulator start values and where the epilogue terms enter -- ONE convention for every kernel, so that a row's result
+// does not depend on the tile shape that computed it (the property tests compare a sample run alone with the same sample
+// inside a batch, bit for bit):
+//   * a plain fp32 residual (identity row map) is loaded INTO the accumulators (divided by the column's weight scale in the e4m3
+//     class, whose epilogue multiplies by it again) before the first
+//     MFMA (C fragment layout: 2 rows x 128 contiguous bytes per load instruction), so no epilogue reads global memory for
+//     it -- on gfx9 loads and stores share the in-order vmcnt, and an epilogue that loads after it has stored waits for its
+//     own stores to be acknowledged (measured: 13.8k cycles per 256x192 tile for a LONE workgroup, profiles/r2_gemm_epilogue.md);
+//   * everything else starts at zero;
+//   * scale * acc + bias is applied when the accumulators leave the registers (per-column values, one register per 32-column
+//     tile), then the activation, the table rows and a remapped / scaled-mode residual.
+__device__ __forceinline__ bool resid_in_acc(const bd_gemm_args& p) { return p.resid && p.rpg_in <= 0; }
+
+template <int MI, int NI>
+__device__ __forceinline__ void acc_init(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wm0, int wn0, int lane) {
+    if (resid_in_acc(p)) {
+        // rows / columns past the edge are clamped: those accumulators are never stored
+        const int lrow = lane & 31, lhalf = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int gr = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                gr = gr < p.M ? gr : p.M - 1;
+                const float* rp = p.resid + (int64_t)gr * p.ldr;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int gc = wn0 + j * 32 + lrow;
+                    gc = gc < p.N ? gc : p.N - 1;
+                    acc[i][j][r] = p.wscale ? rp[gc] / p.wscale[gc] : rp[gc];
+                }
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+}
+
+// ---- scalar fallback epilogue (N not a multiple of 8 / unaligned pointers): C fragment = (col = lane & 31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5)); operand-dtype (16-bit) or fp32 outputs only
+template <class T, int NS, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], int wm0, int wn0, int lane) {
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int M = p.M, N = p.N;
+    const float* bias = p.bias;
+    const float* resid = resid_in_acc(p) ? nullptr : p.resid;      // else already in the accumulators (acc_init)
+    const float* addtab = p.addtab;
+    const float* wscale = p.wscale;
+    const int act = p.act, out_f32 = p.out_f32, rpg_in = p.rpg_in, rpg_out = p.rpg_out, row_off = p.row_off;
+    const int tab_rows = p.tab_rows;
+    const int64_t ldr = p.ldr, ldo = p.ldo, out_plane = p.out_plane;
+    float bj[NI], sj[NI];
+    int gcs[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        gcs[j] = wn0 + j * 32 + lrow;
+        bj[j] = (bias && gcs[j] < N) ? bias[gcs[j]] : 0.f;
+        sj[j] = (wscale && gcs[j] < N) ? wscale[gcs[j]] : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gr = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            if (gr < M) {
+                int64_t orow = gr;
+                if (rpg_in > 0) orow = (int64_t)(gr / rpg_in) * rpg_out + gr % rpg_in + row_off;
+                const float* tab = addtab ? addtab + (int64_t)(gr % tab_rows) * N : nullptr;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int gc = gcs[j];
+                    if (gc < N) {
+                        float v = fmaf(acc[i][j][r], sj[j], bj[j]);
+                        if (act == BD_ACT_GELU) v = gelu_erf(v);
+                        if (tab) v += tab[gc];
+                        if (resid) v += resid[orow * ldr + gc];
+                        if (out_f32 == OUT_F32) {
+                            ((float*)p.out)[orow * ldo + gc] = v;
+                        } else if constexpr (sizeof(T) == 2) {
+                            T* o = (T*)p.out + orow * ldo + gc;
+                            if (NS == 2) {
+                                float h, l;
+                                split_hi_lo<T>(v, h, l);
+                                o[0] = from_f32<T>(h);
+                                o[out_plane] = from_f32<T>(l);
+                            } else {
+                                o[0] = from_f32<T>(v);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- wide epilogue: accumulators -> this wave's private LDS scratch -> row-contiguous 16-byte accesses.
+// The MFMA C fragment gives each lane one column and 16 scattered rows (64 narrow stores per lane, each half-wave
+// touching half a cache line): measured store-issue- and load-latency-bound (~27 us per tile round vs 1.3 us per
+// K-slab).  Here every 32-row chunk of the wave tile is written to LDS with conflict-free ds_write_b32 (one row per
+// half-wave), read back with ds_read_b128 as 4 (fp32 out) or 8 (narrow out) consecutive columns per lane, the residual
+// / table rows are fetched as 16-byte vectors in batches, and the result leaves as full-line stores.  Same-wave LDS
+// traffic is ordered, so no workgroup barrier is needed between chunks.
+// SR: rows of the wave tile staged per pass through the scratch (32 = one MFMA row chunk; 16 = half of it, for kernels whose
+// scratch must fit a smaller LDS region: registers r with (r >> 2) in {2 hc, 2 hc + 1} are exactly rows 16 hc .. 16 hc + 15).
+// LEAN: register-frugal form for kernels capped at 168 VGPRs (gemm_kernel_pc: three waves on one SIMD): per-column bias /
+// scale vectors are re-loaded per column block instead of kept live across the whole tile, and the fp32 path batches its
+// global reads two passes at a time instead of four.
+template <class T, int NS, int MI, int NI, int SR = 32, bool LEAN = false>
+__device__ __forceinline__ void gemm_epilogue_lds(const bd_gemm_args& p, f32x16 (&acc)[MI][NI], unsigned char* scratch,
+                                                  int wm0, int wn0, int lane_) {
+    constexpr int COLS = NI * 32;                      // wave-tile width (fp32 words per scratch row)
+    int lane = lane_;
+    if constexpr (LEAN) {     // persistent kernels: keep the epilogue's lane-dependent addressing out of the K loop's live ranges (pc_epilogue)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    }
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int M = p.M, N = p.N;
+    const float* resid = resid_in_acc(p) ? nullptr : p.resid;      // else already in the accumulators (acc_init)
+    const float* addtab = p.addtab;
+    const int act = p.act, rpg_in = p.rpg_in, rpg_out = p.rpg_out, row_off = p.row_off, tab_rows = p.tab_rows;
+    const int64_t ldr = p.ldr, ldo = p.ldo, out_plane = p.out_plane;
+    float* sc = (float*)scratch;
+    // scale * acc + bias on the way INTO the scratch: one column per lane and 32-column tile
+    float bj[NI], sj[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int gc = wn0 + j * 32 + lrow;
+        bj[j] = (p.bias && gc < N) ? p.bias[gc] : 0.f;
+        sj[j] = (p.wscale && gc < N) ? p.wscale[gc] : 1.f;
+    }
+    auto to_scratch = [&](int i, int hc) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = hc * (SR / 2); r < (hc + 1) * (SR / 2); ++r)
+                sc[((r & 3) + 8 * ((r >> 2) - hc * (SR / 8)) + 4 * lhalf) * COLS + j * 32 + lrow] = fmaf(acc[i][j][r], sj[j], bj[j]);
+    };
+    // the wave tile is flushed in column blocks of CW columns (all of it when it is 32 or 64 wide; 3 x 32 for the 96-wide
+    // wave tile of the 256 x 192 workgroup tile) so that the lanes of a pass always cover whole rows of a block
+    constexpr int CW = (NI % 2 == 0) ? 64 : 32, NCB = COLS / CW;
+    if (p.out_f32 == OUT_F32) {
+        constexpr int LPR = CW / 4;                    // lanes per row (4 floats each)
+        constexpr int RPI = 64 / LPR;                  // rows per pass
+        constexpr int PASSES = SR / RPI;
+        const int c4 = lane % LPR, rsub = lane / LPR;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ih = 0; ih < MI * (32 / SR); ++ih) {
+            const int i = ih / (32 / SR), hc = ih % (32 / SR);
+            to_scratch(i, hc);
+            // global reads are issued in batches of PB passes (register budget); native vector types only -- HIP's
+            // float4 struct in a local array lands in scratch
+            constexpr int PB = LEAN ? (PASSES > 2 ? 2 : PASSES) : (PASSES > 4 ? 4 : PASSES);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int gc = wn0 + cb * CW + c4 * 4;
+                const bool cok = gc < N;
+#pragma unroll
+                for (int t0 = 0; t0 < PASSES; t0 += PB) {
+                    f32x4 rv[PB], tv[PB];
+                    int64_t orow[PB];
+                    bool ok[PB];
+#pragma unroll
+                    for (int u = 0; u < PB; ++u) {
+                        const int gr = wm0 + i * 32 + hc * SR + (t0 + u) * RPI + rsub;
+                        ok[u] = cok && gr < M;
+                        const int grc = gr < M ? gr : M - 1;
+                        orow[u] = rpg_in > 0 ? (int64_t)(grc / rpg_in) * rpg_out + grc % rpg_in + row_off : (int64_t)grc;
+                        rv[u] = zero4;
+                        tv[u] = zero4;
+                        if (resid && ok[u]) rv[u] = *(const f32x4*)(resid + orow[u] * ldr + gc);
+                        if (addtab && ok[u]) tv[u] = *(const f32x4*)(addtab + (int64_t)(grc % tab_rows) * N + gc);
+                    }
+#pragma unroll
+                    for (int u = 0; u < PB; ++u) {
+                        f32x4 v = *(const f32x4*)(sc + ((t0 + u) * RPI + rsub) * COLS + cb * CW + c4 * 4);
+                        if (act == BD_ACT_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        }
+                        v = v + tv[u] + rv[u];
+                        if (ok[u]) *(f32x4*)((float*)p.out + orow[u] * ldo + gc) = v;
+                    }
+                }
+            }
+        }
+    } else {
+        constexpr int LPR = CW / 8;                    // lanes per row (8 output columns each)
+        constexpr int RPI = 64 / LPR;
+        constexpr int PASSES = SR / RPI;
+        const int c8 = lane % LPR, rsub = lane / LPR;
+        const int out_mode = p.out_f32;
+        auto store8 = [&](int64_t orow, int gc, const float (&v)[8]) {
+            if (out_mode == OUT_F16) {            // f16 single plane (optional f16 attention of the strict mode)
+                store_cvt<_Float16, 8>((_Float16*)p.out + orow * ldo + gc, v);
+            } else if (out_mode == OUT_BF16) {    // bf16 single plane (fp8 mode: attention operands stay bf16)
+                store_cvt<__bf16, 8>((__bf16*)p.out + orow * ldo + gc, v);
+            } else if (out_mode == OUT_BF16X2) {  // split-bf16 planes (F16C8 mode: DINOv2's split-bf16 attention)
+                store_operand8<__bf16, 2>((__bf16*)p.out, out_plane, orow * ldo + gc, v);
+            } else if (out_mode == OUT_F16X2) {   // split-f16 planes (an F16C8 Linear feeding a promoted, split-f16 one)
+                store_operand8<_Float16, 2>((_Float16*)p.out, out_plane, orow * ldo + gc, v);
+            } else {
+                store_operand8<T, NS>((T*)p.out, out_plane, orow * ldo + gc, v);
+            }
+        };
+        if constexpr (LEAN && NI == 3 && PASSES == 1) {
+            if (p.rms_wq) {
+                // Fused q/k RMSNorm: the 96-column wave tile IS one head (host-checked).  A lane owns 3 x 8 columns of one row per
+                // 16-row pass and the 4 lanes of a row (one quad) combine their sums of squares: fp32 mean / rsqrt on the
+                // accumulators themselves, then the learned weight, then the 16-bit store.  Which third of the output this
+                // wave tile lies in (q: normalise with wq, k: with wk, v: untouched) is wave-uniform.
+                const int part = wn0 / (N / (p.rms_parts == 2 ? 2 : 3));
+                const float* rw = part == 0 ? p.rms_wq : (part == 1 ? p.rms_wk : nullptr);
+                float wv[3][8];
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) wv[cb][e] = rw ? rw[cb * 32 + c8 * 8 + e] : 1.f;
+                const float eps = p.rms_eps;
+#pragma unroll
+                for (int ih = 0; ih < MI * (32 / SR); ++ih) {
+                    const int i = ih / (32 / SR), hc = ih % (32 / SR);
+                    to_scratch(i, hc);
+                    const int gr = wm0 + i * 32 + hc * SR + rsub;
+                    float v[3][8];
+                    float ss = 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb) {
+                        const float* src = sc + rsub * COLS + cb * CW + c8 * 8;
+                        const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[cb][e] = a0[e]; v[cb][4 + e] = a1[e]; }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ss = fmaf(v[cb][e], v[cb][e], ss);
+                    }
+                    ss += __shfl_xor(ss, 1);
+                    ss += __shfl_xor(ss, 2);
+                    const float inv = rw ? rsqrtf(ss * (1.0f / 96.0f) + eps) : 1.f;
+                    if (gr < M) {
+#pragma unroll
+                        for (int cb = 0; cb < 3; ++cb) {
+                            float o8[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o8[e] = wv[cb][e] * (v[cb][e] * inv);     // w * (x * rsqrt(..)): blocks.py:51-56
+                            store8((int64_t)gr, wn0 + cb * CW + c8 * 8, o8);
+                        }
+                    }
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int ih = 0; ih < MI * (32 / SR); ++ih) {
+            const int i = ih / (32 / SR), hc = ih % (32 / SR);
+            to_scratch(i, hc);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int gc = wn0 + cb * CW + c8 * 8;
+#pragma unroll
+                for (int t = 0; t < PASSES; ++t) {
+                    const int gr = wm0 + i * 32 + hc * SR + t * RPI + rsub;
+                    const float* src = sc + (t * RPI + rsub) * COLS + cb * CW + c8 * 8;
+                    const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[4 + e] = a1[e]; }
+                    if (act == BD_ACT_GELU) gelu_n<GeluKind<T, NS>::value, 8>(v);   // 16/8-bit result: fitted forms (bd_common.h)
+                    if (gc < N && gr < M) {
+                        const int64_t orow = rpg_in > 0 ? (int64_t)(gr / rpg_in) * rpg_out + gr % rpg_in + row_off : (int64_t)gr;
+                        if (addtab) {
+                            const float* tp = addtab + (int64_t)(gr % tab_rows) * N + gc;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += tp[e];
+                        }
+                        if (resid) {
+                            const float* rp = resid + orow * ldr + gc;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += rp[e];
+                        }
+                        store8(orow, gc, v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// quad all-reduce (lanes 4k .. 4k+3) on the VALU: two DPP quad_perm adds
+__device__ __forceinline__ float quad_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // [2,3,0,1]
+    return x;
+}
+
+// Epilogue of gemm_kernel_pc for the 64 x 96 wave tile (MI = 2, NI = 3), 16 rows per pass through this wave's 6-KiB scratch.
+//   colp: this tile's per-column vectors in LDS (bias at [0, 256), weight scale at [256, 512)), indexed by tile column
+//   rmsw: q weights at [0, 96), k weights at [256, 352)
+//   wcol: first column of the wave tile inside the workgroup tile;  (wm0, wn0): its global origin
+//   next: the wave tile origin of this workgroup's next tile (EP 3 pre-loads its residual), has_next = there is one
+template <class T, int NS, int EP, int OUTK, bool GELU, int MI = 2>
+__device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)[MI][3], float* sc, const float* colp, const float* colp_next,
+                                            const float* rmsw, int wcol, int wm0, int wn0, int lane_, bool has_next, int nwm0, int nwn0) {
+    constexpr int COLS = 96;
+    // The lane id is re-derived HERE from an opaque instruction pair, so that none of the epilogue's lane-dependent addressing can be
+    // hoisted above the K loop, whose register budget (168) is full: hoisted, three of those values were spilled in the F16C8 / e4m3
+    // instances and RELOADED inside the epilogue -- a vector-memory load whose s_waitcnt vmcnt(0) also waited for the 24 residual
+    // pre-loads of the chunk before the first row could be stored (round 4; the build now fails on a spill, boxdreamer_amd/build.py).
+    (void)lane_;
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int M = p.M;
+    float bj[3], sj[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        bj[j] = p.bias ? colp[wcol + j * 32 + lrow] : 0.f;
+        sj[j] = 1.f;
+        if constexpr (sizeof(T) == 1) sj[j] = p.wscale ? colp[256 + wcol + j * 32 + lrow] : 1.f;
+    }
+    auto to_scratch = [&](int i, int hc) {          // rows 16 hc .. 16 hc + 15 of 32-row block i: registers r with (r >> 2) in {2 hc, 2 hc + 1}
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = hc * 8; r < hc * 8 + 8; ++r) {
+                const float a = acc[i][j][r];
+                sc[((r & 3) + 8 * ((r >> 2) - hc * 2) + 4 * lhalf) * COLS + j * 32 + lrow] = sizeof(T) == 1 ? fmaf(a, sj[j], bj[j]) : a + bj[j];
+            }
+    };
+    if constexpr (EP == 3) {
+        // fp32 rows: 8 lanes x 16 bytes = one 128-byte line per row and 32-column block; 8 rows per pass, 2 passes per chunk
+        const int c4 = lane & 7, rsub = lane >> 3;
+        const bool pre = has_next && p.resid != nullptr;
+        float rsn[3] = {1.f, 1.f, 1.f};       // e4m3 class: the NEXT tile's column scales (its side-buffer slot landed with its first slab)
+        if constexpr (sizeof(T) == 1) {
+            if (pre && p.wscale) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) rsn[j] = colp_next[256 + wcol + j * 32 + lrow];
+            }
+        }
+#pragma unroll
+        for (int ih = 0; ih < 2 * MI; ++ih) {
+            const int i = ih >> 1, hc = ih & 1;
+            to_scratch(i, hc);
+            // these accumulator registers are free now: the next tile's residual (or zero) goes in
+            if (pre) {
+#pragma unroll
+                for (int r = hc * 8; r < hc * 8 + 8; ++r) {
+                    int gr = nwm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    gr = gr < M ? gr : M - 1;
+                    const float* rp = p.resid + (int64_t)gr * p.ldr + nwn0 + lrow;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i][j][r] = (sizeof(T) == 1 && p.wscale) ? rp[j * 32] / rsn[j] : rp[j * 32];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = hc * 8; r < hc * 8 + 8; ++r) acc[i][j][r] = 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int gr = wm0 + i * 32 + hc * 16 + t * 8 + rsub;
+                f32x4 v[3];
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) v[cb] = *(const f32x4*)(sc + (t * 8 + rsub) * COLS + cb * 32 + c4 * 4);
+                if (gr < M) {
+                    float* op = (float*)p.out + (int64_t)gr * p.ldo + wn0 + c4 * 4;
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb) {
+                        *(f32x4*)(op + cb * 32) = v[cb];
+                    }
+                }
+            }
+        }
+    } else if constexpr (EP == 1 && NS == 1 && sizeof(T) == 2 && OUTK == OUT_OPERAND) {
+        // Plain bf16 / f16 result (optional GELU): rounded to 16 bits BEFORE the LDS round trip, two adjacent rows per dword
+        // (registers r, r + 1 of a C fragment are rows 2 k, 2 k + 1 of the same column), so the transposition moves half the bytes:
+        // per 32-row block 24 ds_write_b32 + 6 ds_read_b128 per lane instead of 48 + 12.  A lane then owns 8 consecutive columns of
+        // one row PAIR, splits the dwords with two byte permutes each and stores two 16-byte row pieces; 12 lanes cover a row
+        // (192-byte runs).  Same values, same roundings as the fp32 staging (the conversion is the separate step of store_cvt).
+        unsigned* sp = (unsigned*)sc;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) {
+                    float v2[2] = {acc[i][j][2 * pp] + bj[j], acc[i][j][2 * pp + 1] + bj[j]};
+                    if constexpr (GELU) gelu_n<GeluKind<T, NS>::value, 2>(v2);
+                    float x0 = v2[0], x1 = v2[1];
+                    asm("" : "+v"(x0));          // separate fp32 -> 16-bit rounding (store_cvt's rule)
+                    asm("" : "+v"(x1));
+                    typedef T pair_t __attribute__((ext_vector_type(2)));
+                    const pair_t pr = {(T)x0, (T)x1};
+                    const int prow = (pp & 1) + 4 * (pp >> 1) + 2 * lhalf;
+                    sp[prow * COLS + j * 32 + lrow] = __builtin_bit_cast(unsigned, pr);
+                }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int t = u * 64 + lane, prow = t / 12, cg = t % 12;
+                const u128 d0 = *(const u128*)(sp + prow * COLS + cg * 8), d1 = *(const u128*)(sp + prow * COLS + cg * 8 + 4);
+                u128 ra, rb;          // even row: low halves, odd row: high halves
+                ra[0] = __builtin_amdgcn_perm(d0[1], d0[0], 0x05040100u); ra[1] = __builtin_amdgcn_perm(d0[3], d0[2], 0x05040100u);
+                ra[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x05040100u); ra[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x05040100u);
+                rb[0] = __builtin_amdgcn_perm(d0[1], d0[0], 0x07060302u); rb[1] = __builtin_amdgcn_perm(d0[3], d0[2], 0x07060302u);
+                rb[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x07060302u); rb[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x07060302u);
+                const int gr = wm0 + i * 32 + 2 * prow;
+                T* op = (T*)p.out + (int64_t)gr * p.ldo + wn0 + cg * 8;
+                if (gr < M) __builtin_nontemporal_store(ra, (u128*)op);
+                if (gr + 1 < M) __builtin_nontemporal_store(rb, (u128*)(op + p.ldo));
+            }
+        }
+    } else {
+        // 16-bit rows: 4 lanes x 16 bytes per row and 32-column block, 16 rows per pass
+        const int c8 = lane & 3, rsub = lane >> 2;
+        auto store8 = [&](int64_t e, const float (&v)[8]) {
+            if constexpr (OUTK == OUT_F16) store_cvt<_Float16, 8>((_Float16*)p.out + e, v);
+            else if constexpr (OUTK == OUT_BF16) store_cvt<__bf16, 8>((__bf16*)p.out + e, v);
+            else if constexpr (OUTK == OUT_BF16X2) store_operand8<__bf16, 2>((__bf16*)p.out, p.out_plane, e, v);
+            else if constexpr (OUTK == OUT_F16X2) store_operand8<_Float16, 2>((_Float16*)p.out, p.out_plane, e, v);
+            else store_operand8<T, NS>((T*)p.out, p.out_plane, e, v);
+        };
+        float wv[EP == 2 ? 3 : 1][8];
+        bool norm = false;
+        if constexpr (EP == 2) {
+            // the 96-column wave tile IS one head (host-checked); which third of the output it lies in is wave-uniform
+            const int part = wn0 / (p.N / (p.rms_parts == 2 ? 2 : 3));
+            norm = part < 2;
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const float* src = rmsw + (part & 1) * 256 + cb * 32 + c8 * 8;
+                const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wv[cb][e] = a0[e]; wv[cb][4 + e] = a1[e]; }
+            }
+        }
+#pragma unroll
+        for (int ih = 0; ih < 2 * MI; ++ih) {
+            const int i = ih >> 1, hc = ih & 1;
+            to_scratch(i, hc);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = hc * 8; r < hc * 8 + 8; ++r) acc[i][j][r] = 0.f;
+            const int gr = wm0 + i * 32 + hc * 16 + rsub;
+            float v[3][8];
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const float* src = sc + rsub * COLS + cb * 32 + c8 * 8;
+                const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[cb][e] = a0[e]; v[cb][4 + e] = a1[e]; }
+            }
+            if constexpr (GELU) {
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) gelu_n<GeluKind<T, NS>::value, 8>(v[cb]);   // 16/8-bit result: fitted forms (bd_common.h)
+            }
+            if constexpr (EP == 2) {
+                float ss = 0.f;
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss = fmaf(v[cb][e], v[cb][e], ss);
+                ss = quad_sum(ss);
+                const float inv = rsqrtf(ss * (1.0f / 96.0f) + p.rms_eps);
+                if (norm) {
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[cb][e] = wv[cb][e] * (v[cb][e] * inv);     // w * (x * rsqrt(..)): blocks.py:51-56
+                }
+            }
+            if (gr < M) {
+                const int64_t e0 = (int64_t)gr * p.ldo + wn0 + c8 * 8;
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) store8(e0 + cb * 32, v[cb]);
+            }
+        }
+    }
+}
+
+
+// the wide (LDS-staged, 16-byte) epilogue needs 16-byte aligned rows: N % 8 == 0 and aligned leading dimensions / pointers
+inline bool wide_epilogue_ok(const bd_gemm_args& p, int ns) {
+    return (p.N % 8 == 0) && (p.ldo % 8 == 0) && (((uintptr_t)p.out & 15) == 0) &&
+           (!p.resid || ((p.ldr % 4 == 0) && ((uintptr_t)p.resid & 15) == 0)) &&
+           (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.addtab || ((uintptr_t)p.addtab & 15) == 0) &&
+           (!p.wscale || ((uintptr_t)p.wscale & 15) == 0) && (p.out_f32 || ns == 1 || (p.out_plane % 8 == 0));
+}
+
+
+// Compute units of the current device (MI355X: 256; partitioned / harvested parts differ): the tile-choice model counts
+// resident workgroup slots per round (one 256x256 workgroup per CU, two 128x128, four 64x64).  Immutable device property,
+// looked up once per device.
+inline int cu_count() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
+// rows [row0, row0 + rows) of the problem as its own launch (no row remap / table: checked by the caller)
+inline bool rms_geometry_ok(const bd_gemm_args& a) {
+    return a.rms_wq && a.rms_wk && a.out_f32 != OUT_F32 && a.act == BD_ACT_NONE && !a.resid && !a.addtab && a.rpg_in <= 0 &&
+           (a.rms_parts == 0 || a.rms_parts == 2 || a.rms_parts == 3) &&
+           a.N % (a.rms_parts == 2 ? 2 : 3) == 0 && (a.N / (a.rms_parts == 2 ? 2 : 3)) % 96 == 0 && a.N % 192 == 0 && (((uintptr_t)a.rms_wq | (uintptr_t)a.rms_wk) & 3) == 0;
+}
+
+}  // namespace
+
+// the F16C8 class has its own persistent kernel (gemm_f16c8.hip); every shape goes through it
+int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s);

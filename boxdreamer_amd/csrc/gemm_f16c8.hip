@@ -1,0 +1,319 @@
+// The GEMM of the F16C8 operand class (include/boxdreamer_hip.h: BD_PREC_F16C8): one f16 MFMA pass + one block-scaled e4m3 correction
+// pass per product, in the persistent producer / consumer structure of gemm.hip's gemm_kernel_pc.  Epilogues: gemm_common.h.
+#include "gemm_common.h"
+
+#ifdef BD_GEMM_PROBE
+extern "C" int bd_gemm_f16c8_probe_set(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(bd_probe_buf), &buf, sizeof(buf));
+}
+#endif
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// BD_PREC_F16C8 GEMM (bd_common.h: f16 hi pass + one e4m3 correction pass; 3 bytes per element through LDS-DMA).
+// Same producer / consumer persistent structure and 256 x 192 tile as gemm_kernel_pc, with
+//   * a stage of four sub-planes per 32-deep slab: A hi (256 x 64 B), W hi (192 x 64 B), A lo8 (256 x 32 B), W lo8 (192 x 32 B)
+//     = 42 KiB, so THREE stages fit next to nothing else (the LDS-staged epilogue's 48 KiB scratch overlays stage 2, which is
+//     where every tile's last slab lives when K / 32 is a multiple of 3 -- K = 768 and 3072 -- and is free while the next
+//     tile's first two slabs land in stages 0 and 1).  With three stages the producers run TWO slabs ahead and wait with a
+//     counted vmcnt: the ~1100-cycle issue-to-landing latency of a slab, which bounds the 2-stage kernels at ~2800 cycles per
+//     slab in this operand class, is off the critical path.  NSTAGE = 2 (scratch separate) serves the other K.
+//   * the e4m3 image q8 of an f16 fragment derived in registers (v_cvt_scalef32_pk_fp8_f16, 4 per fragment), so the
+//     correction pass costs one extra ds_read_b128 per 32-row fragment pair instead of two.
+template <int NSTAGE, int EP, int OUTK, bool GELU>
+__global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_args p) {
+    constexpr int WM = 4, WN = 2, MI = 2, NI = 3, NPW = 4, NCW = WM * WN;
+    constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32, BK = 32;
+    constexpr int A0 = TBM * 64, W0 = TBN * 64, A1 = TBM * 32, W1 = TBN * 64;     // W's e4m3 plane carries q8 AND lo8 (weights: packed once)
+    constexpr int OFF_W0 = A0, OFF_A1 = A0 + W0, OFF_W1 = A0 + W0 + A1, STAGE = A0 + W0 + A1 + W1;
+    constexpr int SR = 16, SCRATCH = NCW * SR * NI * 32 * 4;
+    static_assert(SCRATCH == STAGE, "the epilogue scratch overlays stage 2 exactly");
+    // side buffer behind the ring + scratch (gemm_kernel_pc): per-column vectors of the current / next tile, q / k RMSNorm weights
+    constexpr int AUX_COLP = 2 * STAGE + SCRATCH, AUX_RMS = AUX_COLP + 4096, AUX_BYTES = EP == 0 ? 0 : 6144;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE + SCRATCH + AUX_BYTES];   // stages at 0, STAGE, 2*STAGE; scratch at 2*STAGE
+
+    bd_saturating_conversions();      // q8 images (K loop) and F16C8 / f16 results (epilogue) saturate instead of turning NaN / inf
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = p.M, N = p.N;
+    const int nk = p.K / BK;
+    const int tilesM = (M + TBM - 1) / TBM, tilesN = (N + TBN - 1) / TBN, nt = tilesM * tilesN;
+    const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7;
+    const int tq = nt >> 3, tr = nt & 7;
+    const int t_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int t_end = t_begin + tq + (xcd < tr ? 1 : 0);
+    const int stride = (nwg - xcd + 7) >> 3;
+    constexpr int GROUP_M = 4;
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int per_group = GROUP_M * tilesN;
+        const int g = t / per_group, in_g = t % per_group;
+        const int gm0 = g * GROUP_M;
+        const int gh = (tilesM - gm0) < GROUP_M ? (tilesM - gm0) : GROUP_M;
+        m0 = (gm0 + in_g % gh) * TBM;
+        n0 = (in_g / gh) * TBN;
+    };
+    const unsigned lds_off = lds_offset_of(lds);
+
+    if (wid >= NCW) {
+        // ------------------------------------------------------------------ producers
+        const int pw = wid - NCW;
+        const unsigned lda0 = (unsigned)(p.lda * 2), ldw0 = (unsigned)(p.ldw * 2), lda1 = (unsigned)p.lda, ldw1 = (unsigned)(p.ldw * 2);
+        unsigned oA0[4], oW0[3], oA1[2], oW1[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int row = (pw + 4 * i) * 16 + lane / 4; oA0[i] = row * lda0 + swz_chunk<4>(row, lane % 4) * 16; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const int row = (pw + 4 * i) * 16 + lane / 4; oW0[i] = row * ldw0 + swz_chunk<4>(row, lane % 4) * 16; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int row = (pw + 4 * i) * 32 + lane / 2; oA1[i] = row * lda1 + swz_chunk<2>(row, lane % 2) * 16; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const int row = (pw + 4 * i) * 16 + lane / 4; oW1[i] = row * ldw1 + swz_chunk<4>(row, lane % 4) * 16; }
+        const unsigned char* pA0 = (const unsigned char*)p.A;
+        const unsigned char* pW0 = (const unsigned char*)p.W;
+        const unsigned char* pA1 = pA0 + p.a_plane * 2;
+        const unsigned char* pW1 = pW0 + p.w_plane * 2;
+        auto issue = [&](int stage, int m0, int n0, int kt) {
+            const int rows_a = (M - m0) < TBM ? (M - m0) : TBM, rows_w = (N - n0) < TBN ? (N - n0) : TBN;
+            const unsigned la0 = (unsigned)(rows_a - 1) * lda0 + 48, lw0 = (unsigned)(rows_w - 1) * ldw0 + 48;
+            const unsigned la1 = (unsigned)(rows_a - 1) * lda1 + 16, lw1 = (unsigned)(rows_w - 1) * ldw1 + 48;
+            const unsigned st = lds_off + stage * STAGE + pw * 1024;
+            const unsigned char* ba0 = pA0 + (int64_t)m0 * lda0 + (int64_t)kt * 64;
+            const unsigned char* bw0 = pW0 + (int64_t)n0 * ldw0 + (int64_t)kt * 64;
+            const unsigned char* ba1 = pA1 + (int64_t)m0 * lda1 + (int64_t)kt * 32;
+            const unsigned char* bw1 = pW1 + (int64_t)n0 * ldw1 + (int64_t)kt * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16_s(oA0[i] < la0 ? oA0[i] : la0, ba0, st + i * 4096);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) glds16_s(oW0[i] < lw0 ? oW0[i] : lw0, bw0, st + OFF_W0 + i * 4096);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) glds16_s(oA1[i] < la1 ? oA1[i] : la1, ba1, st + OFF_A1 + i * 4096);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) glds16_s(oW1[i] < lw1 ? oW1[i] : lw1, bw1, st + OFF_W1 + i * 4096);
+        };
+        // issue cursor over this workgroup's slab sequence (all tiles, slab by slab); slab number ig goes to stage ig % NSTAGE
+        int ig = 0, ist = 0, it = t_begin + (bid >> 3), ikt = 0, im0 = 0, in0 = 0, itn = 0;
+        if (it < t_end) tile_origin(it, im0, in0);
+        if constexpr (EP == 2) {
+            if (pw == 1) {        // q / k RMSNorm weights (96 floats each), once
+                const unsigned off = (unsigned)lane * 16 < 368u ? (unsigned)lane * 16 : 368u;
+                glds16_s(off, (const unsigned char*)p.rms_wq, lds_off + AUX_RMS);
+                glds16_s(off, (const unsigned char*)p.rms_wk, lds_off + AUX_RMS + 1024);
+            }
+        }
+        auto issue_next = [&]() {
+            if (it >= t_end) return;
+            if constexpr (EP != 0) {
+                // the tile's bias vector rides in FRONT of its first slab (the counted vmcnt below covers everything but the
+                // most recent slab's 12 pieces); the host sends K >= 128 here, so a slot is rewritten only after its tile is done
+                if (ikt == 0) {
+                    if (pw == 0 && p.bias) {
+                        const unsigned off = (unsigned)lane * 16 < (unsigned)(TBN * 4 - 16) ? (unsigned)lane * 16 : (unsigned)(TBN * 4 - 16);
+                        glds16_s(off, (const unsigned char*)(p.bias + in0), lds_off + AUX_COLP + (itn & 1) * 2048);
+                    }
+                    ++itn;
+                }
+            }
+            issue(ist, im0, in0, ikt);
+            ++ig;
+            ist = ist + 1 == NSTAGE ? 0 : ist + 1;
+            if (++ikt == nk) {
+                ikt = 0;
+                it += stride;
+                if (it < t_end) tile_origin(it, im0, in0);
+            }
+        };
+        // wait until at most `slabs` of this wave's most recent slab fetches are still in flight (12 pieces each)
+        auto wait_landed = [&](int slabs) {
+            if (slabs <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        };
+#ifdef BD_GEMM_PROBE
+        unsigned probe_ts = 0;
+#endif
+#pragma unroll
+        for (int i = 0; i < NSTAGE - 1; ++i) issue_next();
+        int g = 0;
+        for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
+            for (int kt = 0; kt < nk; ++kt) {
+                BD_PROBE_IF(g < 20, g * 3 + 2)
+                wait_landed(ig - g - 1);                  // slab g has landed (later slabs may still fly)
+                BD_PROBE_IF(g < 20, g * 3)
+                pc_barrier();                             // B(g): releases the consumers into slab g; slab g-1 is dead
+                BD_PROBE_IF(g < 20, g * 3 + 1)
+                if (ig <= g + NSTAGE - 1) issue_next();   // refill the stage slab g-1 lived in
+                ++g;
+            }
+            pc_barrier();                                 // X: consumers are done with the tile's last slab (scratch = stage 2 ..)
+        }
+#ifdef BD_GEMM_PROBE
+        if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * 16 + wid) * 64 + lane] = probe_ts;
+#endif
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wm = wid / WN, wn = wid % WN;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int scale_a = 127, scale_w = 127 - (p.w_qexp + BD_F16C8_D);           // E8M0: the cross terms carry 2^(E + D)
+    int g_st = 0;
+#ifdef BD_GEMM_PROBE
+    unsigned probe_ts = 0;
+    int g = 0;
+#endif
+    BD_PROBE(58) BD_PROBE_RT(56)
+    int ti = 0;
+    f32x16 acc[MI][NI];
+    if constexpr (EP != 0) {      // first tile; later tiles are initialised inside the previous tile's epilogue
+        int m0, n0;
+        tile_origin(t_begin + (bid >> 3), m0, n0);
+        acc_init<MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+    }
+    for (int t = t_begin + (bid >> 3); t < t_end; t += stride, ++ti) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
+        if constexpr (EP == 0) acc_init<MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+        for (int kt = 0; kt < nk; ++kt) {
+            BD_PROBE_IF(g < 20, g * 3)
+            pc_barrier();                                 // B
+            BD_PROBE_IF(g < 20, g * 3 + 1)
+#ifdef BD_GEMM_PROBE
+            ++g;
+#endif
+            const unsigned char* base = lds + g_st * STAGE;
+            g_st = g_st + 1 == NSTAGE ? 0 : g_st + 1;
+            f16x8 ah[2][MI], wh[2][NI];
+            u128 al[MI];
+            i32x8 w8[NI];
+#define LD16(dst, ptr, row, ks) dst = __builtin_bit_cast(f16x8, *(const u128*)((ptr) + (row) * 64 + (swz_chunk<4>((row), (ks) * 2 + lhalf) << 4)));
+#define LDLO(dst, ptr, row) dst = *(const u128*)((ptr) + (row) * 32 + (swz_chunk<2>((row), lhalf) << 4));
+            // W's e4m3 operand straight from LDS: 32 bytes = [q8 x 16 | lo8 x 16] of this lane half
+#define LDW8(dst, ptr, row)                                                                                    \
+            {                                                                                                     \
+                const u128 lo_ = *(const u128*)((ptr) + (row) * 64 + (swz_chunk<4>((row), 2 * lhalf) << 4));        \
+                const u128 hi_ = *(const u128*)((ptr) + (row) * 64 + (swz_chunk<4>((row), 2 * lhalf + 1) << 4));    \
+                dst = (i32x8){(int)lo_[0], (int)lo_[1], (int)lo_[2], (int)lo_[3], (int)hi_[0], (int)hi_[1], (int)hi_[2], (int)hi_[3]}; \
+            }
+            // e4m3 image of one f16 A fragment (8 values of a k-step), 2 dwords; scale 1.0.  The wave runs with MODE.FP16_OVFL set
+            // (bd_saturating_conversions): the conversion clamps to +-448, so an activation beyond 448 keeps its full value in the f16
+            // pass and only its q_A . lo_W correction term is computed from 448 (bd_common.h, RANGE).
+            // (pairs built element-wise: __builtin_bit_cast of a vector ELEMENT to a 2 x f16 vector is miscompiled by hipcc 7.2
+            // here -- every conversion then reads the first dword)
+#define Q8P(f, a, b) ((h2_){f[a], f[b]})
+#define Q8H(d0, d1, f)                                                                                        \
+            {                                                                                                     \
+                typedef _Float16 h2_ __attribute__((ext_vector_type(2)));                                         \
+                typedef short s2_ __attribute__((ext_vector_type(2)));                                            \
+                s2_ a_ = {0, 0}, b_ = {0, 0};                                                                     \
+                a_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(a_, Q8P(f, 0, 1), 1.0f, false);                     \
+                a_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(a_, Q8P(f, 2, 3), 1.0f, true);                      \
+                b_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b_, Q8P(f, 4, 5), 1.0f, false);                     \
+                b_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(b_, Q8P(f, 6, 7), 1.0f, true);                      \
+                d0 = __builtin_bit_cast(unsigned, a_);                                                            \
+                d1 = __builtin_bit_cast(unsigned, b_);                                                            \
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) LD16(wh[0][j], base + OFF_W0, wn * (NI * 32) + j * 32 + lrow, 0)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) LD16(ah[0][i], base, wm * (MI * 32) + i * 32 + lrow, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int NMM = MI * NI;
+            static_assert(MI == 2 && NI == 3, "the interleave below is written for 2 x 3 MFMA tiles per wave");
+            unsigned qd[MI][4];
+#pragma unroll
+            for (int q = 0; q < NMM; ++q) {                       // f16, k-step 0
+                const int i = q % MI, j = q / MI;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], wh[0][j], acc[i][j], 0, 0, 0);
+                if (q < MI) LD16(ah[1][q], base, wm * (MI * 32) + q * 32 + lrow, 1)
+                else if (q < MI + NI) LD16(wh[1][q - MI], base + OFF_W0, wn * (NI * 32) + (q - MI) * 32 + lrow, 1)
+                if (q == 3) Q8H(qd[0][0], qd[0][1], ah[0][0])
+                if (q == 4) Q8H(qd[1][0], qd[1][1], ah[0][1])
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < NMM; ++q) {                       // f16, k-step 1
+                const int i = q % MI, j = q / MI;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], wh[1][j], acc[i][j], 0, 0, 0);
+                if (q < MI) LDLO(al[q], base + OFF_A1, wm * (MI * 32) + q * 32 + lrow)
+                if (q == 2) LDW8(w8[0], base + OFF_W1, wn * (NI * 32) + lrow)
+                if (q == 4) LDW8(w8[1], base + OFF_W1, wn * (NI * 32) + 32 + lrow)
+                if (q == 2) Q8H(qd[0][2], qd[0][3], ah[1][0])
+                if (q == 3) Q8H(qd[1][2], qd[1][3], ah[1][1])
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < NMM; ++q) {                       // e4m3 correction pass: [lo_A | q_A] . [q_W | lo_W]
+                const int i = q % MI, j = q / MI;
+                const i32x8 a8 = {(int)al[i][0], (int)al[i][1], (int)al[i][2], (int)al[i][3], (int)qd[i][0], (int)qd[i][1], (int)qd[i][2], (int)qd[i][3]};
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, w8[j], acc[i][j], 0, 0, 0, scale_a, 0, scale_w);
+                if (q == 0) LDW8(w8[2], base + OFF_W1, wn * (NI * 32) + 64 + lrow)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef LDW8
+#undef LD16
+#undef LDLO
+#undef Q8H
+#undef Q8P
+        }
+        BD_PROBE_IF(g == nk, 60)
+        pc_barrier();                                     // X
+        BD_PROBE_IF(g == nk, 61)
+        unsigned char* scratch = lds + 2 * STAGE + wid * (SR * NI * 32 * 4);
+        if constexpr (EP == 0) {
+            gemm_epilogue_lds<f16c8, 2, MI, NI, SR, true>(p, acc, scratch, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+        } else {
+            const bool has_next = t + stride < t_end;
+            int nm0 = 0, nn0 = 0;
+            if (has_next) tile_origin(t + stride, nm0, nn0);
+            pc_epilogue<f16c8, 2, EP, OUTK, GELU, 2>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
+                                                 (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
+                                                 lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
+        }
+        BD_PROBE_IF(g == nk, 62)
+    }
+    BD_PROBE(59) BD_PROBE_RT(57)
+#ifdef BD_GEMM_PROBE
+    if (bd_probe_buf && blockIdx.x < 1024) bd_probe_buf[((size_t)blockIdx.x * 16 + wid) * 64 + lane] = probe_ts;
+#endif
+}
+
+}  // namespace
+
+// F16C8 has its own persistent kernel; every shape goes through it
+int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
+    if (!wide_epilogue_ok(a, 2) || 256 * a.lda * 2 >= ((int64_t)1 << 31) || 256 * a.ldw * 2 >= ((int64_t)1 << 31)) return BD_ERR_ALIGN;
+    if ((a.K % 32) || (a.lda % 32) || (a.ldw % 32)) return BD_ERR_SHAPE;            // the lo8 planes are laid out in 32-element blocks
+    if (a.out_f32 == OUT_OPERAND && (a.ldo % 32)) return BD_ERR_SHAPE;
+    if (a.w_qexp + BD_F16C8_D < -100 || a.w_qexp + BD_F16C8_D > 120) return BD_ERR_SHAPE;
+    if (a.rms_wq && !rms_geometry_ok(a)) return BD_ERR_SHAPE;
+    const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
+    const int cus = cu_count();
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 191) / 192);
+    const int grid = tiles < cus ? tiles : cus;
+    // epilogue specialisation (gemm_kernel_pc's header): native / f16 / split-bf16 16-bit results, fp32 (+ residual)
+    int ep = 0, outk = a.out_f32;
+    const bool gelu = a.act == BD_ACT_GELU;
+    if (!a.addtab && a.rpg_in <= 0 && !a.wscale && a.N % 192 == 0 && a.K >= 128 && !(a.bias && ((uintptr_t)a.bias & 15))) {
+        if (a.out_f32 == OUT_F32) ep = (gelu || a.rms_wq) ? 0 : 3;
+        else if (!a.resid && (outk == OUT_OPERAND || outk == OUT_F16 || outk == OUT_BF16X2)) ep = a.rms_wq ? (gelu ? 0 : 2) : 1;
+    }
+    if (ep == 1 && gelu && outk != OUT_OPERAND) ep = 0;
+    const bool s3 = (a.K / 32) % 3 == 0;
+    const dim3 g(grid), b(768);
+#define BD_C8_LAUNCH(EP_, OUTK_, GELU_)                                                                     \
+    { if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_>), g, b, 0, s, a);                 \
+      else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, EP_, OUTK_, GELU_>), g, b, 0, s, a); }
+    if (ep == 3) BD_C8_LAUNCH(3, OUT_F32, false)
+    else if (ep == 2 && outk == OUT_OPERAND) BD_C8_LAUNCH(2, OUT_OPERAND, false)
+    else if (ep == 2 && outk == OUT_F16) BD_C8_LAUNCH(2, OUT_F16, false)
+    else if (ep == 2) BD_C8_LAUNCH(2, OUT_BF16X2, false)
+    else if (ep == 1 && gelu) BD_C8_LAUNCH(1, OUT_OPERAND, true)
+    else if (ep == 1 && outk == OUT_OPERAND) BD_C8_LAUNCH(1, OUT_OPERAND, false)
+    else if (ep == 1 && outk == OUT_F16) BD_C8_LAUNCH(1, OUT_F16, false)
+    else if (ep == 1) BD_C8_LAUNCH(1, OUT_BF16X2, false)
+    else BD_C8_LAUNCH(0, OUT_OPERAND, false)
+#undef BD_C8_LAUNCH
+    bd_trace_close(s, slot);
+    BD_CHECK_LAUNCH();
+    return BD_OK;
+}
+

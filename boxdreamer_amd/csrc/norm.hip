@@ -64,8 +64,14 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_kernel(T* __restrict__ qkv, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float y = w[c * 8 + j] * (f[c][j] * r);
-            hi[j] = from_f32<T>(y);
-            if (NS == 2) lo[j] = from_f32<T>(y - to_f32<T>(hi[j]));
+            if (NS == 2) {
+                float h, l;
+                split_hi_lo<T>(y, h, l);
+                hi[j] = from_f32<T>(h);
+                lo[j] = from_f32<T>(l);
+            } else {
+                hi[j] = from_f32<T>(y);
+            }
         }
         *(vec8*)(ptr + c * 8) = hi;
         if (NS == 2) *(vec8*)(ptr + plane + c * 8) = lo;
@@ -116,8 +122,14 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_row_kernel(T* __restrict__ qkv
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float y = (j < 4 ? w0[j] : w1[j - 4]) * (f[c][j] * r);
-            hi[j] = from_f32<T>(y);
-            if (NS == 2) lo[j] = from_f32<T>(y - to_f32<T>(hi[j]));
+            if (NS == 2) {
+                float h, l;
+                split_hi_lo<T>(y, h, l);
+                hi[j] = from_f32<T>(h);
+                lo[j] = from_f32<T>(l);
+            } else {
+                hi[j] = from_f32<T>(y);
+            }
         }
         *(vec8*)(ptr + c * 8) = hi;
         if (NS == 2) *(vec8*)(ptr + plane + c * 8) = lo;

@@ -10,8 +10,10 @@ from oracle import boxdreamer_oracle as orc
 
 pytestmark = pytest.mark.gpu
 PRECS = ["bf16", "fp16", "bf16x3"]
-# operand rounding of the mode (relative); bf16x3 keeps ~16 mantissa bits
-EPS = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11, "bf16x3": 2.0 ** -15}
+PRECS_LIN = PRECS + ["f16x3"]          # operand classes of the Linears / their producers (attention takes f16x3 only as an OUTPUT class)
+SPLIT = ("bf16x3", "f16x3")
+# operand rounding of the mode (relative); bf16x3 keeps ~16 mantissa bits, f16x3 ~22
+EPS = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11, "bf16x3": 2.0 ** -15, "f16x3": 2.0 ** -20}
 
 
 def _rand(name, shape, std=1.0, seed=3):
@@ -23,7 +25,7 @@ def _q(x, prec):
     return hip_ops.from_operand(hip_ops.to_operand(x, prec), prec)
 
 
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", PRECS_LIN)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (77, 1568, 768), (1000, 768, 3072),
                                    (2048, 768, 128), (1500, 1536, 192), (1300, 1568, 64), (2304, 2304, 768)])
 def test_gemm_plain(hip, prec, M, N, K):
@@ -33,7 +35,7 @@ def test_gemm_plain(hip, prec, M, N, K):
     ref = (_q(a, prec).double() @ _q(w, prec).double().t() + b.double()).float()
     err = (out.cpu() - ref).abs().max().item()
     # operands are exactly representable -> only fp32 accumulation order (and the dropped lo*lo term) differ
-    tol = 2e-5 * K ** 0.5 if prec != "bf16x3" else 2e-5 * K ** 0.5 + 1e-4
+    tol = 2e-5 * K ** 0.5 if prec != "bf16x3" else 2e-5 * K ** 0.5 + 1e-4      # (f16x3's dropped lo*lo term is ~2^-22: no allowance)
     assert err < tol, (prec, err)
     # transpose / layout detector: asymmetric operands, exact small integers
     ai = torch.arange(M * K, dtype=torch.float32).reshape(M, K).remainder(7) - 3
@@ -82,7 +84,7 @@ def test_gemm_f16c8(hip, M, N, K):
         assert ((o[0].float() + o[1].float()).cpu() - ref.float()).abs().max().item() < 2.0 ** -15 * max(1.0, ref.abs().max().item()) + 2e-5 * K ** 0.5
 
 
-@pytest.mark.parametrize("prec", PRECS + ["fp8"])
+@pytest.mark.parametrize("prec", PRECS_LIN + ["fp8"])
 @pytest.mark.parametrize("M,N,K", [(7500, 2304, 768), (9000, 3072, 640), (16500, 1024, 320)])
 def test_gemm_block_sized(hip, prec, M, N, K):
     """Transformer-block sized Linears (hundreds of 256x256 / 128x128 tiles, several tile rounds per CU, ragged last
@@ -121,7 +123,7 @@ def test_gemm_block_sized(hip, prec, M, N, K):
     assert (buf - want).abs().max().item() <= tol
 
 
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", PRECS_LIN)
 def test_gemm_epilogues(hip, prec):
     M, N, K, P, TPI, OFF = 512, 256, 128, 256, 261, 5
     a, w, b = _rand("a2", (M, K)), _rand("w2", (N, K), 0.05), _rand("b2", (N,), 0.1)
@@ -147,7 +149,7 @@ def test_gemm_epilogues(hip, prec):
     assert torch.equal(buf.cpu()[untouched], res[untouched])
 
 
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", PRECS_LIN)
 @pytest.mark.parametrize("affine,eps", [(True, 1e-5), (True, 1e-6), (False, 1e-6)])
 def test_layernorm(hip, prec, affine, eps):
     x = _rand("lnx", (1001, 768), 2.0) + 0.3
@@ -164,7 +166,7 @@ def test_layernorm(hip, prec, affine, eps):
     assert (o32.cpu() - F.layer_norm(x[idx], (768,), None, None, eps)).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", PRECS_LIN)
 @pytest.mark.parametrize("hd,heads", [(96, 8), (64, 12)])
 def test_qk_rmsnorm(hip, prec, hd, heads):
     rows = 333
@@ -180,7 +182,7 @@ def test_qk_rmsnorm(hip, prec, hd, heads):
     assert torch.equal(got[:, 2], src[:, 2])           # v untouched
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp16", "bf16x3", "fp8"])
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "bf16x3", "f16x3", "fp8"])
 @pytest.mark.parametrize("N,K,kind", [(2304, 768, "plain"), (2304, 768, "rms"), (3072, 768, "gelu"), (768, 768, "resid"),
                                       (768, 3072, "resid"), (768, 768, "f32")])
 def test_gemm_row_result_independent_of_tile_shape(hip, prec, N, K, kind):
@@ -492,7 +494,7 @@ def test_attention_prefix_split(hip, variant, batch, seq, heads, npre):
         assert torch.equal(skip.reshape(2, batch, seq, -1)[:, :, :npre], keep.reshape(2, batch, seq, -1)[:, :, :npre])
 
 
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", PRECS_LIN)
 def test_im2col_and_patchify(hip, prec):
     data = synth.make_batch(seed=21, B=1, T=2)
     img = data["images"][0]                                          # (2,3,224,224)

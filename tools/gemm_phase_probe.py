@@ -45,8 +45,10 @@ def run(M, N, K, prec="bf16"):
         rms = (torch.ones(96, device="cuda"), torch.ones(96, device="cuda"), 1e-6)
     for _ in range(3):
         hip_ops.gemm(a, w, b, prec=prec, w_qexp=qe, rms=rms)
-    lib.bd_gemm_probe_set.argtypes = [C.c_void_p]
-    assert lib.bd_gemm_probe_set(C.c_void_p(buf.data_ptr())) == 0
+    for setter in ("bd_gemm_probe_set", "bd_gemm_f16c8_probe_set"):      # one probe buffer pointer per GEMM translation unit
+        fn = getattr(lib, setter)
+        fn.argtypes = [C.c_void_p]
+        assert fn(C.c_void_p(buf.data_ptr())) == 0
     torch.cuda.synchronize()
     for _ in range(int(os.environ.get("BD_PROBE_LAUNCHES", "60"))):      # back to back: the stamps of the LAST launch survive,
         hip_ops.gemm(a, w, b, prec=prec, w_qexp=qe, rms=rms)                          # taken at sustained (DVFS-settled) clocks
