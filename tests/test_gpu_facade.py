@@ -122,6 +122,26 @@ def test_reference_feature_cache_is_bit_identical(hip):
         assert torch.equal(model.decoder.last_logits, logits_ref)
         assert torch.equal(out["pred_bbox"], ref["pred_bbox"])
         assert torch.equal(out["regression_boxes"], ref["regression_boxes"])
+    # with a PROMOTED adapter the encoder hands its features over as split-f16 planes (another operand class in the cache): same bits
+    # again, and features cached BEFORE the promotion state changed are refused loudly by the re-cast guard, never misread
+    from boxdreamer_amd import _lib, calibrate
+    model = BoxDreamer(_config("f16c8_qk16"))
+    model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
+    model = model.cuda().eval()
+    st = calibrate.get_state(model.rgb_encoder, model.decoder)
+    st["dec_misc"] = _lib.PROMOTE_ADAPTER_FC1 | _lib.PROMOTE_BBOX_PROJ
+    st["enc"][1] = _lib.PROMOTE_PROJ | _lib.PROMOTE_FC2
+    calibrate.set_state(model.rgb_encoder, model.decoder, st)
+    model._calibrated_for = model.decoder._signature()                 # (this state is the test's: no self-calibration on top)
+    ref = model(dict(dev))
+    logits_ref = model.decoder.last_logits.clone()
+    assert model.rgb_encoder.model.feats_class() == _lib.PREC_F16X3
+    cache = RefFeatureCache(model.rgb_encoder)
+    feats = cache.encode(dev["images"][~ref["camera_mask"]].reshape(B, T - 1, 3, 224, 224))
+    d2 = dict(dev)
+    d2["cached_rgb_feat"], d2["cached_rgb_mask"] = cache.place(feats, dev["query_idx"], T)
+    model(d2)
+    assert torch.equal(model.decoder.last_logits, logits_ref) and model.decoder.recast_count == 0
 
 
 def test_hip_graph_replay_matches_eager(hip):

@@ -266,7 +266,9 @@ def test_fp8_mixed_policy(hip):
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/fp8_mixed_report.json", "w") as f:
         json.dump(res, f, indent=1)
-    assert res["fp8_mixed"]["logits_rms"] <= 0.75 * res["fp8"]["logits_rms"]
+    # e4m3's error is spread evenly over the Linear types (CPU emulation, profiles/r4_fp8.md: any ONE type in e4m3 costs 0.05-0.065
+    # rms), so keeping a third of the Linear FLOPs in bf16 buys ~20 %, not an order of magnitude
+    assert res["fp8_mixed"]["logits_rms"] <= 0.9 * res["fp8"]["logits_rms"]
     assert res["fp8_mixed"]["logits_max_abs"] <= 0.6 and res["fp8_mixed"]["logits_rms"] <= 0.12
     assert res["fp8_mixed"]["peaked_corner_px_max"] <= 1.0 and res["fp8"]["peaked_corner_px_max"] <= 1.5
 
