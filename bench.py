@@ -706,7 +706,7 @@ def gather_latency_ms(kp, world, dist, gather, reps: int = 50, sync=None) -> flo
 
 
 def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, counters, counters_why):
-    peak = PEAK_MFMA_FP8 if prec == "fp8" else PEAK_MFMA_16BIT
+    peak = PEAK_MFMA_FP8 if prec in ("fp8", "fp8_mixed") else PEAK_MFMA_16BIT      # (mixed: priced against the e4m3 peak too: conservative)
     g = [(2.0 * m * n * k, ms) for kind, m, n, k, ms in recs if kind == 0]
     a = [(4.0 * m * n * n * k, ms) for kind, m, n, k, ms in recs if kind == 1]   # 4*S^2*d per (batch*head)
     gemm_tf = sum(f for f, _ in g) / max(sum(ms for _, ms in g), 1e-9) / 1e9 if g else 0.0
@@ -957,9 +957,9 @@ def workload_name(B: int, T: int, prec: str, world: int, cache_refs: bool) -> st
     tail = ", DINOv2 ViT-B/14-reg + BETR-12 + top-20 decode, random-init weights, inputs bf16 in HBM"
     if cache_refs:
         return "SURVEY 8f1 (reference features cached): " + shape + tail
-    if prec == "fp8" and T == 6 and B == 64:
-        return "configs[4]: fp8 (e4m3) Linears, " + shape + tail
-    if T == 6 and B == 32 and prec != "fp8":
+    if prec in ("fp8", "fp8_mixed") and T == 6 and B == 64:
+        return ("configs[4]: fp8 (e4m3) Linears, " if prec == "fp8" else "configs[4], mixed policy: e4m3 MLPs / DINOv2 QKV, bf16 elsewhere, ") + shape + tail
+    if T == 6 and B == 32 and prec not in ("fp8", "fp8_mixed"):
         return "configs[1]: " + shape + tail
     if T == 17:
         full = B * world == 256 and world == 8

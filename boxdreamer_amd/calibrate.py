@@ -138,23 +138,32 @@ def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUD
                 on = [True] * nu
                 on[k] = False
                 e.append(float((run(on) - ref).abs().max()))
-            order = sorted(range(nu), key=lambda k: e[k] / units[k][4])          # cheapest-to-keep first
-            lo, hi = 0, nu                     # invariant: keeping order[:lo] is fine, keeping order[:hi] is not (hi = nu: d0 > budget)
-            deltas = {0: 0.0, nu: d0}
-            while hi - lo > 1:
-                mid = (lo + hi) // 2
-                on = [True] * nu
-                for k in order[:mid]:
-                    on[k] = False
-                deltas[mid] = float((run(on) - ref).abs().max())
-                if deltas[mid] <= budget:
-                    lo = mid
-                else:
-                    hi = mid
+            # Which units may stay in the default class?  A knapsack: keep as much WORK as possible while the errors -- which add
+            # roughly in quadrature -- stay inside the budget.  Two greedy orders (e^2 per unit of work: the knapsack ratio; e per
+            # unit of work), each with a MEASURED binary search for the longest admissible prefix; the cheaper result wins.
+            best = None
+            for key in (lambda k: e[k] * e[k] / units[k][4], lambda k: e[k] / units[k][4]):
+                order = sorted(range(nu), key=key)
+                lo, hi = 0, nu                 # invariant: keeping order[:lo] is fine, keeping order[:hi] is not (hi = nu: d0 > budget)
+                deltas = {0: 0.0, nu: d0}
+                while hi - lo > 1:
+                    mid = (lo + hi) // 2
+                    on = [True] * nu
+                    for k in order[:mid]:
+                        on[k] = False
+                    deltas[mid] = float((run(on) - ref).abs().max())
+                    if deltas[mid] <= budget:
+                        lo = mid
+                    else:
+                        hi = mid
+                cost = sum(units[k][4] for k in order[lo:])
+                if best is None or cost < best[0]:
+                    best = (cost, order, lo, deltas[lo])
+            _, order, lo, dfin = best
             chosen = [True] * nu
             for k in order[:lo]:
                 chosen[k] = False
-            rep.update(delta_final=deltas[lo], unit_errors={units[k][0]: round(e[k], 7) for k in order[::-1][:12]})
+            rep.update(delta_final=dfin, unit_errors={units[k][0]: round(e[k], 7) for k in sorted(range(nu), key=lambda k: -e[k])[:12]})
         else:
             rep.update(delta_final=d0)
         set_state(encoder, decoder, _state_of(units, chosen, n_enc, n_dec))
