@@ -39,7 +39,7 @@ SPILL_ALLOWED = {      # regex on the mangled name -> tolerated scratch bytes
     # heatmap-embed GEMMs (2 of the 101 launches of a step) and the hand-off GEMMs of promoted Linears; its spills live in the epilogue
     # (profiles/r2_gemm_epilogue.md), the specialised epilogues EP 1-3 that every block Linear takes must stay at zero
     r"gemm_kernel_pc_f16c8ILi[23]ELi0ELi0ELb0EE": 256,
-    r"gemm_kernel_pcI.*Li4ELi0ELi0ELb0EE": 256,
+    r"gemm_kernel_pcI.*Li4ELi0ELi0ELb0ELi0EE": 256,
 }
 
 

@@ -223,7 +223,14 @@ __global__ __launch_bounds__(WM * WN * 64, NSTG == 2 ? 2 : 1) void gemm_kernel_g
 // store touching 32 rows x 32 bytes is issue-bound in the texture path), non-temporal vs plain stores (equal), start-up
 // staggers that spread the CUs' epilogues over the tile period (+1 % / -9 % QKV, -7 % / -2 % fc1).
 
-template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NPW, int EP, int OUTK, bool GELU>
+// RING (round 4): 0 = two symmetric stages (above).  1 = an ASYMMETRIC operand ring: A three slabs deep, W two (3 x 32 + 2 x 24 KiB; three
+// whole 56-KiB stages do not fit the 160 KiB).  After B(g) the producers fetch W(g+1) -- 24 pieces, ~550 cycles of issue + the landing
+// latency: inside the 1536 cycles of matrix work slab g holds -- and then A(g+2), which has a whole extra slab to land.  The 2-stage
+// form needs ~1000 + ~840 cycles for slab g+1 against those 1536, and the counters show the consumers parked at the slab barrier for
+// ~28 % of their time (profiles/r4_gemm_counters.md); the F16C8 kernel, whose 3-stage ring of 48-KiB stages fits, shows ~7 %.
+// DMA rows stay 128 bytes (round 3's deeper rings shortened them and lost).  The epilogue scratch (8 waves x 6 KiB) is the two operand
+// buffers the tile's last slab lived in -- rows 0-7 of a 16-row chunk in the W buffer, rows 8-15 in the A buffer (pc_epilogue: sc, sc_hi).
+template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NPW, int EP, int OUTK, bool GELU, int RING = 0>
 __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const bd_gemm_args p) {
     bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 frag_t;
@@ -244,8 +251,14 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
     static_assert(EP == 0 || (MI == 2 && NI == 3 && SR == 16 && TBN <= 256), "pc_epilogue is written for 96-column wave tiles");
     // side buffer behind the ring: per-column vectors of the current / next tile (2 x [bias 1 KiB | weight scale 1 KiB]) and
     // the q / k RMSNorm weights (2 x 1 KiB)
-    constexpr int AUX_COLP = 2 * STAGE_BYTES, AUX_RMS = AUX_COLP + 4096, AUX_BYTES = EP == 0 ? 0 : 6144;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES + AUX_BYTES];
+    constexpr int RA = NS * A_BYTES, RW = NS * W_BYTES;            // one slab's A / W image (all planes)
+    constexpr int RING_BYTES = RING ? 3 * RA + 2 * RW : 2 * STAGE_BYTES;
+    static_assert(RING == 0 || (EP != 0 && NCW * 8 * NI * 32 * 4 <= RW && NCW * 8 * NI * 32 * 4 <= RA), "split scratch: half a chunk per buffer");
+    constexpr int AUX_COLP = RING_BYTES, AUX_RMS = AUX_COLP + 4096, AUX_BYTES = EP == 0 ? 0 : 6144;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[RING_BYTES + AUX_BYTES];
+    // byte offset of slab g's A / W image inside the ring (ga = g % 3, gw = g % 2 in the asymmetric form; both = g & 1 otherwise)
+    auto off_a = [](int ga) { return RING ? ga * RA : ga * STAGE_BYTES; };
+    auto off_w = [](int gw) { return RING ? 3 * RA + gw * RW : gw * STAGE_BYTES + RA; };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -292,20 +305,36 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
             offW[j] = (unsigned)row * ldw_b + swz_chunk<CH>(row, lane % CH) * 16;
         }
         const int64_t a_plane = p.a_plane * ESZ, w_plane = p.w_plane * ESZ;
-        auto issue = [&](int stage, int m0, int n0, int kt) {
-            const int rows_a = (M - m0) < TBM ? (M - m0) : TBM, rows_w = (N - n0) < TBN ? (N - n0) : TBN;
-            const unsigned lim_a = (unsigned)(rows_a - 1) * lda_b + (CH - 1) * 16, lim_w = (unsigned)(rows_w - 1) * ldw_b + (CH - 1) * 16;
-            const unsigned st = lds_off + stage * STAGE_BYTES + pw * 1024;
+        auto issue_a = [&](int ga, int m0, int kt) {
+            const int rows_a = (M - m0) < TBM ? (M - m0) : TBM;
+            const unsigned lim_a = (unsigned)(rows_a - 1) * lda_b + (CH - 1) * 16;
+            const unsigned st = lds_off + off_a(ga) + pw * 1024;
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2) {
                 const unsigned char* ba = (const unsigned char*)p.A + (int64_t)m0 * lda_b + (int64_t)kt * ROWB + s2 * a_plane;
-                const unsigned char* bw = (const unsigned char*)p.W + (int64_t)n0 * ldw_b + (int64_t)kt * ROWB + s2 * w_plane;
 #pragma unroll
                 for (int j = 0; j < PA / NPW; ++j)
                     glds16_s(offA[j] < lim_a ? offA[j] : lim_a, ba, st + s2 * A_BYTES + j * NPW * 1024);
+            }
+        };
+        auto issue_w = [&](int gw, int n0, int kt) {
+            const int rows_w = (N - n0) < TBN ? (N - n0) : TBN;
+            const unsigned lim_w = (unsigned)(rows_w - 1) * ldw_b + (CH - 1) * 16;
+            const unsigned st = lds_off + off_w(gw) + pw * 1024;
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const unsigned char* bw = (const unsigned char*)p.W + (int64_t)n0 * ldw_b + (int64_t)kt * ROWB + s2 * w_plane;
 #pragma unroll
                 for (int j = 0; j < PW / NPW; ++j)
-                    glds16_s(offW[j] < lim_w ? offW[j] : lim_w, bw, st + NS * A_BYTES + s2 * W_BYTES + j * NPW * 1024);
+                    glds16_s(offW[j] < lim_w ? offW[j] : lim_w, bw, st + s2 * W_BYTES + j * NPW * 1024);
+            }
+        };
+        auto issue = [&](int stage, int m0, int n0, int kt) { issue_a(stage, m0, kt); issue_w(stage, n0, kt); };
+        auto issue_colp = [&](int n0, int slot) {     // a tile's per-column vectors (N % TBN == 0: TBN floats are in bounds), producer wave 0
+            if (pw == 0) {
+                const unsigned off = (unsigned)lane * 16 < (unsigned)(TBN * 4 - 16) ? (unsigned)lane * 16 : (unsigned)(TBN * 4 - 16);
+                if (p.bias) glds16_s(off, (const unsigned char*)(p.bias + n0), lds_off + AUX_COLP + (slot & 1) * 2048);
+                if (sizeof(T) == 1 && p.wscale) glds16_s(off, (const unsigned char*)(p.wscale + n0), lds_off + AUX_COLP + (slot & 1) * 2048 + 1024);
             }
         };
 #ifdef BD_GEMM_PROBE
@@ -329,12 +358,8 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
         auto issue_next = [&]() {
             if (it >= t_end) return;
             if constexpr (EP != 0) {
-                if (ikt == 0) {   // the tile's per-column vectors ride with its first slab (N % TBN == 0: TBN floats are in bounds)
-                    if (pw == 0) {
-                        const unsigned off = (unsigned)lane * 16 < (unsigned)(TBN * 4 - 16) ? (unsigned)lane * 16 : (unsigned)(TBN * 4 - 16);
-                        if (p.bias) glds16_s(off, (const unsigned char*)(p.bias + in0), lds_off + AUX_COLP + (itn & 1) * 2048);
-                        if (sizeof(T) == 1 && p.wscale) glds16_s(off, (const unsigned char*)(p.wscale + in0), lds_off + AUX_COLP + (itn & 1) * 2048 + 1024);
-                    }
+                if (ikt == 0) {   // the tile's per-column vectors ride with its first slab
+                    issue_colp(in0, itn);
                     ++itn;
                 }
             }
@@ -346,6 +371,44 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 if (it < t_end) tile_origin(it, im0, in0);
             }
         };
+        if constexpr (RING == 1) {
+            // Two cursors over this workgroup's slab sequence (all its tiles, slab by slab): A runs two slabs ahead of the consumers, W
+            // one.  Program order of this wave's DMA:  A(0) W(0) A(1) | B(0) | W(1) A(2) | B(1) | W(2) A(3) | ...  Before B(g) everything
+            // but the YOUNGEST A image (A(g+1), PA / NPW pieces per plane) must have landed: a counted vmcnt, the pieces of a tile's
+            // column vectors are older than the W image they precede.
+            struct Cur { int t, kt, m0, n0, g; };
+            Cur ca{t_begin + (bid >> 3), 0, 0, 0, 0}, cw = ca;
+            if (ca.t < t_end) { tile_origin(ca.t, ca.m0, ca.n0); cw.m0 = ca.m0; cw.n0 = ca.n0; }
+            auto advance = [&](Cur& c) {
+                ++c.g;
+                if (++c.kt == nk) { c.kt = 0; c.t += stride; if (c.t < t_end) tile_origin(c.t, c.m0, c.n0); }
+            };
+            int ga = 0, gw = 0, tiles_w = 0;                       // ring positions of the NEXT A / W image to fetch
+            auto fetch_a = [&]() { if (ca.t < t_end) { issue_a(ga, ca.m0, ca.kt); ga = ga == 2 ? 0 : ga + 1; advance(ca); } };
+            auto fetch_w = [&]() {
+                if (cw.t < t_end) {
+                    if (cw.kt == 0) { issue_colp(cw.n0, tiles_w); ++tiles_w; }
+                    issue_w(gw, cw.n0, cw.kt); gw ^= 1; advance(cw);
+                }
+            };
+            constexpr int YOUNG = NS * (PA / NPW);                 // pieces of one A image issued by this wave
+            fetch_a(); fetch_w(); fetch_a();
+            int g = 0;
+            for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
+                for (int kt = 0; kt < nk; ++kt, ++g) {
+                    if (ca.g > g + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG) : "memory");     // A(g+1) may still fly
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    pc_barrier();                      // B(g): A(g), W(g) landed; the images of slab g-1 are dead
+                    fetch_w();                         // W(g+1), first: the consumers need it at B(g+1)
+                    fetch_a();                         // A(g+2)
+                }
+                // (e4m3 class, fp32-residual epilogue: the NEXT tile's column scales are read inside this tile's epilogue -- they rode in
+                // front of W(g) of that tile's first slab, fetched one slab ago; everything else waits at the next B, after the epilogue)
+                if constexpr (sizeof(T) == 1 && EP == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pc_barrier();                          // X: every consumer is done with the tile's last slab
+            }
+            return;
+        }
         issue_next();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int g = 0;
@@ -375,6 +438,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
 #endif
     BD_PROBE(58) BD_PROBE_RT(56)
     int g = 0;       // (the host launches this kernel only when the wide, 16-byte epilogue applies: wide_epilogue_ok)
+    int ga = 0;      // RING 1: g % 3, the A image of the current slab
     int ti = 0;      // tiles done by this workgroup (parity = side-buffer slot of the tile's column vectors)
     f32x16 acc[MI][NI];
     if constexpr (EP != 0) {      // first tile; later tiles are initialised inside the previous tile's epilogue
@@ -390,7 +454,9 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
             BD_PROBE_IF(g < 20, g * 3)
             pc_barrier();                              // B(kt)
             BD_PROBE_IF(g < 20, g * 3 + 1)
-            const unsigned char* base = lds + (g & 1) * STAGE_BYTES;
+            const unsigned char* const baseA = lds + off_a(RING ? ga : (g & 1));
+            const unsigned char* const baseW = lds + off_w(RING ? (g & 1) : (g & 1));
+            if constexpr (RING == 1) ga = ga == 2 ? 0 : ga + 1;
             constexpr int FB = NS == 1 ? 2 : 1;
             frag_t a[FB][NS][MI], b[FB][NS][NI];
 #define LOAD_ONE(dst, ptr, row, ks)                                                                           \
@@ -407,9 +473,9 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
 #define LOAD_FRAGS(ks, slot)                                                                                  \
             _Pragma("unroll") for (int s2 = 0; s2 < NS; ++s2) {                                               \
                 _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                \
-                    LOAD_ONE(a[slot][s2][i], base + s2 * A_BYTES, wm * (MI * 32) + i * 32 + lrow, ks)         \
+                    LOAD_ONE(a[slot][s2][i], baseA + s2 * A_BYTES, wm * (MI * 32) + i * 32 + lrow, ks)         \
                 _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                \
-                    LOAD_ONE(b[slot][s2][j], base + NS * A_BYTES + s2 * W_BYTES, wn * (NI * 32) + j * 32 + lrow, ks) \
+                    LOAD_ONE(b[slot][s2][j], baseW + s2 * W_BYTES, wn * (NI * 32) + j * 32 + lrow, ks) \
             }
             if constexpr (NS == 1) {
                 // Software pipeline inside the slab, order PINNED (sched_barrier(0) after every MFMA / ds_read pair): the
@@ -424,8 +490,8 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 auto load_q = [&](int slot, int ks, int q) {
                     const int which = (q < 2 * (MI < NI ? MI : NI)) ? (q & 1) : (MI > NI ? 0 : 1);   // 0: an A fragment, 1: a W fragment
                     const int idx = (q < 2 * (MI < NI ? MI : NI)) ? (q >> 1) : (q - (MI < NI ? MI : NI));
-                    if (which == 0) LOAD_ONE(a[slot][0][idx], base, wm * (MI * 32) + idx * 32 + lrow, ks)
-                    else LOAD_ONE(b[slot][0][idx], base + NS * A_BYTES, wn * (NI * 32) + idx * 32 + lrow, ks)
+                    if (which == 0) LOAD_ONE(a[slot][0][idx], baseA, wm * (MI * 32) + idx * 32 + lrow, ks)
+                    else LOAD_ONE(b[slot][0][idx], baseW, wn * (NI * 32) + idx * 32 + lrow, ks)
                 };
 #pragma unroll
                 for (int q = 0; q < NRD; ++q) load_q(0, 0, q);
@@ -451,8 +517,8 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 // so one ds_read rides under almost every MFMA and no wave depends on its SIMD partner to cover its reads.
                 constexpr int NMM = MI * NI;
                 frag_t ah[2][MI], wh[2][NI], al[MI], wl[NI];
-                const unsigned char* wbase = base + NS * A_BYTES;
-#define LD_A(dst, plane, idx, ks) LOAD_ONE(dst, base + (plane) * A_BYTES, wm * (MI * 32) + (idx) * 32 + lrow, ks)
+                const unsigned char* wbase = baseW;
+#define LD_A(dst, plane, idx, ks) LOAD_ONE(dst, baseA + (plane) * A_BYTES, wm * (MI * 32) + (idx) * 32 + lrow, ks)
 #define LD_W(dst, plane, idx, ks) LOAD_ONE(dst, wbase + (plane) * W_BYTES, wn * (NI * 32) + (idx) * 32 + lrow, ks)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) LD_W(wh[0][j], 0, j, 0)
@@ -510,13 +576,18 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
         BD_PROBE_IF(g == nk, 61)
         {   // LDS-staged epilogue; its scratch is the stage the tile's last slab lived in (free after X)
             unsigned char* scratch = lds + ((g - 1) & 1) * STAGE_BYTES + wid * (SR * NI * 32 * 4);
+            unsigned char* scratch_hi = scratch + 8 * NI * 32 * 4;
+            if constexpr (RING == 1) {         // the W and the A image of the tile's last slab (ga already points one past it)
+                scratch = lds + off_w((g - 1) & 1) + wid * (8 * NI * 32 * 4);
+                scratch_hi = lds + off_a(ga == 0 ? 2 : ga - 1) + wid * (8 * NI * 32 * 4);
+            }
             if constexpr (EP == 0) {
                 gemm_epilogue_lds<T, NS, MI, NI, SR, true>(p, acc, scratch, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
             } else {
                 const bool has_next = t + stride < t_end;
                 int nm0 = 0, nn0 = 0;
                 if (has_next) tile_origin(t + stride, nm0, nn0);
-                pc_epilogue<T, NS, EP, OUTK, GELU, MI>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
+                pc_epilogue<T, NS, EP, OUTK, GELU, MI>(p, acc, (float*)scratch, (float*)scratch_hi, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
                                                   (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
                                                   lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
             }
@@ -560,10 +631,17 @@ template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_p
     int outk = 0;
     bool gelu = false;
     const int ep = (a.N % TBN == 0) ? pc_epilogue_kind<T, NS>(a, outk, gelu) : 0;
-#define BD_PC_LAUNCH(EP_, OUTK_, GELU_) hipLaunchKernelGGL((gemm_kernel_pc<T, NS, BK, WM, WN, MI, NI, NPW, EP_, OUTK_, GELU_>), g, b, 0, s, a)
+    // Operand ring: the asymmetric A3 / W2 form for every specialised epilogue (same-box A/B, profiles/r4_gemm_ring.md: K = 3072 +8-16 %,
+    // split classes +3-9 %, e4m3 +4 %, K = 768 within 1 %) except the shallow fp32-residual Linears of the plain 16-bit classes (proj,
+    // K = 768: HBM-bound, 2.5-5 % slower with it).  A row's result does not depend on the choice (same K order): it follows the
+    // launch's class, K and epilogue only, never M.
+    const bool ring0_ep3 = NS == 1 && sizeof(T) == 2 && a.K < 1536;
+#define BD_PC_LAUNCH_R(EP_, OUTK_, GELU_, RING_) hipLaunchKernelGGL((gemm_kernel_pc<T, NS, BK, WM, WN, MI, NI, NPW, EP_, OUTK_, GELU_, RING_>), g, b, 0, s, a)
+#define BD_PC_LAUNCH(EP_, OUTK_, GELU_) BD_PC_LAUNCH_R(EP_, OUTK_, GELU_, ((EP_) != 0 ? 1 : 0))
     constexpr int ALT = (NS == 2 && sizeof(T) == 2) ? OUT_F16 : (sizeof(T) == 1 ? OUT_BF16 : OUT_OPERAND);   // the one non-native 16-bit kind
     constexpr bool X2 = NS == 2 && std::is_same<T, _Float16>::value;     // split-f16 also emits split-bf16 planes (attention input)
-    if (ep == 3) BD_PC_LAUNCH(3, OUT_F32, false);
+    if (ep == 3 && ring0_ep3) BD_PC_LAUNCH_R(3, OUT_F32, false, 0);
+    else if (ep == 3) BD_PC_LAUNCH(3, OUT_F32, false);
     else if (ep == 2 && outk == OUT_BF16X2) { if constexpr (X2) BD_PC_LAUNCH(2, OUT_BF16X2, false); }
     else if (ep == 2) { if (outk == OUT_OPERAND) BD_PC_LAUNCH(2, OUT_OPERAND, false); else BD_PC_LAUNCH(2, ALT, false); }
     else if (ep == 1 && gelu && outk == OUT_OPERAND) BD_PC_LAUNCH(1, OUT_OPERAND, true);
@@ -571,6 +649,7 @@ template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_p
     else if (ep == 1 && !gelu) { if (outk == OUT_OPERAND) BD_PC_LAUNCH(1, OUT_OPERAND, false); else BD_PC_LAUNCH(1, ALT, false); }
     else BD_PC_LAUNCH(0, OUT_OPERAND, false);
 #undef BD_PC_LAUNCH
+#undef BD_PC_LAUNCH_R
 }
 
 template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NSTG = 2> void launch_glds(const bd_gemm_args& a, hipStream_t s) {

@@ -384,7 +384,7 @@ __device__ __forceinline__ float quad_sum(float x) {
 //   wcol: first column of the wave tile inside the workgroup tile;  (wm0, wn0): its global origin
 //   next: the wave tile origin of this workgroup's next tile (EP 3 pre-loads its residual), has_next = there is one
 template <class T, int NS, int EP, int OUTK, bool GELU, int MI = 2>
-__device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)[MI][3], float* sc, const float* colp, const float* colp_next,
+__device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)[MI][3], float* sc, float* sc_hi, const float* colp, const float* colp_next,
                                             const float* rmsw, int wcol, int wm0, int wn0, int lane_, bool has_next, int nwm0, int nwn0) {
     constexpr int COLS = 96;
     // The lane id is re-derived HERE from an opaque instruction pair, so that none of the epilogue's lane-dependent addressing can be
@@ -409,7 +409,9 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
 #pragma unroll
             for (int r = hc * 8; r < hc * 8 + 8; ++r) {
                 const float a = acc[i][j][r];
-                sc[((r & 3) + 8 * ((r >> 2) - hc * 2) + 4 * lhalf) * COLS + j * 32 + lrow] = sizeof(T) == 1 ? fmaf(a, sj[j], bj[j]) : a + bj[j];
+                // rows 0-7 of the 16-row chunk live at sc, rows 8-15 at sc_hi (one contiguous block, or two regions of the operand ring)
+                float* const dst = ((r >> 2) - hc * 2) == 0 ? sc : sc_hi;
+                dst[((r & 3) + 4 * lhalf) * COLS + j * 32 + lrow] = sizeof(T) == 1 ? fmaf(a, sj[j], bj[j]) : a + bj[j];
             }
     };
     if constexpr (EP == 3) {
@@ -448,7 +450,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
                 const int gr = wm0 + i * 32 + hc * 16 + t * 8 + rsub;
                 f32x4 v[3];
 #pragma unroll
-                for (int cb = 0; cb < 3; ++cb) v[cb] = *(const f32x4*)(sc + (t * 8 + rsub) * COLS + cb * 32 + c4 * 4);
+                for (int cb = 0; cb < 3; ++cb) v[cb] = *(const f32x4*)((t == 0 ? sc : sc_hi) + rsub * COLS + cb * 32 + c4 * 4);
                 if (gr < M) {
                     float* op = (float*)p.out + (int64_t)gr * p.ldo + wn0 + c4 * 4;
 #pragma unroll
@@ -465,6 +467,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
         // one row PAIR, splits the dwords with two byte permutes each and stores two 16-byte row pieces; 12 lanes cover a row
         // (192-byte runs).  Same values, same roundings as the fp32 staging (the conversion is the separate step of store_cvt).
         unsigned* sp = (unsigned*)sc;
+        unsigned* sp_hi = (unsigned*)sc_hi;          // pair-rows 8-15
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -479,7 +482,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
                     typedef T pair_t __attribute__((ext_vector_type(2)));
                     const pair_t pr = {(T)x0, (T)x1};
                     const int prow = (pp & 1) + 4 * (pp >> 1) + 2 * lhalf;
-                    sp[prow * COLS + j * 32 + lrow] = __builtin_bit_cast(unsigned, pr);
+                    ((pp >> 1) < 2 ? sp : sp_hi - 8 * COLS)[prow * COLS + j * 32 + lrow] = __builtin_bit_cast(unsigned, pr);
                 }
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -488,7 +491,8 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int t = u * 64 + lane, prow = t / 12, cg = t % 12;
-                const u128 d0 = *(const u128*)(sp + prow * COLS + cg * 8), d1 = *(const u128*)(sp + prow * COLS + cg * 8 + 4);
+                const unsigned* const spr = (prow < 8 ? sp : sp_hi - 8 * COLS) + prow * COLS + cg * 8;
+                const u128 d0 = *(const u128*)spr, d1 = *(const u128*)(spr + 4);
                 u128 ra, rb;          // even row: low halves, odd row: high halves
                 ra[0] = __builtin_amdgcn_perm(d0[1], d0[0], 0x05040100u); ra[1] = __builtin_amdgcn_perm(d0[3], d0[2], 0x05040100u);
                 ra[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x05040100u); ra[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x05040100u);
@@ -536,7 +540,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
             float v[3][8];
 #pragma unroll
             for (int cb = 0; cb < 3; ++cb) {
-                const float* src = sc + rsub * COLS + cb * 32 + c8 * 8;
+                const float* src = (rsub < 8 ? sc : sc_hi - 8 * COLS) + rsub * COLS + cb * 32 + c8 * 8;
                 const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[cb][e] = a0[e]; v[cb][4 + e] = a1[e]; }

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
             const bool has_next = t + stride < t_end;
             int nm0 = 0, nn0 = 0;
             if (has_next) tile_origin(t + stride, nm0, nn0);
-            pc_epilogue<f16c8, 2, EP, OUTK, GELU, 2>(p, acc, (float*)scratch, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
+            pc_epilogue<f16c8, 2, EP, OUTK, GELU, 2>(p, acc, (float*)scratch, (float*)scratch + 8 * 96, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
                                                  (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
                                                  lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
         }
