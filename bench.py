@@ -741,7 +741,8 @@ def calibration_summary(rep: dict) -> dict:
         return {"applicable": False}
     return {"applicable": True, "self_check_unpromoted_max_abs_dlogits": rep["delta_unpromoted"], "self_check_final": rep["delta_final"],
             "budget": rep["budget"], "ok": rep["ok"], "promoted_units": len(rep["promoted"]), "units": rep["units"],
-            "promoted_work_frac": rep["promoted_cost_frac"], "forwards": rep["forwards"], "reference": rep["reference"]}
+            "promoted_work_frac": rep["promoted_cost_frac"], "forwards": rep["forwards"], "seconds": rep.get("seconds"),
+            "reference": rep["reference"]}
 
 
 def measure_mode(prec, args, device, world, rank, dist, images, bbox, mask, weights: str = "plain"):

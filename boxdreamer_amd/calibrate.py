@@ -118,6 +118,9 @@ def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUD
     units = units_of(encoder, decoder)
     n_enc, n_dec, nu = len(encoder.model.promote), len(decoder.hip_promote), len(units)
     forwards = 0
+    import time
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
 
     def run(promoted):
         nonlocal forwards
@@ -170,6 +173,8 @@ def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUD
         rep.update(promoted=[units[k][0] for k in range(nu) if chosen[k]], units=nu, forwards=forwards,
                    promoted_cost_frac=round(sum(units[k][4] for k in range(nu) if chosen[k]) / sum(u[4] for u in units), 4),
                    state=get_state(encoder, decoder), ok=bool(rep["delta_final"] <= budget))
+        torch.cuda.synchronize()
+        rep["seconds"] = round(time.perf_counter() - t_start, 3)
     finally:
         decoder.validate_inputs = validate
     if d0 > budget:
@@ -182,3 +187,44 @@ def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUD
         print("[calibrate] " + ", ".join(f"{k}={v}" for k, v in rep.items() if k not in ("state", "unit_errors")), flush=True)
     decoder.hip_calibration = rep
     return rep
+
+
+# ---------------------------------------------------------------------------------------------- persistence (optional)
+# The promotion state depends on the weights only (and mildly on the calibration sample): a deployment can measure once and reuse.
+
+def weights_fingerprint(encoder, decoder) -> str:
+    """A cheap content stamp of both weight sets (shapes + a few float64 sums): a stored promotion state is applied only to the weights
+    it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for name, sd in (("dec", decoder.state_dict()), ("enc", encoder.model.sd)):
+        for k in sorted(sd):
+            t = sd[k].detach()
+            h.update(f"{name}.{k}:{tuple(t.shape)}:{float(t.double().sum()):.10e}:{float(t.double().abs().sum()):.10e}".encode())
+    return h.hexdigest()[:24]
+
+
+def save_state(path: str, encoder, decoder, report: dict | None = None) -> None:
+    import json
+    rec = {"fingerprint": weights_fingerprint(encoder, decoder), "mode": str(decoder.hip_precision), "state": get_state(encoder, decoder)}
+    if report:
+        rec["report"] = {k: v for k, v in report.items() if k not in ("state",)}
+    with open(path, "w") as f:
+        json.dump(rec, f, indent=1)
+
+
+def load_state(path: str, encoder, decoder) -> bool:
+    """Apply a stored promotion state if it was measured on THESE weights in THIS mode; False (and nothing applied) otherwise."""
+    import json, os
+    if not os.path.isfile(path):
+        return False
+    rec = json.load(open(path))
+    if rec.get("mode") != str(decoder.hip_precision) or rec.get("fingerprint") != weights_fingerprint(encoder, decoder):
+        return False
+    st = rec["state"]
+    if len(st["enc"]) != len(encoder.model.promote) or len(st["dec"]) != len(decoder.hip_promote):
+        return False
+    set_state(encoder, decoder, st)
+    decoder.hip_calibration = dict(rec.get("report") or {}, applicable=True, loaded_from=path, state=st,
+                                   promoted=(rec.get("report") or {}).get("promoted", []))
+    return True

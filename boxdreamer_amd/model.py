@@ -77,6 +77,9 @@ class BoxDreamer(nn.Module):
         # that a real checkpoint's outlier channels cannot silently cost the 1e-3 parity bar.  `hip_calibrate: false` in
         # config["modules"] only measures and warns.  Re-armed whenever the decoder weights change (a checkpoint load).
         self.hip_calibrate = bool(module_configs.get("hip_calibrate", True))
+        # optional: a JSON file that keeps the measured promotion state next to the checkpoint (stamped with a content fingerprint of
+        # both weight sets): the first process measures and writes it, later ones load it instead of re-measuring
+        self.hip_promotion_file = module_configs.get("hip_promotion_file", None)
         self._calibrated_for = None
         self.hip_precision_source = ("config" if "hip_precision" in dec_cfg else
                                      ("$BOXDREAMER_HIP_PREC" if "BOXDREAMER_HIP_PREC" in os.environ else "package default"))
@@ -89,8 +92,13 @@ class BoxDreamer(nn.Module):
         mask[torch.arange(B, device=images.device), data["query_idx"].to(images.device).long()] = True
         if images.device != self.rgb_encoder.get_device():
             self.rgb_encoder.to_device(images.device)
+        if self.hip_promotion_file and self.hip_calibrate and calibrate.load_state(self.hip_promotion_file, self.rgb_encoder, self.decoder):
+            self._calibrated_for = self.decoder._signature()
+            return self.decoder.hip_calibration
         rep = calibrate.calibrate(self.rgb_encoder, self.decoder, images, data["bbox_feat"], mask, promote=self.hip_calibrate)
         self._calibrated_for = self.decoder._signature()
+        if self.hip_promotion_file and self.hip_calibrate and rep.get("applicable"):
+            calibrate.save_state(self.hip_promotion_file, self.rgb_encoder, self.decoder, rep)
         return rep
 
     def _precision_record(self) -> dict:

@@ -354,3 +354,38 @@ def test_build_recorded_no_register_spills_in_the_tuned_kernels():
     for k, v in res.items():
         if "gemm_kernel_pc" in k and not re.search(r"Li0ELi0ELb0E", k):
             assert v.get("ScratchSize", 0) == 0, (k, v)
+
+
+def test_promotion_state_file_round_trip(tmp_path):
+    """calibrate.save_state / load_state: a stored promotion state is applied only to the weights (content fingerprint) and the mode it
+    was measured on; host logic only."""
+    from boxdreamer_amd import calibrate
+    from boxdreamer_amd.betr import BETR
+    from boxdreamer_amd.encoder import DinoV2Wrapper
+
+    def pair(seed):
+        enc = DinoV2Wrapper(None, {"model_type": "dinov2_vitb14_reg", "synthetic_seed": seed, "depth": 2})
+        dec = BETR(d_model=768, nhead=8, num_decoder_layers=2, decoder_only=True, patch_size=14, img_size=224, diff_emb=False,
+                   nvs_supervision=False, ray_supervision=True, use_mask=False, use_pretrained=True, patchify_rays=True,
+                   pose_representation="bb8", bbox_representation="heatmap")
+        dec.load_state_dict(synth.betr_state_dict(1234, 2), strict=True)
+        return enc, dec
+    enc, dec = pair(4321)
+    st = calibrate.get_state(enc, dec)
+    st["enc"][1] = _lib.PROMOTE_QKV | _lib.PROMOTE_FC1
+    st["dec"][0] = _lib.PROMOTE_ATTN
+    st["dec_misc"] = _lib.PROMOTE_ADAPTER_FC1
+    calibrate.set_state(enc, dec, st)
+    assert enc.model.feats_prec == _lib.PREC_F16X3                    # the hand-off class follows the decoder's adapter
+    path = str(tmp_path / "promotion.json")
+    calibrate.save_state(path, enc, dec, {"promoted": ["x"], "delta_final": 1e-4})
+    enc2, dec2 = pair(4321)
+    assert calibrate.load_state(path, enc2, dec2)
+    assert calibrate.get_state(enc2, dec2) == st and enc2.model.feats_prec == _lib.PREC_F16X3
+    assert dec2.hip_calibration["loaded_from"] == path
+    enc3, dec3 = pair(999)                                             # other encoder weights: refused
+    assert not calibrate.load_state(path, enc3, dec3) and not any(enc3.model.promote)
+    dec2b = pair(4321)[1]
+    dec2b.hip_precision = "f16c8"                                      # other mode: refused
+    assert not calibrate.load_state(path, pair(4321)[0], dec2b)
+    assert not calibrate.load_state(str(tmp_path / "missing.json"), enc2, dec2)
