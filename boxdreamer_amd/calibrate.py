@@ -128,6 +128,7 @@ def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUD
         set_state(encoder, decoder, _state_of(units, promoted, n_enc, n_dec))
         return _logits(encoder, decoder, images, bbox_feat, masks)
 
+    entry_state = get_state(encoder, decoder)
     try:
         ref = run([True] * nu)
         d0 = float((run([False] * nu) - ref).abs().max())
@@ -175,6 +176,9 @@ def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUD
                    state=get_state(encoder, decoder), ok=bool(rep["delta_final"] <= budget))
         torch.cuda.synchronize()
         rep["seconds"] = round(time.perf_counter() - t_start, 3)
+    except BaseException:
+        set_state(encoder, decoder, entry_state)          # a failed measurement leaves the pair as it found it
+        raise
     finally:
         decoder.validate_inputs = validate
     if d0 > budget:
