@@ -688,22 +688,32 @@ inline bool uses_pc192(const bd_gemm_args& a, int ns, int esz, int cus) {
 // the 192-column workgroup tile: with an odd head count (N = 288 h, h odd) the last column tile's second wave tile would lie
 // past N, and the fused branch stores whole 96-column heads without a column guard
 
+template <class T, int NS, int BK> void launch_one_tile(const bd_gemm_args& a, hipStream_t s, int kCUs);
+
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {
     const int kCUs = cu_count();
     if (a.rms_wq && !(rms_geometry_ok(a) && pc192_possible(a, NS, OpGeom<T>::ESZ))) return BD_ERR_SHAPE;
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     constexpr int ESZ_ = OpGeom<T>::ESZ;
-    {
-        // 256 x 192 tiles (8 consumer waves of 64 x 96: 96 accumulator + 2 x 20 fragment registers fit the 168-VGPR budget
-        // of three waves per SIMD with the fragment double-buffering intact) whenever they tile N exactly -- every Linear of
-        // both stacks except the head (N = 2304, 3072, 768 are multiples of 192).
-        if (uses_pc192(a, NS, ESZ_, kCUs)) {
+    // 256 x 192 tiles (8 consumer waves of 64 x 96: 96 accumulator + 2 x 20 fragment registers fit the 168-VGPR budget
+    // of three waves per SIMD with the fragment double-buffering intact) whenever they tile N exactly -- every Linear of
+    // both stacks except the head (N = 2304, 3072, 768 are multiples of 192).
+    if (uses_pc192(a, NS, ESZ_, kCUs)) {
+        const int64_t rows_main = pc192_main_rows(a, kCUs);
+        if (rows_main < a.M) {
+            launch_pc<T, NS, BK, 4, 2, 2, 3>(row_slice<T>(a, 0, (int)rows_main), s, kCUs);
+            launch_one_tile<T, NS, BK>(row_slice<T>(a, rows_main, (int)(a.M - rows_main)), s, kCUs);
+        } else
             launch_pc<T, NS, BK, 4, 2, 2, 3>(a, s, kCUs);
-            bd_trace_close(s, slot);
-            BD_CHECK_LAUNCH();
-            return BD_OK;
-        }
-    }
+    } else
+        launch_one_tile<T, NS, BK>(a, s, kCUs);
+    bd_trace_close(s, slot);
+    BD_CHECK_LAUNCH();
+    return BD_OK;
+}
+
+// the one-tile-per-workgroup kernels: everything the persistent kernel does not take
+template <class T, int NS, int BK> void launch_one_tile(const bd_gemm_args& a, hipStream_t s, int kCUs) {
     {
         // Tile choice = best estimated efficiency: wave quantisation over the resident slots (256x256: one workgroup
         // per CU; 128x128: two; 64x64: four) times the measured relative mainloop efficiency of the tile
@@ -757,9 +767,7 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
         if constexpr (NS == 1) {
             if (use192) {
                 launch_glds<T, NS, BK, 4, 2, 2, 3>(a, s);
-                bd_trace_close(s, slot);
-                BD_CHECK_LAUNCH();
-                return BD_OK;
+                return;
             }
         }
         if (k256 > 0) {
@@ -784,9 +792,6 @@ template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t
             }
         }
     }
-    bd_trace_close(s, slot);
-    BD_CHECK_LAUNCH();
-    return BD_OK;
 }
 
 }  // namespace

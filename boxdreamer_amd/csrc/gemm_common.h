@@ -607,5 +607,19 @@ inline bool rms_geometry_ok(const bd_gemm_args& a) {
 
 }  // namespace
 
+// Rows the persistent 256 x 192 kernel takes when the tiles of ALL rows would end in a nearly empty round: DINOv2's M = 50112 is
+// 195.75 row tiles -- N = 768: 784 tiles = 3 rounds + 16 tiles, a fourth round on 16 of 256 CUs.  The rows of the k full rounds stay
+// here, the rest (960 rows) goes to the one-tile kernels as a second, sparse launch (fc2 266 -> 231 us, proj 95 -> 90 us;
+// profiles/r4_gemm_tail_rows.md).  Only where a round is a large part of the launch (k <= 4): behind 9 or 12 rounds (N = 2304, 3072)
+// the second launch costs what the empty round did.  A row's result does not depend on the kernel form (same K order, same
+// epilogue arithmetic: tests/test_gpu_ops.py::test_gemm_row_result_independent_of_tile_shape).
+inline int64_t pc192_main_rows(const bd_gemm_args& a, int cus) {
+    if (a.rms_wq || a.addtab || a.rpg_in > 0) return a.M;        // (row_slice does not re-phase the table / row-group maps)
+    const int64_t tn = a.N / 192, mt = (a.M + 255) / 256, nt = mt * tn;
+    const int64_t k = nt / cus, rem = nt % cus;
+    if (k < 1 || k > 4 || rem == 0 || rem * 4 > cus) return a.M;  // the last round is at least a quarter full: leave it
+    return (k * cus / tn) * 256;
+}
+
 // the F16C8 class has its own persistent kernel (gemm_f16c8.hip); every shape goes through it
 int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s);

@@ -217,6 +217,40 @@ def test_gemm_row_result_independent_of_tile_shape(hip, prec, N, K, kind):
         assert torch.equal(head.contiguous().view(torch.uint8), small.contiguous().view(torch.uint8)), (prec, kind, rows)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16x3", "fp8", "f16c8"])
+@pytest.mark.parametrize("K", [768, 3072])
+def test_gemm_rows_of_a_sparse_last_round_take_smaller_tiles(hip, prec, K):
+    """DINOv2's M = 50112 rows are 195.75 row tiles of 256: at N = 768 (proj, fc2) 3 full rounds of 256 x 192 tiles + 16 tiles.  bd_gemm
+    then runs the last 960 rows as a second launch of one-tile kernels (gemm_common.h: pc192_main_rows; the F16C8 class keeps its one
+    launch, profiles/r4_gemm_tail_rows.md).  Every row must equal, bit for bit, the same row launched without the split: rows
+    [0, 49152) alone (whole rounds, one launch) and rows [49152, 50112) alone (below the split's threshold)."""
+    M, N, main = 50112, 768, 49152
+    a, w, b = _rand("a", (M, K)).cuda(), _rand("w", (N, K), 0.05).cuda(), _rand("b", (N,), 0.5).cuda()
+    res = _rand("r", (M, N)).cuda()
+    kw = {}
+    if prec == "f16c8":
+        kw["w_qexp"] = hip_ops.f16c8_qexp(w)
+        w16 = hip_ops.f16c8_encode(w, kw["w_qexp"], True)
+    else:
+        w16 = hip_ops.to_operand(w, prec)
+    if prec == "fp8":
+        kw["wscale"] = (torch.rand(N, generator=torch.Generator().manual_seed(5)) + 0.5).cuda()
+
+    def go(r0, r1):
+        return hip_ops.gemm(hip_ops.to_operand(a[r0:r1], prec), w16, b, prec=prec, resid=res[r0:r1].clone(), out_f32=True, **kw)
+
+    full = go(0, M)
+    assert torch.equal(full[:main], go(0, main)), (prec, K, "rows of the full rounds")
+    assert torch.equal(full[main:], go(main, M)), (prec, K, "rows of the sparse round")
+    ref = hip_ops.from_operand(hip_ops.to_operand(a[main:], prec), prec).double() @ (
+        hip_ops.f16c8_decode(w16, kw["w_qexp"], True)[0].double() if prec == "f16c8" else hip_ops.from_operand(w16, prec).double()).t()
+    if prec == "fp8":
+        ref = ref * kw["wscale"].double()
+    ref = ref + b.double() + res[main:].double()
+    tol = {"bf16": 1e-3, "f16x3": 1e-4, "fp8": 1e-3, "f16c8": 2e-2}[prec]       # (F16C8: ref uses W's f16 plane only)
+    assert (full[main:].double() - ref).abs().max().item() < tol * K ** 0.5, (prec, K)
+
+
 @pytest.mark.parametrize("prec,out_mode", [("bf16", None), ("fp16", None), ("bf16x3", None), ("bf16x3", 2), ("f16c8", 2), ("f16c8", 4)])
 @pytest.mark.parametrize("M", [300, 4096, 49152 // 8])
 def test_gemm_fused_qk_rmsnorm(hip, prec, out_mode, M):
