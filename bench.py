@@ -480,7 +480,7 @@ def _kclass(name: str) -> str:
 def measure_counters(args) -> None:
     import collections, csv
     prec, B, T = args.prec, args.batch, args.views
-    child = ["--prec", prec, "--batch", str(B), "--views", str(T), "--steps", "2", "--warmup", "1", "--no-graph", "--in-flight", "1",
+    child = ["--prec", prec, "--batch", str(B), "--views", str(T), "--steps", "2", "--warmup", "1", "--no-graph", "--in-flight", "1", "--lanes", "1",
              "--no-strict", "--no-fp8", "--no-cpu-baseline", "--no-parity", "--no-pnp", "--no-h2d", "--no-trained-like"]
     acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES") + LDS_COUNTERS + STALL_COUNTERS}
     acc["stall:SQ_WAVE_CYCLES"] = collections.defaultdict(float)      # (SQ_WAVE_CYCLES is collected in both SQ passes: keep them apart)
@@ -588,6 +588,12 @@ class ModeRun:
                 return torch.cat(parts, 0).to(kp.device)
             self.gather = host_staged_gather
         self.enc, self.dec = build_models(prec, device, weights)
+        # sub-batch lanes of one batch (two BATCHES in flight already fill each other's idle CUs: each then runs as one lane)
+        def lane_arg(v):
+            return v if v == "auto" else int(v)
+        la = str(args.lanes).split(",")            # "auto" | N | E,D (encoder lanes, decoder lanes)
+        self.lane_setting = (1, 1) if max(1, args.in_flight) > 1 else (lane_arg(la[0]), lane_arg(la[-1]))
+        self.set_lanes(self.lane_setting)
         # what a maintainer's first forward does (boxdreamer_amd/model.py): the load-time self-check of the mode on the batch's first
         # sample, promoting the Linears that need it -- BEFORE anything is captured or timed; a no-op outside the f16c8 family
         import warnings
@@ -620,6 +626,7 @@ class ModeRun:
             for li in range(1, max(1, args.in_flight)):
                 try:
                     enc2, dec2 = build_models(prec, device, weights)
+                    enc2.model.lanes, dec2.hip_lanes = 1, 1
                     if self.calibration.get("state"):
                         calibrate.set_state(enc2, dec2, self.calibration["state"])
                     g2 = GraphedPath(enc2, dec2, self.B, self.T, 224, torch.bfloat16, device)
@@ -639,6 +646,26 @@ class ModeRun:
             main = torch.cuda.current_stream(device)
             for ln in self.lanes:
                 ln["free"].record(main)
+
+    def set_lanes(self, setting):
+        self.enc.model.lanes, self.dec.hip_lanes = setting if isinstance(setting, tuple) else (setting, setting)
+
+    def effective_lanes(self) -> int:
+        from boxdreamer_amd import _lib
+        return max(_lib.resolve_lanes(self.enc.model.lanes, self.B * self.T, self.B * self.T),
+                   _lib.resolve_lanes(self.dec.hip_lanes, self.B * self.T, self.B))
+
+    def recapture(self, setting):
+        """Re-capture the step's graph with another lane setting (same modules, same static inputs)."""
+        from boxdreamer_amd.graph import GraphedPath
+        assert self.graphed is not None and len(self.lanes) == 1
+        imgs, bb = self.graphed.images, self.graphed.bbox_feat
+        self.lanes[0]["g"] = None
+        self.graphed = None              # lifts the freeze of the modules (graph.py)
+        self.set_lanes(setting)
+        self.graphed = GraphedPath(self.enc, self.dec, self.B, self.T, 224, torch.bfloat16, self.device)
+        self.graphed.set_inputs(imgs, bb)
+        self.lanes[0]["g"] = self.graphed
 
     def eager(self):
         if self.cached is not None:
@@ -722,8 +749,9 @@ def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, coun
                         "whole_step_one_batch_at_a_time": counters["mfma_busy_whole_step"],
                         "unit": "fraction of SIMD cycles with the MFMA pipe busy (counted, rocprofv3 PMC)"} if counters else None),
          "algorithmic_flops_per_launch": round(sum(f for f, _ in g) / max(len(g), 1)), "launches": len(g),
-         "events": f"HIP events (launch stream) around every GEMM / attention launch of {trace_runs} un-graphed executions of "
-                   "the step on the same buffers right after the timed region (events cannot be timed inside a captured graph)",
+         "events": f"HIP events (launch stream) around every GEMM / attention launch of {trace_runs} un-graphed ONE-LANE executions of "
+                   "the step on the same buffers right after the timed region (events cannot be timed inside a captured graph; with "
+                   "sub-batch lanes two launches overlap and a per-launch duration is not defined)",
          "avg_launch_ms": round(sum(ms for _, ms in g) / max(len(g), 1), 4),
          "mfma_passes_per_algorithmic_flop": MFMA_PASSES.get(prec, 1.0),
          "attention_achieved": round(attn_tf, 2),
@@ -750,18 +778,32 @@ def measure_mode(prec, args, device, world, rank, dist, images, bbox, mask, weig
     lib = _lib.load()
     run = ModeRun(prec, args, device, world, rank, dist, images, bbox, mask, weights)
     sync = torch.cuda.synchronize if world == 1 else interruptible_sync(device)
-    dt, per_rank, out = timed_steps(run.step, args.steps, args.warmup, world, dist, sync, device)
     B, T = run.B, run.T
+    sub_lanes = run.effective_lanes()
+    one_lane = None
+    if sub_lanes > 1 and run.graphed is not None and len(run.lanes) == 1:
+        # for the record, first: the same K steps with the batch as ONE lane on one stream (the form of rounds 1-3), then the laned form
+        run.recapture(1)
+        dt1, _, out1 = timed_steps(run.step_single, args.steps, args.warmup, world, dist, sync, device)
+        one_lane = {"value": round(B * world * args.steps / dt1, 2), "ms_per_step": round(dt1 / args.steps * 1e3, 3), "sub_batch_lanes": 1}
+        run.recapture(run.lane_setting)
+    dt, per_rank, out = timed_steps(run.step, args.steps, args.warmup, world, dist, sync, device)
     assert out.shape[0] == B * world and torch.isfinite(out).all()
-    res = {"dt": dt, "per_rank": per_rank, "out": out, "run": run, "in_flight": max(1, len(run.lanes)),
+    if one_lane is not None:
+        assert torch.equal(out, out1), "sub-batch lanes changed the corners (they must be bit-identical to the one-lane form)"
+    res = {"dt": dt, "per_rank": per_rank, "out": out, "run": run, "in_flight": max(1, len(run.lanes)), "sub_lanes": sub_lanes,
            "calibration": calibration_summary(run.calibration)}
+    if one_lane is not None:
+        res["single_stream"] = one_lane
     if len(run.lanes) > 1:        # the same K steps one batch at a time on one stream, for the record
         dt1, _, out1 = timed_steps(run.step_single, args.steps, 1, world, dist, sync, device)
         assert out1.shape == out.shape and torch.isfinite(out1).all()     # (lanes hold different batches: values differ by design)
         res["single_stream"] = {"value": round(B * world * args.steps / dt1, 2), "ms_per_step": round(dt1 / args.steps * 1e3, 3)}
     if rank == 0:
         TRACE = 3
+        run.set_lanes(1)             # per-launch durations are only defined with one launch at a time: the trace runs the one-lane form
         recs, _ = trace_launches(lib, _lib, run.eager, TRACE)
+        run.set_lanes(run.lane_setting)
         value = B * world * args.steps / dt
         fpp = flops_per_pose(T) if not args.cache_refs else DINO_FLOP_PER_IMAGE + betr_flops(T)
         counters, why = (None, "reference features cached: other algorithmic traffic") if args.cache_refs else load_counters(prec, B, T)
@@ -909,9 +951,13 @@ def main():
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="replay the step from a captured HIP graph (default)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel from the host each step")
-    ap.add_argument("--in-flight", type=int, default=2,
-                    help="batches in flight in graph mode: 2 = two captured copies of the path replayed alternately on two streams "
-                         "(default), 1 = one batch at a time")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="batches in flight in graph mode: 1 = one batch at a time (default since round 4: the batch itself runs as "
+                         "sub-batch lanes, --lanes), 2 = two captured copies of the path replayed alternately on two streams (rounds 2-4; "
+                         "each batch then runs as one lane)")
+    ap.add_argument("--lanes", default="auto",
+                    help="sub-batch lanes of ONE batch (bd_*_forward_lanes, ABI v6): 'auto' (2 from 96 images per call on), or 1..4; "
+                         "bit-identical results for every value")
     ap.add_argument("--no-strict", action="store_true", help="skip the second (strict-mode) timing")
     ap.add_argument("--no-trained-like", action="store_true", help="skip the strict-mode leg on the trained-like outlier weights")
     ap.add_argument("--no-fp8", action="store_true", help="skip the configs[4] leg (fp8 Linears, batch 64) of the default single-GPU run")
@@ -1018,9 +1064,10 @@ def run(args):
                 "config": {"workload": workload_name(B, T, prec, world, args.cache_refs),
                            "global_batch": B * world, "views": T, "parallelism": f"dp{world}",
                            "hip_graph": main_res["run"].graphed is not None, "gflop_per_pose": round(fpp / 1e9, 2),
-                           "batches_in_flight": main_res["in_flight"],
-                           "batches_in_flight_note": "2 = two captured copies of the whole path replayed alternately on two streams (each "
-                                                     "batch computed in full on its lane; `single_stream` is the same K steps one at a time)"},
+                           "batches_in_flight": main_res["in_flight"], "sub_batch_lanes": main_res["sub_lanes"],
+                           "sub_batch_lanes_note": "ONE batch at a time; inside the captured step the batch runs as this many contiguous sub-batches "
+                                                   "on as many streams (bd_*_forward_lanes, ABI v6; outputs bit-identical to the one-lane form, "
+                                                   "asserted here on the corners); `single_stream` is the same K steps as one lane on one stream"},
                 "poses_per_s_per_gpu": round(value / world, 2),
                 "value_is": "whole-job aggregate over n_gpus (bench contract); the per-GPU figure of the metric is poses_per_s_per_gpu",
                 "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in main_res["per_rank"]],
@@ -1030,7 +1077,7 @@ def run(args):
             line["calibration"] = main_res["calibration"]
         if "single_stream" in main_res:
             line["single_stream"] = main_res["single_stream"]
-            line["value_single_stream"] = main_res["single_stream"]["value"]       # one batch of configs[1]'s 32 at a time
+            line["value_single_stream"] = main_res["single_stream"]["value"]       # the batch as ONE lane on one stream (rounds 1-3's step)
         if world > 1:          # what the collective layer itself saw (not the CLI argument): the first SCALE record must prove N ranks
             names = rank_devices
             line["distributed"] = {"backend": dist.get_backend(), "world_size_seen_by_the_collective": dist.get_world_size(),
@@ -1076,7 +1123,7 @@ def run(args):
                               "value": round(sres["value"], 2), "unit": "poses/s",
                               "poses_per_s_per_gpu": round(sres["value"] / world, 2),
                               "ms_per_step": round(sres["ms_per_step"], 3), "dtype": DTYPE_LABEL[STRICT_PREC],
-                              "roofline": sres["roofline"], "batches_in_flight": sres["in_flight"]}
+                              "roofline": sres["roofline"], "batches_in_flight": sres["in_flight"], "sub_batch_lanes": sres["sub_lanes"]}
             line["strict"]["calibration"] = sres["calibration"]
             # the figures of record where the driver's `parsed` shows them
             line["value_meeting_parity"] = line["strict"]["value"]
@@ -1099,12 +1146,12 @@ def run(args):
         torch.cuda.empty_cache()
         argsT = argparse.Namespace(**{**vars(args), "in_flight": 1})
         tres = measure_mode(STRICT_PREC, argsT, device, world, rank, dist, images, bbox, mask, weights=TRAINED_LIKE)
-        base = line.get("strict", {}).get("single_stream", {}).get("value")
+        base = line.get("strict", {}).get("value") if line.get("strict", {}).get("batches_in_flight") == 1 else None
         line["strict_trained_like"] = {"weights": TRAINED_LIKE + " (synth.*_state_dict_outliers: massive-activation channels, LayerNorm gain outliers, "
                                                   "MLP hidden units in the hundreds)", "mode": STRICT_PREC,
                                        "value": round(tres["value"], 2), "unit": "poses/s", "ms_per_step": round(tres["ms_per_step"], 3),
                                        "batches_in_flight": 1, "calibration": tres["calibration"],
-                                       "throughput_vs_unpromoted_single_stream": round(tres["value"] / base, 4) if base else None,
+                                       "throughput_vs_unpromoted": round(tres["value"] / base, 4) if base else None,
                                        "roofline": {k: tres["roofline"][k] for k in ("achieved", "frac", "whole_path_achieved") if k in tres["roofline"]}}
         if not args.no_parity:
             line["strict_trained_like"]["parity"] = parity_probe(STRICT_PREC, T, device, (tres["run"].enc, tres["run"].dec), weights=TRAINED_LIKE)

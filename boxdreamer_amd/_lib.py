@@ -120,6 +120,8 @@ EXPORTS = [
     "bd_encoder_workspace_bytes", "bd_encoder_forward", "bd_decoder_workspace_bytes", "bd_decoder_forward",
     "bd_trace_begin", "bd_trace_end", "bd_render_corner_heatmaps", "bd_attention_q", "bd_gather_query_rows_f32",
     "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm", "bd_solve_pnp_host", "bd_attention_prefix",
+    "bd_lanes_prepare", "bd_encoder_workspace_bytes_lanes", "bd_encoder_forward_lanes", "bd_decoder_workspace_bytes_lanes",
+    "bd_decoder_forward_lanes",
 ]
 
 _lib = None
@@ -162,6 +164,13 @@ def load() -> C.CDLL:
     lib.bd_decoder_workspace_bytes.argtypes = [C.POINTER(BetrWeights), i, i, i]
     lib.bd_decoder_workspace_bytes.restype = sz
     lib.bd_decoder_forward.argtypes = [C.POINTER(BetrWeights), vp, i, vp, i64, vp, i, i, i, vp, vp, vp, sz, i, vp]
+    lib.bd_encoder_workspace_bytes_lanes.argtypes = [C.POINTER(DinoWeights), i, i, i]
+    lib.bd_encoder_workspace_bytes_lanes.restype = sz
+    lib.bd_encoder_forward_lanes.argtypes = [C.POINTER(DinoWeights), vp, i, i, i, vp, vp, i64, vp, sz, i, i, vp]
+    lib.bd_decoder_workspace_bytes_lanes.argtypes = [C.POINTER(BetrWeights), i, i, i, i]
+    lib.bd_decoder_workspace_bytes_lanes.restype = sz
+    lib.bd_decoder_forward_lanes.argtypes = [C.POINTER(BetrWeights), vp, i, vp, i64, vp, i, i, i, vp, vp, vp, sz, i, i, vp]
+    lib.bd_lanes_prepare.argtypes = []
     lib.bd_attention_q.argtypes = [vp, i64, vp, i64, i, i, i, i, f, vp, i, i, vp]
     lib.bd_attention_prefix.argtypes = [vp, i64, vp, i64, i, i, i, i, f, i, i, i, vp]
     lib.bd_gather_query_rows_f32.argtypes = [vp, vp, vp, i, i, i, i, vp]
@@ -172,7 +181,7 @@ def load() -> C.CDLL:
     lib.bd_solve_pnp_host.argtypes = [vp, vp, vp, i, i, i, vp, i]
     lib.bd_trace_begin.argtypes = [i]
     lib.bd_trace_end.argtypes = [C.POINTER(TraceRecord), i]
-    if lib.bd_abi_version() != 5:
+    if lib.bd_abi_version() != 6:
         raise HipLibraryError("libboxdreamer_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -231,6 +240,21 @@ def k_multiple(prec) -> int:
 
 def planes(prec) -> int:
     return 2 if prec_id(prec) in _X3_FAMILY + _F16X3_FAMILY or prec_id(prec) in (PREC_F16C8, PREC_F16C8_QKV16, PREC_F16C8_QK16) else 1
+
+
+AUTO_LANES_MIN_VIEWS = 64      # one batch runs as two sub-batch lanes from this many (sample, view) images on (profiles/r4_subbatch_lanes.md)
+
+
+def resolve_lanes(setting, views: int, samples: int) -> int:
+    """Sub-batch lanes of one whole-path call (include/boxdreamer_hip.h, ABI v6): `setting` is "auto" or 1..4; `views` = images of
+    the call (B x T), `samples` = the units the batch can be cut at.  Bit-identical results for every value."""
+    if setting in (None, "auto"):
+        n = 2 if views >= AUTO_LANES_MIN_VIEWS else 1
+    else:
+        n = int(setting)
+        if not 1 <= n <= 4:
+            raise ValueError(f"hip_lanes must be 'auto' or 1..4, got {setting!r}")
+    return max(1, min(n, samples))
 
 
 def dtype_id(t: torch.Tensor) -> int:

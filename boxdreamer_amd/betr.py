@@ -84,6 +84,7 @@ class BETR(nn.Module):
         self.hip_precision = kwargs.get("hip_precision", os.environ.get("BOXDREAMER_HIP_PREC", _lib.DEFAULT_PREC))
         # per-Linear promotion of the F16C8 family to split-bf16 (include/boxdreamer_hip.h: BD_PROMOTE_*): one mask per block and
         # one for the Linears outside the blocks; all zero until boxdreamer_amd/calibrate.py (or the caller) sets them
+        self.hip_lanes = kwargs.get("hip_lanes", "auto")   # sub-batch lanes of one forward ("auto" | 1..4; bit-identical results)
         self.hip_promote = [0] * num_decoder_layers
         self.hip_promote_misc = 0
         if self.hip_precision == "fp8_mixed":
@@ -203,12 +204,14 @@ class BETR(nn.Module):
                               "(slow path, see boxdreamer_amd/features.py)", stacklevel=2)
             feats16 = hip_ops.to_operand(pretrain_rgb_feat.reshape(B * T * P, D).float(), fcls)
         pose_feat = pose_feat.contiguous()
-        ws = self._workspace(lib.bd_decoder_workspace_bytes(w, B, T, pid), dev)
+        lanes = _lib.resolve_lanes(self.hip_lanes, B * T, B)
+        ws = self._workspace(max(lib.bd_decoder_workspace_bytes(w, B, T, pid),
+                                 lib.bd_decoder_workspace_bytes_lanes(w, B, T, pid, lanes)), dev)
         logits = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)
         heat = torch.empty_like(logits)
-        _lib.check(lib.bd_decoder_forward(w, _lib.ptr(pose_feat), _lib.dtype_id(pose_feat), _lib.ptr(feats16),
-                                          B * T * P * D if np_ == 2 else 0, _lib.ptr(query_idx), B, T, H,
-                                          _lib.ptr(logits), _lib.ptr(heat), _lib.ptr(ws), ws.numel(), pid,
-                                          _lib.stream()), "bd_decoder_forward")
+        _lib.check(lib.bd_decoder_forward_lanes(w, _lib.ptr(pose_feat), _lib.dtype_id(pose_feat), _lib.ptr(feats16),
+                                                B * T * P * D if np_ == 2 else 0, _lib.ptr(query_idx), B, T, H,
+                                                _lib.ptr(logits), _lib.ptr(heat), _lib.ptr(ws), ws.numel(), pid, lanes,
+                                                _lib.stream()), "bd_decoder_forward_lanes")
         self.last_logits = logits
         return heat

@@ -373,3 +373,165 @@ extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_fea
     BD_TRY(bd_unpatchify_sigmoid(d.proj, logits, heat, B, w->box_dim, size, w->patch, stream));
     return BD_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------------------
+// Sub-batch lanes.  Samples are independent all the way down the path, and every row's result is independent
+// of the tile shape its launch picks (tests/test_gpu_ops.py::test_gemm_row_result_independent_of_tile_shape, the batch-invariance
+// tests), so ONE batch may run as `lanes` contiguous sub-batches on `lanes` streams without changing a bit of the result: lane 0 on
+// the caller's stream, the others on side streams this library owns, forked from and joined back into the caller's stream with
+// events inside the call -- the call stays stream-ordered for the caller (and capturable: an event wait pulls the side stream into
+// the caller's capture).  What it buys: the kernels of one lane run on the CUs the other lane's ragged last round leaves idle and
+// the HBM-bound launches (LayerNorm) of one lane overlap the MFMA-bound launches of the other -- what two BATCHES in flight bought
+// in rounds 2-4, now inside one batch of configs[1] (profiles/r4_subbatch_lanes.md).
+#include <mutex>
+namespace {
+
+constexpr int kMaxLanes = 4, kMaxDevices = 64;
+struct LaneSet {
+    hipStream_t side[kMaxLanes - 1];
+    hipEvent_t fork, join[kMaxLanes - 1];
+    bool ready = false;
+};
+std::mutex g_lane_mu;          // held for the whole host-side enqueue of a laned call: the events / side streams are per device
+LaneSet g_lanes[kMaxDevices];
+
+int lanes_of_current_device(LaneSet** out) {      // caller holds g_lane_mu
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= kMaxDevices) return BD_ERR_SHAPE;
+    LaneSet& L = g_lanes[dev];
+    if (!L.ready) {
+        if ((e = hipEventCreateWithFlags(&L.fork, hipEventDisableTiming)) != hipSuccess) return (int)e;
+        for (int i = 0; i < kMaxLanes - 1; ++i) {
+            if ((e = hipStreamCreateWithFlags(&L.side[i], hipStreamNonBlocking)) != hipSuccess) return (int)e;
+            if ((e = hipEventCreateWithFlags(&L.join[i], hipEventDisableTiming)) != hipSuccess) return (int)e;
+        }
+        L.ready = true;
+    }
+    *out = &L;
+    return BD_OK;
+}
+
+inline int lane_count(int lanes, int units) { return lanes < 1 ? 1 : (lanes > kMaxLanes ? kMaxLanes : (lanes > units ? units : lanes)); }
+inline int lane_units(int units, int lanes, int l) { return units / lanes + (l < units % lanes ? 1 : 0); }
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// element offset e0 into a 16-bit operand buffer of class `cls`: plane 0 moves by e0 elements; F16C8's one-byte lo8 plane (which
+// starts `plane` 2-byte units behind plane 0) moves by e0 BYTES, i.e. the plane distance seen from the moved base shrinks by e0 / 2
+inline void operand_slice(const void* base, int64_t plane, int cls, int64_t e0, const void** b, int64_t* p) {
+    const int esz = cls == BD_PREC_FP8 ? 1 : 2;
+    *b = base ? (const unsigned char*)base + e0 * esz : nullptr;
+    *p = cls == BD_PREC_F16C8 ? plane - e0 / 2 : plane;
+}
+inline int dtype_bytes(int dt) { return dt == BD_DTYPE_F32 ? 4 : 2; }
+
+// fork / join around the per-lane calls.  Every lane is enqueued even after an earlier one failed, and the joins are always
+// recorded, so that a capture in progress is left well-formed; the first error is returned.
+template <class F> int run_lanes(int lanes, hipStream_t main, F&& lane_call) {
+    std::lock_guard<std::mutex> guard(g_lane_mu);
+    LaneSet* L = nullptr;
+    BD_TRY(lanes_of_current_device(&L));
+    hipError_t e = hipEventRecord(L->fork, main);
+    if (e != hipSuccess) return (int)e;
+    int rc = BD_OK;
+    for (int l = 0; l < lanes; ++l) {
+        hipStream_t s = l == 0 ? main : L->side[l - 1];
+        if (l > 0 && (e = hipStreamWaitEvent(s, L->fork, 0)) != hipSuccess && rc == BD_OK) rc = (int)e;
+        const int r = lane_call(l, s);
+        if (r != BD_OK && rc == BD_OK) rc = r;
+    }
+    for (int l = 1; l < lanes; ++l) {
+        if ((e = hipEventRecord(L->join[l - 1], L->side[l - 1])) != hipSuccess && rc == BD_OK) rc = (int)e;
+        if ((e = hipStreamWaitEvent(main, L->join[l - 1], 0)) != hipSuccess && rc == BD_OK) rc = (int)e;
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int bd_lanes_prepare(void) {
+    std::lock_guard<std::mutex> guard(g_lane_mu);
+    LaneSet* L = nullptr;
+    return lanes_of_current_device(&L);
+}
+
+extern "C" size_t bd_encoder_workspace_bytes_lanes(const bd_dino_weights* w, int n_images, int prec, int lanes) {
+    if (!w || n_images <= 0 || bad_prec(prec)) return 0;
+    const int nl = lane_count(lanes, n_images);
+    size_t total = 0;
+    for (int l = 0; l < nl; ++l) total += align256(carve_encoder(w, lane_units(n_images, nl, l), gemm_prec(prec), nullptr).bytes);
+    return total;
+}
+
+extern "C" int bd_encoder_forward_lanes(const bd_dino_weights* w, const void* images, int img_dtype, int n_images, int size,
+                                        float* feats32, void* feats16, int64_t feats16_plane, void* workspace,
+                                        size_t workspace_bytes, int wprec, int lanes, void* stream) {
+    const int nl = lane_count(lanes, n_images);
+    if (nl <= 1 || !w) return bd_encoder_forward(w, images, img_dtype, n_images, size, feats32, feats16, feats16_plane, workspace,
+                                                 workspace_bytes, wprec, stream);
+    if (bad_prec(wprec)) return BD_ERR_DTYPE;
+    if (!images || !workspace) return BD_ERR_NULL;
+    if (img_dtype < 0 || img_dtype > 2) return BD_ERR_DTYPE;
+    if ((uintptr_t)workspace & 255) return BD_ERR_ALIGN;
+    if (workspace_bytes < bd_encoder_workspace_bytes_lanes(w, n_images, wprec, nl)) return BD_ERR_WORKSPACE;
+    const int prec = gemm_prec(wprec), fcls = w->feats_prec ? w->feats_prec : prec;
+    const int64_t PD = (int64_t)w->grid * w->grid * w->dim, img_elems = (int64_t)3 * size * size;
+    return run_lanes(nl, (hipStream_t)stream, [&](int l, hipStream_t s) {
+        int first = 0;
+        size_t woff = 0;
+        for (int j = 0; j < l; ++j) {
+            first += lane_units(n_images, nl, j);
+            woff += align256(carve_encoder(w, lane_units(n_images, nl, j), prec, nullptr).bytes);
+        }
+        const int n = lane_units(n_images, nl, l);
+        const void* f16 = nullptr;
+        int64_t plane = feats16_plane;
+        operand_slice(feats16, feats16_plane, fcls, first * PD, &f16, &plane);
+        return bd_encoder_forward(w, (const unsigned char*)images + first * img_elems * dtype_bytes(img_dtype), img_dtype, n, size,
+                                  feats32 ? feats32 + first * PD : nullptr, const_cast<void*>(f16), plane,
+                                  (unsigned char*)workspace + woff, align256(carve_encoder(w, n, prec, nullptr).bytes), wprec, s);
+    });
+}
+
+extern "C" size_t bd_decoder_workspace_bytes_lanes(const bd_betr_weights* w, int B, int T, int prec, int lanes) {
+    if (!w || B <= 0 || T <= 0 || bad_prec(prec)) return 0;
+    const int nl = lane_count(lanes, B);
+    size_t total = 0;
+    for (int l = 0; l < nl; ++l) total += align256(carve_decoder(w, lane_units(B, nl, l), T, gemm_prec(prec), nullptr).bytes);
+    return total;
+}
+
+extern "C" int bd_decoder_forward_lanes(const bd_betr_weights* w, const void* bbox_feat, int in_dtype, const void* feats16,
+                                        int64_t feats16_plane, const int32_t* query_idx, int B, int T, int size, float* logits,
+                                        float* heat, void* workspace, size_t workspace_bytes, int wprec, int lanes, void* stream) {
+    const int nl = lane_count(lanes, B);
+    if (nl <= 1 || !w) return bd_decoder_forward(w, bbox_feat, in_dtype, feats16, feats16_plane, query_idx, B, T, size, logits, heat,
+                                                 workspace, workspace_bytes, wprec, stream);
+    if (bad_prec(wprec)) return BD_ERR_DTYPE;
+    if (!bbox_feat || !feats16 || !query_idx || !workspace) return BD_ERR_NULL;
+    if (in_dtype < 0 || in_dtype > 2) return BD_ERR_DTYPE;
+    if (T <= 0) return BD_ERR_SHAPE;
+    if ((uintptr_t)workspace & 255) return BD_ERR_ALIGN;
+    if (workspace_bytes < bd_decoder_workspace_bytes_lanes(w, B, T, wprec, nl)) return BD_ERR_WORKSPACE;
+    const int prec = gemm_prec(wprec);
+    const int pm0 = (prec == BD_PREC_F16C8 || prec == BD_PREC_FP8) ? w->promote_misc : 0;
+    const int fcls = lin_class(prec, pm0, BD_PROMOTE_ADAPTER_FC1);       // the class bd_decoder_forward reads feats16 in
+    const int64_t PD = (int64_t)w->grid * w->grid * w->dim, view_elems = (int64_t)w->box_dim * size * size;
+    return run_lanes(nl, (hipStream_t)stream, [&](int l, hipStream_t s) {
+        int first = 0;
+        size_t woff = 0;
+        for (int j = 0; j < l; ++j) {
+            first += lane_units(B, nl, j);
+            woff += align256(carve_decoder(w, lane_units(B, nl, j), T, prec, nullptr).bytes);
+        }
+        const int b = lane_units(B, nl, l);
+        const void* f16 = nullptr;
+        int64_t plane = feats16_plane;
+        operand_slice(feats16, feats16_plane, fcls, (int64_t)first * T * PD, &f16, &plane);
+        return bd_decoder_forward(w, (const unsigned char*)bbox_feat + (int64_t)first * T * view_elems * dtype_bytes(in_dtype), in_dtype,
+                                  f16, plane, query_idx + first, b, T, size, logits ? logits + first * view_elems : nullptr,
+                                  heat ? heat + first * view_elems : nullptr, (unsigned char*)workspace + woff,
+                                  align256(carve_decoder(w, b, T, prec, nullptr).bytes), wprec, s);
+    });
+}

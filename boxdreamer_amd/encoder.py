@@ -52,6 +52,7 @@ class DinoV2Encoder:
         self._frozen_by = weakref.WeakSet()  # live GraphedPaths that captured raw pointers into _packed / _ws (graph.py)
         depth = 1 + max(int(k.split(".")[1]) for k in self.sd if k.startswith("blocks."))
         # per-Linear promotion of the F16C8 family to split-bf16 (include/boxdreamer_hip.h: BD_PROMOTE_*), set by calibrate.py
+        self.lanes = "auto"          # sub-batch lanes of one predict() call ("auto" | 1..4; bit-identical results, _lib.resolve_lanes)
         self.promote = [0] * depth
         self.promote_misc = 0
         self.feats_prec = 0          # 0: feats16 in the class of `prec`; the promoted class when the decoder's adapter fc1 is promoted
@@ -115,15 +116,18 @@ class DinoV2Encoder:
         pk = self._weights(size, prec)
         w = pk.struct
         P, D = w.grid * w.grid, w.dim
-        ws = self._workspace(lib.bd_encoder_workspace_bytes(w, n, _lib.prec_id(prec)), images.device)
+        lanes = _lib.resolve_lanes(self.lanes, n, n)
+        # sized for the laned AND the plain form: switching `lanes` under a live captured graph must never grow the workspace
+        ws = self._workspace(max(lib.bd_encoder_workspace_bytes(w, n, _lib.prec_id(prec)),
+                                 lib.bd_encoder_workspace_bytes_lanes(w, n, _lib.prec_id(prec), lanes)), images.device)
         feats32 = torch.empty((n, P, D), dtype=torch.float32, device=images.device)
         fcls = self.feats_class(prec)
         np_ = _lib.planes(fcls)
         feats16 = torch.empty((np_, n * P, D) if np_ == 2 else (n * P, D), dtype=_lib.op_dtype(fcls),
                               device=images.device)
-        _lib.check(lib.bd_encoder_forward(w, _lib.ptr(images), _lib.dtype_id(images), n, size, _lib.ptr(feats32),
-                                          _lib.ptr(feats16), n * P * D if np_ == 2 else 0, _lib.ptr(ws),
-                                          ws.numel(), _lib.prec_id(prec), _lib.stream()), "bd_encoder_forward")
+        _lib.check(lib.bd_encoder_forward_lanes(w, _lib.ptr(images), _lib.dtype_id(images), n, size, _lib.ptr(feats32),
+                                                _lib.ptr(feats16), n * P * D if np_ == 2 else 0, _lib.ptr(ws),
+                                                ws.numel(), _lib.prec_id(prec), lanes, _lib.stream()), "bd_encoder_forward_lanes")
         return feats32, feats16
 
 
@@ -176,6 +180,7 @@ class DinoV2Wrapper(PretrainedModelWrapper):
                 "DINOv2 weights: give encoder.dino.ckpt_path (or $BOXDREAMER_DINO_WEIGHTS) pointing at a local "
                 f"{self.model_type} state_dict file; torch.hub download is not available on this path")
         self.model = DinoV2Encoder(sd, heads=heads, prec=self.prec)
+        self.model.lanes = self.cfg.get("hip_lanes", "auto")
         if torch.cuda.is_available():
             self.model.to(device)
             self.device = torch.device(device) if not isinstance(device, torch.device) else device

@@ -22,6 +22,10 @@ class GraphedPath:
         self.mask = torch.zeros((B, T), dtype=torch.bool, device=dev)
         self.mask[:, T - 1] = True
         self.want_idx = want_idx
+        # sub-batch lanes (the modules' `hip_lanes`): the library's side streams / events exist before the capture starts
+        from . import _lib
+        with torch.cuda.device(dev.index if dev.index is not None else torch.cuda.current_device()):
+            _lib.check(_lib.load().bd_lanes_prepare(), "bd_lanes_prepare")
         # warm-up on a side stream (allocates workspaces / packs weights outside the capture), then capture
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))

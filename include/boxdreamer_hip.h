@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define BD_ABI_VERSION 5
+#define BD_ABI_VERSION 6
 
 #define BD_DTYPE_BF16 0
 #define BD_DTYPE_F16 1
@@ -347,6 +347,26 @@ int bd_decoder_forward(const bd_betr_weights* w /*[host]*/, const void* bbox_fea
                        const void* feats16, int64_t feats16_plane, const int32_t* query_idx, int B,
                        int T, int size, float* logits, float* heat, void* workspace,
                        size_t workspace_bytes, int prec, void* stream);
+
+/* Sub-batch lanes (ABI v6).  The same two operators with ONE batch run as `lanes` (1..4) contiguous sub-batches on `lanes`
+ * streams: lane 0 on `stream`, the others on side streams the library owns (per device), forked from and joined back into
+ * `stream` by events inside the call, so the call is stream-ordered for the caller exactly like the plain form (and capturable
+ * into a HIP graph: the event wait pulls the side streams into the caller's capture).  Samples are independent on this path
+ * (BETR attends within a sample, betr.py:282-296; the reference's per-sample loop is prediction_utils.py:63-101) and a row's
+ * result does not depend on the launch geometry, so the outputs are BIT-identical to the plain form; what changes is that the
+ * kernels of one lane fill the CUs the other lane's ragged last round leaves idle.  `lanes` <= 1 (or more lanes than samples)
+ * IS the plain form.  The workspace is the sum of the lanes' workspaces (*_workspace_bytes_lanes).  bd_lanes_prepare creates
+ * the current device's side streams / events ahead of a stream capture (they are otherwise created on first use). */
+int bd_lanes_prepare(void);
+size_t bd_encoder_workspace_bytes_lanes(const bd_dino_weights* w /*[host]*/, int n_images, int prec, int lanes);
+int bd_encoder_forward_lanes(const bd_dino_weights* w /*[host]*/, const void* images, int img_dtype,
+                             int n_images, int size, float* feats32, void* feats16, int64_t feats16_plane,
+                             void* workspace, size_t workspace_bytes, int prec, int lanes, void* stream);
+size_t bd_decoder_workspace_bytes_lanes(const bd_betr_weights* w /*[host]*/, int B, int T, int prec, int lanes);
+int bd_decoder_forward_lanes(const bd_betr_weights* w /*[host]*/, const void* bbox_feat, int in_dtype,
+                             const void* feats16, int64_t feats16_plane, const int32_t* query_idx, int B,
+                             int T, int size, float* logits, float* heat, void* workspace,
+                             size_t workspace_bytes, int prec, int lanes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Launch tracing (measurement aid for bench.py; off by default; the only library state).
