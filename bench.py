@@ -756,9 +756,12 @@ def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, coun
          "mfma_passes_per_algorithmic_flop": MFMA_PASSES.get(prec, 1.0),
          "attention_achieved": round(attn_tf, 2),
          "attention_avg_launch_ms": round(sum(ms for _, ms in a) / max(len(a), 1), 4),
-         # kernel time per step (event-timed, un-graphed) over the TIMED step time (graph replay)
+         # kernel time per step (event-timed, un-graphed, one lane) over the timed ONE-LANE step time (graph replay)
          "gemm_time_frac_of_step": round(sum(ms for _, ms in g) / trace_runs / ms_per_step, 4),
          "attention_time_frac_of_step": round(sum(ms for _, ms in a) / trace_runs / ms_per_step, 4),
+         "peak_note": "peak = dense MFMA rate at 2.4 GHz (MI355X_MICROARCH.md).  Under its 1400 W cap the part does not hold that clock in a dense "
+                      "GEMM: the same persistent kernels on HALF the CUs deliver 72-82 % of the full-chip rate (profiles/r4_cu_limit_probe.md), a "
+                      "pure MFMA loop without memory traffic sustains 1.9-2.0 PFLOP/s (profiles/r2_mfma_util.md)",
          "whole_path_achieved": round(value_per_gpu * fpp / 1e12, 2),
          "whole_path_frac": round(value_per_gpu * fpp / 1e12 / peak, 4)}
     return r
@@ -810,7 +813,9 @@ def measure_mode(prec, args, device, world, rank, dist, images, bbox, mask, weig
         if weights != "plain" and run.calibration.get("promoted"):
             counters, why = None, "promoted Linears: the counter file describes the unpromoted mode"
         res.update(value=value, fpp=fpp, ms_per_step=dt / args.steps * 1e3,
-                   roofline=roofline_block(prec, recs, dt / args.steps * 1e3, TRACE, value / world, fpp, counters, why))
+                   # (kernel-time fractions are of the ONE-LANE step the trace executes, where there is one)
+                   roofline=roofline_block(prec, recs, one_lane["ms_per_step"] if one_lane else dt / args.steps * 1e3, TRACE, value / world,
+                                           fpp, counters, why))
     return res
 
 

@@ -124,6 +124,8 @@ class BoxDreamer(nn.Module):
                     and calibrate.applicable(self.rgb_encoder, self.decoder)):
                 self.calibrate(data)
             data["hip_precision"] = self._precision_record()
+            # sub-batch lanes this batch runs as (bit-identical for every value; `hip_lanes` in the decoder / encoder cfg, default "auto")
+            data["hip_precision"]["sub_batch_lanes"] = _lib.resolve_lanes(self.decoder.hip_lanes, B * T, B)
         if "cached_rgb_feat" in data:       # "next" row f1: references encoded once per object (boxdreamer_amd/cache.py)
             rgb_feature = merge_cached_features(self.rgb_encoder, images, data["cached_rgb_feat"],
                                                 data["cached_rgb_mask"])

@@ -148,3 +148,31 @@ def test_lanes_argument_checks(hip):
                                       ws.numel(), _lib.prec_id("bf16"), 2, _lib.stream())
     with pytest.raises(_lib.HipLibraryError, match="BD_ERR_WORKSPACE"):
         _lib.check(rc, "bd_encoder_forward_lanes")
+
+
+def test_facade_runs_a_large_batch_as_two_lanes_and_says_so(hip):
+    """`BoxDreamer.forward` (BoxDreamerModel.py:112-191) on a batch of >= 64 (sample, view) images: two lanes by default, recorded in
+    the output dict, every output equal to the `hip_lanes: 1` run."""
+    import copy
+    from boxdreamer_amd.model import BoxDreamer
+    from test_gpu_facade import _config_with
+    B, T = 11, 6
+    data = synth.make_batch(seed=41, B=B, T=T, dtype=torch.bfloat16)
+    data["query_idx"] = torch.arange(B) % T
+    outs = []
+    for lanes in ("auto", 1):
+        cfg = _config_with("f16c8_qk16")
+        if lanes != "auto":
+            cfg["modules"]["decoder"]["hip_lanes"] = lanes
+            cfg["modules"]["encoder"]["dino"]["cfg"]["hip_lanes"] = lanes
+        model = BoxDreamer(cfg)
+        model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
+        model = model.cuda().eval()
+        dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in copy.deepcopy(data).items()}
+        with torch.inference_mode():
+            out = model(dev)
+        torch.cuda.synchronize()
+        assert out["hip_precision"]["sub_batch_lanes"] == (2 if lanes == "auto" else 1)
+        outs.append({k: out[k].clone() for k in ("pred_bbox", "pred_corners_px", "pred_poses", "regression_boxes")})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k

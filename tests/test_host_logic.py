@@ -389,3 +389,15 @@ def test_promotion_state_file_round_trip(tmp_path):
     dec2b.hip_precision = "f16c8"                                      # other mode: refused
     assert not calibrate.load_state(path, pair(4321)[0], dec2b)
     assert not calibrate.load_state(str(tmp_path / "missing.json"), enc2, dec2)
+
+
+def test_sub_batch_lane_resolution():
+    """`hip_lanes` ("auto" | 1..4) -> lanes of one whole-path call (include/boxdreamer_hip.h, ABI v6): never more lanes than units the
+    batch can be cut at, auto = two lanes from 64 (sample, view) images on, anything else is rejected on the host."""
+    from boxdreamer_amd import _lib
+    assert _lib.resolve_lanes("auto", 32 * 6, 32) == 2 and _lib.resolve_lanes(None, 32 * 6, 32) == 2
+    assert _lib.resolve_lanes("auto", 6, 1) == 1 and _lib.resolve_lanes("auto", 63, 63) == 1 and _lib.resolve_lanes("auto", 64, 32) == 2
+    assert _lib.resolve_lanes(4, 24, 3) == 3 and _lib.resolve_lanes(1, 1000, 100) == 1 and _lib.resolve_lanes("2", 12, 2) == 2
+    for bad in (0, 5, -1):
+        with pytest.raises(ValueError):
+            _lib.resolve_lanes(bad, 100, 100)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One pass over everything profiles/ quotes for a round (run on the GPU box from the repo root; writes under gpurun_out/final_<tag>/).
-tag=${1:-r4}
+tag=${1:-r4b}
 out=gpurun_out/final_$tag; mkdir -p $out
 R=$(pwd)
 timeout 3000 python -m pytest tests -m gpu -q > $out/pytest.log 2>&1; echo "pytest rc $?" | tee $out/status; tail -3 $out/pytest.log
