@@ -652,8 +652,8 @@ class ModeRun:
 
     def effective_lanes(self) -> int:
         from boxdreamer_amd import _lib
-        return max(_lib.resolve_lanes(self.enc.model.lanes, self.B * self.T, self.B * self.T),
-                   _lib.resolve_lanes(self.dec.hip_lanes, self.B * self.T, self.B))
+        return max(_lib.resolve_lanes(self.enc.model.lanes, self.B * self.T, self.B * self.T, self.prec),
+                   _lib.resolve_lanes(self.dec.hip_lanes, self.B * self.T, self.B, self.prec))
 
     def recapture(self, setting):
         """Re-capture the step's graph with another lane setting (same modules, same static inputs)."""

@@ -245,11 +245,13 @@ def planes(prec) -> int:
 AUTO_LANES_MIN_VIEWS = 64      # one batch runs as two sub-batch lanes from this many (sample, view) images on (profiles/r4_subbatch_lanes.md)
 
 
-def resolve_lanes(setting, views: int, samples: int) -> int:
+def resolve_lanes(setting, views: int, samples: int, prec=None) -> int:
     """Sub-batch lanes of one whole-path call (include/boxdreamer_hip.h, ABI v6): `setting` is "auto" or 1..4; `views` = images of
-    the call (B x T), `samples` = the units the batch can be cut at.  Bit-identical results for every value."""
+    the call (B x T), `samples` = the units the batch can be cut at.  Bit-identical results for every value.  "auto": two lanes from
+    AUTO_LANES_MIN_VIEWS images on, except in the e4m3 class, whose half-batch GEMMs lose more than the filled tail rounds win
+    (measured: -2.7 % at batch 64, -4 % at batch 32; 16-bit classes +2 ... +9 %)."""
     if setting in (None, "auto"):
-        n = 2 if views >= AUTO_LANES_MIN_VIEWS else 1
+        n = 2 if views >= AUTO_LANES_MIN_VIEWS and not (prec is not None and operand_prec(prec) == PREC_FP8) else 1
     else:
         n = int(setting)
         if not 1 <= n <= 4:

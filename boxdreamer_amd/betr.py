@@ -204,7 +204,7 @@ class BETR(nn.Module):
                               "(slow path, see boxdreamer_amd/features.py)", stacklevel=2)
             feats16 = hip_ops.to_operand(pretrain_rgb_feat.reshape(B * T * P, D).float(), fcls)
         pose_feat = pose_feat.contiguous()
-        lanes = _lib.resolve_lanes(self.hip_lanes, B * T, B)
+        lanes = _lib.resolve_lanes(self.hip_lanes, B * T, B, prec)
         ws = self._workspace(max(lib.bd_decoder_workspace_bytes(w, B, T, pid),
                                  lib.bd_decoder_workspace_bytes_lanes(w, B, T, pid, lanes)), dev)
         logits = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)

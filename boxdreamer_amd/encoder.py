@@ -116,7 +116,7 @@ class DinoV2Encoder:
         pk = self._weights(size, prec)
         w = pk.struct
         P, D = w.grid * w.grid, w.dim
-        lanes = _lib.resolve_lanes(self.lanes, n, n)
+        lanes = _lib.resolve_lanes(self.lanes, n, n, prec)
         # sized for the laned AND the plain form: switching `lanes` under a live captured graph must never grow the workspace
         ws = self._workspace(max(lib.bd_encoder_workspace_bytes(w, n, _lib.prec_id(prec)),
                                  lib.bd_encoder_workspace_bytes_lanes(w, n, _lib.prec_id(prec), lanes)), images.device)

@@ -125,7 +125,7 @@ class BoxDreamer(nn.Module):
                 self.calibrate(data)
             data["hip_precision"] = self._precision_record()
             # sub-batch lanes this batch runs as (bit-identical for every value; `hip_lanes` in the decoder / encoder cfg, default "auto")
-            data["hip_precision"]["sub_batch_lanes"] = _lib.resolve_lanes(self.decoder.hip_lanes, B * T, B)
+            data["hip_precision"]["sub_batch_lanes"] = _lib.resolve_lanes(self.decoder.hip_lanes, B * T, B, self.decoder.hip_precision)
         if "cached_rgb_feat" in data:       # "next" row f1: references encoded once per object (boxdreamer_amd/cache.py)
             rgb_feature = merge_cached_features(self.rgb_encoder, images, data["cached_rgb_feat"],
                                                 data["cached_rgb_mask"])

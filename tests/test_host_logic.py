@@ -398,6 +398,8 @@ def test_sub_batch_lane_resolution():
     assert _lib.resolve_lanes("auto", 32 * 6, 32) == 2 and _lib.resolve_lanes(None, 32 * 6, 32) == 2
     assert _lib.resolve_lanes("auto", 6, 1) == 1 and _lib.resolve_lanes("auto", 63, 63) == 1 and _lib.resolve_lanes("auto", 64, 32) == 2
     assert _lib.resolve_lanes(4, 24, 3) == 3 and _lib.resolve_lanes(1, 1000, 100) == 1 and _lib.resolve_lanes("2", 12, 2) == 2
+    assert _lib.resolve_lanes("auto", 64 * 6, 64, "fp8") == 1 and _lib.resolve_lanes(2, 64 * 6, 64, "fp8") == 2     # e4m3 class: auto stays at one
+    assert _lib.resolve_lanes("auto", 32 * 6, 32, "f16c8_qk16") == 2 and _lib.resolve_lanes("auto", 32 * 6, 32, "bf16") == 2
     for bad in (0, 5, -1):
         with pytest.raises(ValueError):
             _lib.resolve_lanes(bad, 100, 100)
