@@ -95,8 +95,10 @@ __host__ __device__ void rvec_from_R(const double* R, double* rv) {
     rv[0] = (R[7] - R[5]) * f; rv[1] = (R[2] - R[6]) * f; rv[2] = (R[3] - R[1]) * f;
 }
 
-// residuals of pose x = (rvec, t) for n points; returns false on a non-finite value
-__host__ __device__ bool residuals(const double* x, const double* p3, const double* p2n, int n, double* r) {
+// residuals of pose x = (rvec, t) for n points; returns false on a non-finite value.  OpenCV's ITERATIVE solver minimises the
+// reprojection error in PIXELS, i.e. it weights the normalised x / y residuals by fx / fy: (wx, wy) = (fx, fy) / sqrt(fx fy) gives the
+// same minimiser and is exactly (1, 1) for square pixels.
+__host__ __device__ bool residuals(const double* x, const double* p3, const double* p2n, int n, double* r, double wx, double wy) {
     double R[9];
     rodrigues(x, R);
     bool ok = true;
@@ -104,8 +106,8 @@ __host__ __device__ bool residuals(const double* x, const double* p3, const doub
         const double X = p3[i * 3], Y = p3[i * 3 + 1], Z = p3[i * 3 + 2];
         const double cx = R[0] * X + R[1] * Y + R[2] * Z + x[3], cy = R[3] * X + R[4] * Y + R[5] * Z + x[4],
                      cz = R[6] * X + R[7] * Y + R[8] * Z + x[5];
-        r[2 * i] = cx / cz - p2n[2 * i];
-        r[2 * i + 1] = cy / cz - p2n[2 * i + 1];
+        r[2 * i] = (cx / cz - p2n[2 * i]) * wx;
+        r[2 * i + 1] = (cy / cz - p2n[2 * i + 1]) * wy;
         ok = ok && finite_d(r[2 * i]) && finite_d(r[2 * i + 1]);
     }
     return ok;
@@ -215,7 +217,8 @@ __host__ __device__ void solve_one_pose(const float* kp, const float* pts3, cons
     double x[6], r[MAXPTS * 2], rn[MAXPTS * 2], J[MAXPTS * 2 * 6];
     rvec_from_R(R, x);
     x[3] = t[0]; x[4] = t[1]; x[5] = t[2];
-    if (!residuals(x, p3, p2n, n, r)) return;
+    const double fgm = sqrt(fabs(fx * fy)), wx = fgm > 0 ? fabs(fx) / fgm : 1.0, wy = fgm > 0 ? fabs(fy) / fgm : 1.0;
+    if (!residuals(x, p3, p2n, n, r, wx, wy)) return;
     double lam = 1e-3;
     const int m = 2 * n;
     for (int it = 0; it < iters; ++it) {
@@ -223,7 +226,7 @@ __host__ __device__ void solve_one_pose(const float* kp, const float* pts3, cons
             double xd[6];
             for (int k = 0; k < 6; ++k) xd[k] = x[k];
             xd[j] += 1e-6;
-            residuals(xd, p3, p2n, n, rn);
+            residuals(xd, p3, p2n, n, rn, wx, wy);
             for (int i = 0; i < m; ++i) {
                 const double d = (rn[i] - r[i]) / 1e-6;
                 J[i * 6 + j] = finite_d(d) ? d : 0.0;
@@ -244,7 +247,7 @@ __host__ __device__ void solve_one_pose(const float* kp, const float* pts3, cons
         if (!solve6(H, g, step)) break;
         double xn[6], e0 = 0.0, e1 = 0.0, sn = 0.0;
         for (int k = 0; k < 6; ++k) { xn[k] = x[k] + step[k]; sn += step[k] * step[k]; }
-        const bool fin = residuals(xn, p3, p2n, n, rn);
+        const bool fin = residuals(xn, p3, p2n, n, rn, wx, wy);
         for (int i = 0; i < m; ++i) { e0 += r[i] * r[i]; e1 += rn[i] * rn[i]; }
         if (fin && e1 < e0) {
             for (int k = 0; k < 6; ++k) x[k] = xn[k];
