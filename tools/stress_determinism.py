@@ -1,5 +1,6 @@
-"""Race screen (python tools/stress_determinism.py <prec> <runs> [batch]): the full-depth step (T=6; default B=32) repeated N times must give bit-identical logits every time
-(LDS-DMA / barrier schedules: a RAW race shows up as rare differing tiles)."""
+"""Race screen (python tools/stress_determinism.py <prec> <runs> [batch] [lanes]): the full-depth step (T=6; default B=32) repeated N times must give bit-identical logits
+every time (LDS-DMA / barrier schedules: a RAW race shows up as rare differing tiles).  The reference run is the ONE-LANE step; the repeated runs use `lanes`
+("auto" by default: two sub-batch lanes at B >= 11), so a cross-lane overlap of workspace slices or a missing join shows up here too."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,14 +20,17 @@ rep = max(1, B // 4)
 img = small["images"].repeat(rep, 1, 1, 1, 1).to(torch.bfloat16).cuda()
 bf = small["bbox_feat"].repeat(rep, 1, 1, 1, 1).to(torch.bfloat16).cuda()
 mask = torch.zeros(img.shape[0], 6, dtype=torch.bool, device="cuda"); mask[:, 5] = True
-ref = None
+lanes = sys.argv[4] if len(sys.argv) > 4 else "auto"
+lanes = lanes if lanes == "auto" else int(lanes)
+enc.model.lanes, dec.hip_lanes = 1, 1
+dec(bf, img, mask, enc.predict(img), None)
+ref = dec.last_logits.clone()
+enc.model.lanes, dec.hip_lanes = lanes, lanes
 bad = 0
 for i in range(n):
     dec(bf, img, mask, enc.predict(img), None)
     l = dec.last_logits.clone()
-    if ref is None:
-        ref = l
-    elif not torch.equal(ref, l):
+    if not torch.equal(ref, l):
         bad += 1
         print("run", i, "differs: max", (ref - l).abs().max().item(), "count", int((ref != l).sum()))
-print(f"{prec} B={img.shape[0]}: {n} runs, {bad} differing")
+print(f"{prec} B={img.shape[0]} lanes={lanes}: {n} runs against the one-lane step, {bad} differing")
