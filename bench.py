@@ -760,8 +760,9 @@ def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, coun
          "gemm_time_frac_of_step": round(sum(ms for _, ms in g) / trace_runs / ms_per_step, 4),
          "attention_time_frac_of_step": round(sum(ms for _, ms in a) / trace_runs / ms_per_step, 4),
          "peak_note": "peak = dense MFMA rate at 2.4 GHz (MI355X_MICROARCH.md).  Under its 1400 W cap the part does not hold that clock in a dense "
-                      "GEMM: the same persistent kernels on HALF the CUs deliver 72-82 % of the full-chip rate (profiles/r4_cu_limit_probe.md), a "
-                      "pure MFMA loop without memory traffic sustains 1.9-2.0 PFLOP/s (profiles/r2_mfma_util.md)",
+                      "GEMM: the same persistent kernels on HALF the CUs deliver 72-82 % of the full-chip rate (profiles/r4_cu_limit_probe.md), every "
+                      "MFMA-heavy launch draws 1398-1400 W at a reported 1.73-1.93 GHz (profiles/r4_power_by_kernel.md; this run's board power: the "
+                      "`power` block of the line), a pure MFMA loop without memory traffic sustains 1.9-2.0 PFLOP/s (profiles/r2_mfma_util.md)",
          "whole_path_achieved": round(value_per_gpu * fpp / 1e12, 2),
          "whole_path_frac": round(value_per_gpu * fpp / 1e12 / peak, 4)}
     return r
@@ -886,6 +887,70 @@ def h2d_inclusive(run: "ModeRun", steps: int) -> dict:
             "how": "measured: pinned host buffers, copy stream + 2 device buffer sets, events between copy and compute"}
 
 
+def _hwmon_of(device) -> str | None:
+    """hwmon directory (power1_input / power1_cap / freq1_input) of the amdgpu card behind a HIP device, matched by PCI address."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+    except Exception:  # noqa: BLE001
+        return None
+    for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+        pci = os.path.basename(os.path.realpath(os.path.join(h, "..", "..")))
+        if pci.lower().startswith(want) and os.path.exists(os.path.join(h, "power1_input")):
+            return h
+    return None
+
+
+def power_probe(run: "ModeRun", seconds: float = 1.5) -> dict:
+    """Board power and shader clock WHILE the step runs back to back (sysfs hwmon of the card, sampled from a thread every ~5 ms):
+    the evidence for `roofline.peak_note` in every bench line -- this path runs at the part's power cap, not at a pipe limit."""
+    h = _hwmon_of(run.device)
+    if h is None:
+        return {"available": False, "why": "no amdgpu hwmon node for this device (power1_input) visible in this container"}
+
+    def rd(name):
+        try:
+            return int(open(os.path.join(h, name)).read().strip())
+        except (OSError, ValueError):
+            return None
+    cap = rd("power1_cap")
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            p, f = rd("power1_input"), rd("freq1_input")
+            if p is not None:
+                samples.append((time.perf_counter(), p / 1e6, (f or 0) / 1e6))
+            time.sleep(0.005)
+    idle_w = (rd("power1_input") or 0) / 1e6
+    th = threading.Thread(target=sampler, daemon=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    th.start()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        run.step_single() if len(run.lanes) <= 1 else run.step()
+        n += 1
+        if n % 4 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    stop.set(); th.join()
+    # the SMU's reading lags the load by ~100 ms: the second half of the window is the steady state
+    late = [(w, f) for (t, w, f) in samples if t - t0 > 0.5 * (t1 - t0)]
+    if not late:
+        return {"available": False, "why": "no samples"}
+    ws, fs = [w for w, _ in late], [f for _, f in late]
+    return {"available": True, "avg_w": round(sum(ws) / len(ws), 1), "max_w": round(max(ws), 1), "cap_w": round(cap / 1e6, 1) if cap else None,
+            "frac_of_cap": round(sum(ws) / len(ws) / (cap / 1e6), 3) if cap else None, "before_the_load_w": round(idle_w, 1),
+            "sclk_reported_mhz_avg": round(sum(fs) / len(fs)), "samples": len(late), "steps": n, "seconds": round(t1 - t0, 2),
+            "poses_per_s_during_probe": round(n * run.B / (t1 - t0), 1),
+            "how": "sysfs hwmon power1_input / freq1_input of the card (matched by PCI address), 5 ms sampling from a thread while the captured step "
+                   "replays back to back; steady-state half of the window (the reported sclk is the PLL target, not the delivered rate: "
+                   "profiles/r2_gemm_phase_probe.md section 3)"}
+
+
 def pnp_inclusive(run: "ModeRun", one, steps: int, step_ms: float) -> dict:
     """MEASURED PnP-inclusive rates (never `value`): one D2H of the decoded corners per batch + ONE batched host
     solve (boxdreamer_amd/pnp.py).  serialised: step, D2H, solve, next step.  overlapped: a host thread solves batch i
@@ -970,6 +1035,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-pnp", action="store_true", help="skip the PnP-inclusive side measurement (host PnP, SURVEY 8d / 8f3)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-buffer (PCIe-inclusive) side measurement")
+    ap.add_argument("--no-power", action="store_true", help="skip the board-power / clock probe (sysfs hwmon, 1.5 s of back-to-back steps per mode)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--cpu-plumbing", action="store_true",
                     help="run ONLY the launcher / barrier / corner-gather plumbing on CPU (tests); needs --backend gloo")
@@ -1107,6 +1173,8 @@ def run(args):
             line["h2d_inclusive"] = h2d_inclusive(run, max(4, args.steps))
         if world == 1 and not args.no_pnp:
             line["pnp_inclusive"] = pnp_inclusive(run, one, max(4, args.steps), main_res["ms_per_step"])
+        if world == 1 and not args.no_power and run.graphed is not None:
+            line["power"] = power_probe(run)
     main_res["run"].close()
     del main_res
 
@@ -1136,6 +1204,8 @@ def run(args):
             if "single_stream" in sres:
                 line["strict"]["single_stream"] = sres["single_stream"]
                 line["value_meeting_parity_single_stream"] = sres["single_stream"]["value"]
+            if world == 1 and not args.no_power and srun.graphed is not None:
+                line["strict"]["power"] = power_probe(srun)
             if not args.no_parity:
                 line["strict"]["parity"] = parity_probe(STRICT_PREC, T, device, (srun.enc, srun.dec) if B >= 2 else None)
                 line["value_meeting_parity_logits_max_abs_err"] = line["strict"]["parity"]["logits_max_abs_err"]
