@@ -242,7 +242,7 @@ def planes(prec) -> int:
     return 2 if prec_id(prec) in _X3_FAMILY + _F16X3_FAMILY or prec_id(prec) in (PREC_F16C8, PREC_F16C8_QKV16, PREC_F16C8_QK16) else 1
 
 
-AUTO_LANES_MIN_VIEWS = 64      # one batch runs as two sub-batch lanes from this many (sample, view) images on (profiles/r4_subbatch_lanes.md)
+AUTO_LANES_MIN_VIEWS = 24      # one batch runs as two sub-batch lanes from this many (sample, view) images on (profiles/r4_subbatch_lanes.md)
 
 
 def resolve_lanes(setting, views: int, samples: int, prec=None) -> int:

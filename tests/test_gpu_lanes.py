@@ -151,7 +151,7 @@ def test_lanes_argument_checks(hip):
 
 
 def test_facade_runs_a_large_batch_as_two_lanes_and_says_so(hip):
-    """`BoxDreamer.forward` (BoxDreamerModel.py:112-191) on a batch of >= 64 (sample, view) images: two lanes by default, recorded in
+    """`BoxDreamer.forward` (BoxDreamerModel.py:112-191) on a batch of >= 24 (sample, view) images: two lanes by default, recorded in
     the output dict, every output equal to the `hip_lanes: 1` run."""
     import copy
     from boxdreamer_amd.model import BoxDreamer

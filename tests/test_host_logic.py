@@ -393,10 +393,10 @@ def test_promotion_state_file_round_trip(tmp_path):
 
 def test_sub_batch_lane_resolution():
     """`hip_lanes` ("auto" | 1..4) -> lanes of one whole-path call (include/boxdreamer_hip.h, ABI v6): never more lanes than units the
-    batch can be cut at, auto = two lanes from 64 (sample, view) images on, anything else is rejected on the host."""
+    batch can be cut at, auto = two lanes from 24 (sample, view) images on (batch 4 at T = 6), anything else is rejected on the host."""
     from boxdreamer_amd import _lib
     assert _lib.resolve_lanes("auto", 32 * 6, 32) == 2 and _lib.resolve_lanes(None, 32 * 6, 32) == 2
-    assert _lib.resolve_lanes("auto", 6, 1) == 1 and _lib.resolve_lanes("auto", 63, 63) == 1 and _lib.resolve_lanes("auto", 64, 32) == 2
+    assert _lib.resolve_lanes("auto", 6, 1) == 1 and _lib.resolve_lanes("auto", 23, 23) == 1 and _lib.resolve_lanes("auto", 24, 4) == 2
     assert _lib.resolve_lanes(4, 24, 3) == 3 and _lib.resolve_lanes(1, 1000, 100) == 1 and _lib.resolve_lanes("2", 12, 2) == 2
     assert _lib.resolve_lanes("auto", 64 * 6, 64, "fp8") == 1 and _lib.resolve_lanes(2, 64 * 6, 64, "fp8") == 2     # e4m3 class: auto stays at one
     assert _lib.resolve_lanes("auto", 32 * 6, 32, "f16c8_qk16") == 2 and _lib.resolve_lanes("auto", 32 * 6, 32, "bf16") == 2
