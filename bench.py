@@ -946,6 +946,7 @@ def power_probe(run: "ModeRun", seconds: float = 1.5) -> dict:
             "frac_of_cap": round(sum(ws) / len(ws) / (cap / 1e6), 3) if cap else None, "before_the_load_w": round(idle_w, 1),
             "sclk_reported_mhz_avg": round(sum(fs) / len(fs)), "samples": len(late), "steps": n, "seconds": round(t1 - t0, 2),
             "poses_per_s_during_probe": round(n * run.B / (t1 - t0), 1),
+            "joule_per_pose": round(sum(ws) / len(ws) / (n * run.B / (t1 - t0)), 3),
             "how": "sysfs hwmon power1_input / freq1_input of the card (matched by PCI address), 5 ms sampling from a thread while the captured step "
                    "replays back to back; steady-state half of the window (the reported sclk is the PLL target, not the delivered rate: "
                    "profiles/r2_gemm_phase_probe.md section 3)"}

@@ -147,3 +147,19 @@ def test_rank_failure_on_the_gpu_box_is_reported():
     assert r.returncode != 0
     j = _one_line(r)
     assert j["n_gpus"] == 2 and j["value"] is None and "error" in j
+
+
+def test_power_probe_degrades_without_a_card():
+    """bench.py's board-power block reads the amdgpu hwmon node of the HIP device; where there is none (this CPU container, a box that hides
+    sysfs) it must say so instead of raising."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    assert b._hwmon_of(torch.device("cpu")) is None or isinstance(b._hwmon_of(torch.device("cpu")), str)
+
+    class _Run:
+        device = torch.device("cpu")
+    if b._hwmon_of(_Run.device) is None:
+        rep = b.power_probe(_Run())
+        assert rep["available"] is False and "why" in rep
