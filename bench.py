@@ -49,12 +49,11 @@ PEAK_HBM_GBS = 8000.0
 DINO_FLOP_PER_IMAGE = 47_078_313_984          # BASELINE.md §4 / SURVEY.md §8(d)
 TRAINED_LIKE = "outliers_g0.5"                  # the trained-like weight set of the strict_trained_like leg (tests/golden/case_outliers_g0.5_T2.npz)
 STRICT_PREC = "f16c8_qk16"                      # the package default: meets the 1e-3 bar with a 4x margin
-DTYPE_LABEL = {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3", "bf16x3_attn_x3": "bf16x3", "bf16x3_attn_f16": "bf16x3 (attention: f16)",
-               "bf16x3_qkv16": "bf16x3 (BETR QKV: f16)", "f16c8": "f16 + e4m3 corrections",
-               "f16c8_qkv16": "f16 + e4m3 corrections (BETR QKV: f16)", "f16c8_qk16": "f16 + e4m3 corrections (BETR q, k columns: f16)", "fp8": "fp8-e4m3 (Linears) + bf16 (attention)",
+DTYPE_LABEL = {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3", "bf16x3_attn_x3": "bf16x3", "f16c8": "f16 + e4m3 corrections",
+               "f16c8_qk16": "f16 + e4m3 corrections (BETR q, k columns: f16)", "fp8": "fp8-e4m3 (Linears) + bf16 (attention)",
                "fp8_mixed": "fp8-e4m3 (MLPs, DINOv2 QKV) + bf16 (proj, BETR QKV, adapter, head, attention)",
                "f16x3": "f16x3 (split-f16 Linears)", "f16x3_attn_x3": "f16x3 (split-f16 Linears, split-bf16 attention)"}
-MFMA_PASSES = {"f16x3": 3.0, "f16x3_attn_x3": 3.0, "bf16x3": 3.0, "bf16x3_attn_x3": 3.0, "bf16x3_attn_f16": 3.0, "bf16x3_qkv16": 2.75, "f16c8": 2.0, "f16c8_qkv16": 1.9, "f16c8_qk16": 1.93}
+MFMA_PASSES = {"f16x3": 3.0, "f16x3_attn_x3": 3.0, "bf16x3": 3.0, "bf16x3_attn_x3": 3.0, "f16c8": 2.0, "f16c8_qk16": 1.93}
 _PRECS = tuple(DTYPE_LABEL)
 
 
@@ -391,8 +390,8 @@ def kernel_source_sha() -> str:
 def algorithmic_gemm_bytes(prec: str, B: int, T: int) -> tuple[int, int]:
     """(bytes, bd_gemm calls) of one step if every GEMM read each operand ONCE and wrote its result once: A, W, fp32 residual in /
     result out, in the storage formats of the mode."""
-    a = {"bf16": 2, "fp16": 2, "fp8": 1, "f16c8": 3, "f16c8_qkv16": 3, "f16c8_qk16": 3}.get(prec, 4)           # activation operand bytes / element
-    w = {"bf16": 2, "fp16": 2, "fp8": 1, "f16c8": 4, "f16c8_qkv16": 4, "f16c8_qk16": 4}.get(prec, 4)           # weight bytes / element (F16C8: f16 + [q8|lo8])
+    a = {"bf16": 2, "fp16": 2, "fp8": 1, "f16c8": 3, "f16c8_qk16": 3}.get(prec, 4)           # activation operand bytes / element
+    w = {"bf16": 2, "fp16": 2, "fp8": 1, "f16c8": 4, "f16c8_qk16": 4}.get(prec, 4)           # weight bytes / element (F16C8: f16 + [q8|lo8])
     strict = prec not in ("bf16", "fp16", "fp8")
     total, calls = 0, 0
 
@@ -414,7 +413,6 @@ def algorithmic_gemm_bytes(prec: str, B: int, T: int) -> tuple[int, int]:
     M, Mq = n * 256, B * 256
     gemm(M, 768, 768, a, w, a); gemm(M, 768, 768, a, w, 4)                                     # adapter
     gemm(M, 768, 1600 if prec != "fp8" else 1664, a, w, 4, True)                                # heatmap patch embedding + rgb + pos
-    q16 = prec in ("f16c8_qkv16", "bf16x3_qkv16")
     for i in range(12):                                       # BETR: f16 attention in the strict modes (q, k RMS-normalised)
         Mt = M if i < 11 else Mq
         if prec == "f16c8_qk16":                              # QKV split by column: q, k one f16 pass on the f16 plane, v full F16C8
@@ -424,7 +422,7 @@ def algorithmic_gemm_bytes(prec: str, B: int, T: int) -> tuple[int, int]:
             gemm(Mt, 3072, 768, a, w, a)
             gemm(Mt, 768, 3072, a, w, 4, True)
         else:
-            block(M, Mt, 2 if q16 else a, 2 if q16 else w, 2)
+            block(M, Mt, a, w, 2)
     gemm(Mq, 1568, 768, a, w, 4)                                                               # head
     return total, calls
 
@@ -477,83 +475,168 @@ def _kclass(name: str) -> str:
     return "other"
 
 
-def measure_counters(args) -> None:
+MARKER = "erfinv"        # a torch kernel nothing else in this process launches: brackets the measured steps of each mode in the counter child
+
+
+def counter_child(args) -> None:
+    """(hidden: what the rocprofv3 passes profile.)  One process, one or more modes: per mode the step's modules are built exactly as
+    the timed run builds them (load-time calibration included), then 1 warm-up + `--steps` un-graphed ONE-LANE steps run between two
+    marker kernels, so that the parent attributes exactly the measured steps' dispatches to the mode -- no weight packing, no
+    calibration forwards, no warm-up in the figures."""
+    from boxdreamer_amd import synth
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    tiny = torch.full((64,), 0.25, device=device)
+    B, T = args.batch, args.views
+    one = synth.make_batch(seed=100, B=B, T=T)
+    images, bbox = one["images"].to(torch.bfloat16).to(device), one["bbox_feat"].to(torch.bfloat16).to(device)
+    mask = torch.zeros(B, T, dtype=torch.bool, device=device); mask[:, T - 1] = True
+    a1 = argparse.Namespace(**{**vars(args), "graph": False, "in_flight": 1, "lanes": "1", "cache_refs": False})
+    for mode in args.counter_child.split(","):
+        run = ModeRun(mode, a1, device, 1, 0, None, images, bbox, mask)
+        run.eager()
+        torch.cuda.synchronize()
+        tiny.erfinv()
+        for _ in range(args.steps):
+            run.eager()
+        torch.cuda.synchronize()
+        tiny.erfinv()
+        torch.cuda.synchronize()
+        run.close()
+        del run
+        torch.cuda.empty_cache()
+    print(json.dumps({"counter_child": args.counter_child, "steps": args.steps}), flush=True)
+
+
+BASIC_GROUPS = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"))
+
+
+def collect_counters(modes, B: int, T: int, groups, steps: int = 2, deadline: float | None = None, log=None) -> dict:
+    """rocprofv3 PMC passes (one counter group per pass, --kernel-trace only: the combination MI355X_MICROARCH.md prescribes) over
+    `bench.py --counter-child <modes>`; returns {mode: figures per step and per kernel class}.  Stops launching passes once
+    `deadline` (time.monotonic()) has gone by and raises TimeoutError -- a partial set of passes is not reported."""
     import collections, csv
+    child = ["--counter-child", ",".join(modes), "--batch", str(B), "--views", str(T), "--steps", str(steps)]
+    names = sorted({c for g in groups for c in g})
+    acc = {m: {c: collections.defaultdict(float) for c in names + ["stall:SQ_WAVE_CYCLES"]} for m in modes}
+    launches = {m: collections.defaultdict(int) for m in modes}
+    dur_ns = {m: collections.defaultdict(float) for m in modes}
+    pass_seconds = []
+    for group in groups:
+        if deadline is not None and time.monotonic() > deadline:
+            raise TimeoutError(f"counter budget spent after {len(pass_seconds)} of {len(groups)} passes ({pass_seconds} s)")
+        t0 = time.monotonic()
+        left = None if deadline is None else max(20.0, deadline - t0 + 30.0)
+        path = _rocprof_pass(group, child, timeout_s=600 if left is None else left)
+        pass_seconds.append(round(time.monotonic() - t0, 1))
+        if log:
+            log(f"counter pass {group}: {pass_seconds[-1]} s")
+        rows = list(csv.DictReader(open(path)))
+        # dispatch order; the marker kernel brackets the measured steps of mode k between its (2k+1)-th and (2k+2)-th launch
+        disp = {}
+        for r in rows:
+            disp.setdefault(int(r["Dispatch_Id"]), []).append(r)
+        seen_markers, is_stall = 0, "SQ_WAIT_ANY" in group
+        for did in sorted(disp):
+            rs = disp[did]
+            if MARKER in rs[0]["Kernel_Name"]:
+                seen_markers += 1
+                continue
+            if seen_markers % 2 == 0 or seen_markers // 2 >= len(modes):
+                continue                                   # outside a measured window: packing, calibration, warm-up
+            m = modes[seen_markers // 2]
+            k = _kclass(rs[0]["Kernel_Name"])
+            for r in rs:
+                c = r["Counter_Name"]
+                if is_stall and c == "SQ_WAVE_CYCLES":
+                    c = "stall:SQ_WAVE_CYCLES"
+                if c in acc[m]:
+                    acc[m][c][k] += float(r["Counter_Value"])
+            if group[0] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                launches[m][k] += 1
+                dur_ns[m][k] += int(rs[0]["End_Timestamp"]) - int(rs[0]["Start_Timestamp"])
+        if seen_markers != 2 * len(modes):
+            raise RuntimeError(f"counter child: {seen_markers} marker launches in the profile, expected {2 * len(modes)}")
+    lds_group = [c for c in LDS_COUNTERS if c in names]
+    stall_group = [c for c in STALL_COUNTERS if c in names and "SQ_WAIT_ANY" in names]
+    result = {}
+    for m in modes:
+        A = acc[m]
+        alg_bytes, calls = algorithmic_gemm_bytes(m, B, T)
+        per = {}
+        for k in sorted(launches[m], key=lambda k: -dur_ns[m][k]):
+            fetch = 2.0 * A["FETCH_SIZE"][k] * 1024.0 / steps if "FETCH_SIZE" in A else 0.0      # KB -> bytes; x2: gfx950 tallies 128-B requests at 64 B
+            write = A["WRITE_SIZE"][k] * 1024.0 / steps if "WRITE_SIZE" in A else 0.0
+            cyc = A["SQ_BUSY_CYCLES"][k] / 32.0                             # summed over the 32 shader engines
+            per[k] = {"launches_per_step": round(launches[m][k] / steps, 2), "ms_per_step": round(dur_ns[m][k] / steps / 1e6, 3),
+                      "fetch_bytes_per_step": round(fetch), "write_bytes_per_step": round(write),
+                      "hbm_gb_per_s": round((fetch + write) / max(dur_ns[m][k] / steps, 1), 1),
+                      "mfma_busy": round(A["SQ_VALU_MFMA_BUSY_CYCLES"][k] / max(cyc * 1024.0, 1.0), 4),
+                      "delivered_clock_ghz": round(cyc / max(dur_ns[m][k], 1), 3)}
+            if lds_group:
+                wc = A["SQ_WAVE_CYCLES"][k]
+                per[k]["lds"] = {c: round(A[c][k] / steps) for c in lds_group}
+                per[k]["lds"]["wait_inst_lds_over_wave_cycles"] = round(A["SQ_WAIT_INST_LDS"][k] / wc, 4) if wc else None
+                per[k]["lds"]["active_inst_lds_over_wave_cycles"] = round(A["SQ_ACTIVE_INST_LDS"][k] / wc, 4) if wc else None
+                ia = A["SQ_LDS_IDX_ACTIVE"][k]
+                per[k]["lds"]["bank_conflict_over_idx_active"] = round(A["SQ_LDS_BANK_CONFLICT"][k] / ia, 4) if ia else None
+                per[k]["lds"]["lds_array_busy"] = round(ia / max(cyc * 256.0, 1.0), 4) if ia else None
+            if stall_group:
+                wc = A["stall:SQ_WAVE_CYCLES"][k]
+                st = {c: round(A[c][k] / steps) for c in stall_group if c != "SQ_WAVE_CYCLES"}
+                st["SQ_WAVE_CYCLES"] = round(wc / steps)
+                for c, nm in (("SQ_WAIT_ANY", "parked_at_waitcnt_or_barrier"), ("SQ_WAIT_INST_ANY", "issue_stalled"), ("SQ_ACTIVE_INST_ANY", "issuing"),
+                              ("SQ_ACTIVE_INST_VALU", "issuing_valu_incl_mfma"), ("SQ_ACTIVE_INST_MISC", "issuing_misc")):
+                    if c in stall_group:
+                        st[nm + "_frac_of_wave_cycles"] = round(A[c][k] / wc, 4) if wc else None
+                per[k]["stall"] = st
+        step_classes = [k for k in launches[m] if not k.startswith("harness")]
+        tb = sum(A["SQ_VALU_MFMA_BUSY_CYCLES"][k] for k in step_classes)
+        tc = sum(A["SQ_BUSY_CYCLES"][k] for k in step_classes) / 32.0
+        g = per.get("gemm", {})
+        result[m] = {"prec": m, "batch": B, "views": T, "kernel_source_sha": kernel_source_sha(), "steps_profiled": steps,
+                     "gemm_calls_per_step": calls, "gemm_kernel_launches_per_step": g.get("launches_per_step"),
+                     "gemm_hbm_bytes_per_call": round((g.get("fetch_bytes_per_step", 0) + g.get("write_bytes_per_step", 0)) / calls),
+                     "gemm_algorithmic_bytes_per_call": round(alg_bytes / calls),
+                     "gemm_traffic_over_algorithmic": round((g.get("fetch_bytes_per_step", 0) + g.get("write_bytes_per_step", 0)) / alg_bytes, 3),
+                     "mfma_busy_whole_step": round(tb / max(tc * 1024.0, 1.0), 4), "per_kernel_class": per,
+                     "lds_counters": list(lds_group), "stall_counters": list(stall_group), "pass_seconds": pass_seconds,
+                     "how": "rocprofv3 --kernel-trace --pmc <one group per pass: " + " | ".join(" ".join(g) for g in groups) + "> over `bench.py "
+                            + " ".join(child) + "` (un-graphed, one batch at a time as ONE lane; only the dispatches between the child's "
+                            "marker kernels count: no packing, calibration or warm-up); bytes = counter KB x 1024, FETCH_SIZE x 2 (gfx950 "
+                            "correction, MI355X_MICROARCH.md HBM section: L2 -> fabric requests, MALL hits included, i.e. an UPPER bound on "
+                            "HBM bytes), WRITE_SIZE as is; MFMA busy = MFMA-busy SIMD-cycles / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs)"}
+    return result
+
+
+def measure_counters(args) -> None:
+    """`--measure-counters --prec P`: all counter groups (traffic, MFMA busy, LDS, stalls) for ONE mode -> profiles/counters_<P>.json."""
     prec, B, T = args.prec, args.batch, args.views
-    child = ["--prec", prec, "--batch", str(B), "--views", str(T), "--steps", "2", "--warmup", "1", "--no-graph", "--in-flight", "1", "--lanes", "1",
-             "--no-strict", "--no-fp8", "--no-cpu-baseline", "--no-parity", "--no-pnp", "--no-h2d", "--no-trained-like"]
-    acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES") + LDS_COUNTERS + STALL_COUNTERS}
-    acc["stall:SQ_WAVE_CYCLES"] = collections.defaultdict(float)      # (SQ_WAVE_CYCLES is collected in both SQ passes: keep them apart)
-    launches, dur_ns, steps_seen = collections.defaultdict(int), collections.defaultdict(float), 0
-    lds_group = _available_counters(LDS_COUNTERS)          # one more pass: where the LDS time of the mainloops goes
+    lds_group = _available_counters(LDS_COUNTERS)
     stall_group = _available_counters(STALL_COUNTERS)
-    groups = ([("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")] + ([tuple(lds_group)] if lds_group else [])
-              + ([tuple(stall_group)] if stall_group else []))
-    for gi, group in enumerate(groups):
-        path = _rocprof_pass(group, child)
-        first = group[0]
-        is_stall = stall_group and tuple(group) == tuple(stall_group)
-        for r in csv.DictReader(open(path)):
-            c, k = r["Counter_Name"], _kclass(r["Kernel_Name"])
-            if is_stall and c == "SQ_WAVE_CYCLES":
-                c = "stall:SQ_WAVE_CYCLES"
-            if c in acc:
-                acc[c][k] += float(r["Counter_Value"])
-            if c == first and group[0] == "SQ_VALU_MFMA_BUSY_CYCLES":
-                launches[k] += 1
-                dur_ns[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-                if "decode_kernel" in r["Kernel_Name"]:
-                    steps_seen += 1
-    if steps_seen == 0:
-        raise SystemExit("no decode_kernel dispatch in the counter profile: cannot tell how many steps it covers")
-    alg_bytes, calls = algorithmic_gemm_bytes(prec, B, T)
-    per = {}
-    for k in sorted(launches, key=lambda k: -dur_ns[k]):
-        fetch = 2.0 * acc["FETCH_SIZE"][k] * 1024.0 / steps_seen          # KB -> bytes; x2: gfx950 tallies 128-B requests at 64 B
-        write = acc["WRITE_SIZE"][k] * 1024.0 / steps_seen
-        cyc = acc["SQ_BUSY_CYCLES"][k] / 32.0                             # summed over the 32 shader engines
-        per[k] = {"launches_per_step": round(launches[k] / steps_seen, 2), "ms_per_step": round(dur_ns[k] / steps_seen / 1e6, 3),
-                  "fetch_bytes_per_step": round(fetch), "write_bytes_per_step": round(write),
-                  "hbm_gb_per_s": round((fetch + write) / max(dur_ns[k] / steps_seen, 1) , 1),
-                  "mfma_busy": round(acc["SQ_VALU_MFMA_BUSY_CYCLES"][k] / max(cyc * 1024.0, 1.0), 4),
-                  "delivered_clock_ghz": round(cyc / max(dur_ns[k], 1), 3)}
-        if lds_group:
-            # SQ counters are summed over the chip: per step, and as fractions of the class's wave-cycles / LDS-array cycles
-            wc = acc["SQ_WAVE_CYCLES"][k]
-            per[k]["lds"] = {c: round(acc[c][k] / steps_seen) for c in lds_group}
-            per[k]["lds"]["wait_inst_lds_over_wave_cycles"] = round(acc["SQ_WAIT_INST_LDS"][k] / wc, 4) if wc else None
-            per[k]["lds"]["active_inst_lds_over_wave_cycles"] = round(acc["SQ_ACTIVE_INST_LDS"][k] / wc, 4) if wc else None
-            ia = acc["SQ_LDS_IDX_ACTIVE"][k]
-            per[k]["lds"]["bank_conflict_over_idx_active"] = round(acc["SQ_LDS_BANK_CONFLICT"][k] / ia, 4) if ia else None
-            # LDS-array busy fraction: IDX_ACTIVE cycles are summed over the CUs' LDS arrays; the class ran `cyc` shader cycles
-            per[k]["lds"]["lds_array_busy"] = round(ia / max(cyc * 256.0, 1.0), 4) if ia else None
-        if stall_group:
-            wc = acc["stall:SQ_WAVE_CYCLES"][k]
-            st = {c: round(acc[c][k] / steps_seen) for c in stall_group if c != "SQ_WAVE_CYCLES"}
-            st["SQ_WAVE_CYCLES"] = round(wc / steps_seen)
-            for c, nm in (("SQ_WAIT_ANY", "parked_at_waitcnt_or_barrier"), ("SQ_WAIT_INST_ANY", "issue_stalled"), ("SQ_ACTIVE_INST_ANY", "issuing"),
-                          ("SQ_ACTIVE_INST_VALU", "issuing_valu_incl_mfma"), ("SQ_ACTIVE_INST_MISC", "issuing_misc")):
-                if c in stall_group:
-                    st[nm + "_frac_of_wave_cycles"] = round(acc[c][k] / wc, 4) if wc else None
-            per[k]["stall"] = st
-    step_classes = [k for k in launches if not k.startswith("harness")]
-    tb = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"][k] for k in step_classes)
-    tc = sum(acc["SQ_BUSY_CYCLES"][k] for k in step_classes) / 32.0
-    g = per.get("gemm", {})
-    out = {"prec": prec, "batch": B, "views": T, "kernel_source_sha": kernel_source_sha(), "steps_profiled": steps_seen,
-           "gemm_calls_per_step": calls, "gemm_kernel_launches_per_step": g.get("launches_per_step"),
-           "gemm_hbm_bytes_per_call": round((g.get("fetch_bytes_per_step", 0) + g.get("write_bytes_per_step", 0)) / calls),
-           "gemm_algorithmic_bytes_per_call": round(alg_bytes / calls),
-           "gemm_traffic_over_algorithmic": round((g.get("fetch_bytes_per_step", 0) + g.get("write_bytes_per_step", 0)) / alg_bytes, 3),
-           "mfma_busy_whole_step": round(tb / max(tc * 1024.0, 1.0), 4), "per_kernel_class": per,
-           "lds_counters": list(lds_group), "stall_counters": list(stall_group),
-           "how": "rocprofv3 --kernel-trace --pmc <one group per pass: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES | the LDS group> over "
-                  "`bench.py " + " ".join(child) + "` (one batch at a time, un-graphed); bytes = counter KB x 1024, FETCH_SIZE x 2 (gfx950 "
-                  "correction, MI355X_MICROARCH.md HBM section), WRITE_SIZE as is; MFMA busy = MFMA-busy SIMD-cycles / (SQ_BUSY_CYCLES / 32 x "
-                  "1024 SIMDs); per step = totals / decode_kernel dispatches"}
+    groups = list(BASIC_GROUPS) + ([tuple(lds_group)] if lds_group else []) + ([tuple(stall_group)] if stall_group else [])
+    out = collect_counters([prec], B, T, groups)[prec]
     path = os.path.join(ROOT, "profiles", f"counters_{prec}.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "how"}), flush=True)
+
+
+def inline_counters(modes, B: int, T: int, budget_s: float):
+    """The default single-GPU run re-measures MFMA-busy and HBM traffic for the headline and the default mode IN THIS RUN (VERDICT r4
+    item 4): three PMC passes over one child process that runs both modes, bounded by `budget_s`.  ({mode: figures} or None, why-not)."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 is not on PATH"
+    t0 = time.monotonic()
+    try:
+        res = collect_counters(list(modes), B, T, BASIC_GROUPS, steps=2, deadline=t0 + budget_s,
+                               log=lambda msg: print("bench: " + msg, file=sys.stderr, flush=True))
+    except Exception as e:                                   # noqa: BLE001 -- the stamped file is the fall-back, never a failed bench
+        return None, f"in-run counter measurement failed ({type(e).__name__}: {str(e)[:300]})"
+    for m in res.values():
+        m["measured_in_this_run"] = True
+        m["seconds"] = round(time.monotonic() - t0, 1)
+    return res, None
 
 
 def load_counters(prec: str, B: int, T: int):
@@ -748,6 +831,9 @@ def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, coun
                         "attention": counters["per_kernel_class"].get("attention", {}).get("mfma_busy"),
                         "whole_step_one_batch_at_a_time": counters["mfma_busy_whole_step"],
                         "unit": "fraction of SIMD cycles with the MFMA pipe busy (counted, rocprofv3 PMC)"} if counters else None),
+         "mfma_busy_gemm": counters["per_kernel_class"].get("gemm", {}).get("mfma_busy") if counters else None,
+         "mfma_busy_whole_step": counters["mfma_busy_whole_step"] if counters else None,
+         "counters_measured_in_this_run": bool(counters and counters.get("measured_in_this_run")),
          "algorithmic_flops_per_launch": round(sum(f for f, _ in g) / max(len(g), 1)), "launches": len(g),
          "events": f"HIP events (launch stream) around every GEMM / attention launch of {trace_runs} un-graphed ONE-LANE executions of "
                    "the step on the same buffers right after the timed region (events cannot be timed inside a captured graph; with "
@@ -766,6 +852,20 @@ def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, coun
          "whole_path_achieved": round(value_per_gpu * fpp / 1e12, 2),
          "whole_path_frac": round(value_per_gpu * fpp / 1e12 / peak, 4)}
     return r
+
+
+def apply_counters(rf: dict, c: dict) -> None:
+    """Overwrite a roofline block's counter-derived fields with figures measured in THIS run (inline_counters)."""
+    pk = c["per_kernel_class"]
+    rf.update(traffic=c["gemm_hbm_bytes_per_call"], traffic_source="measured in THIS run: " + c["how"],
+              algorithmic_bytes_per_launch=c["gemm_algorithmic_bytes_per_call"], traffic_over_algorithmic=c["gemm_traffic_over_algorithmic"],
+              mfma_busy={"gemm": pk.get("gemm", {}).get("mfma_busy"), "attention": pk.get("attention", {}).get("mfma_busy"),
+                         "whole_step_one_batch_at_a_time": c["mfma_busy_whole_step"],
+                         "unit": "fraction of SIMD cycles with the MFMA pipe busy (counted, rocprofv3 PMC)"},
+              mfma_busy_gemm=pk.get("gemm", {}).get("mfma_busy"), mfma_busy_whole_step=c["mfma_busy_whole_step"],
+              counters_measured_in_this_run=True, counter_pass_seconds=c.get("pass_seconds"),
+              gemm_ms_per_step_under_the_counters=pk.get("gemm", {}).get("ms_per_step"),
+              delivered_clock_ghz_gemm=pk.get("gemm", {}).get("delivered_clock_ghz"))
 
 
 def calibration_summary(rep: dict) -> dict:
@@ -1051,12 +1151,21 @@ def main():
     ap.add_argument("--plumbing-fail-stage", default="before_timed", choices=["before_timed", "after_timed", "before_report"])
     ap.add_argument("--plumbing-short-rank", type=int, default=-1, help="(--cpu-plumbing) this rank offers only one in-flight lane")
     ap.add_argument("--plumbing-global-batch", type=int, default=0, help="(--cpu-plumbing) also gather a ragged global batch of this size")
+    ap.add_argument("--counter-child", default="", help=argparse.SUPPRESS)        # what the rocprofv3 passes profile: comma-separated modes
+    ap.add_argument("--no-inline-counters", action="store_true",
+                    help="do not re-measure MFMA-busy / HBM traffic with rocprofv3 inside this run (single GPU; ~45 s); the stamped "
+                         "profiles/counters_<mode>.json is then the source, if it matches the kernel sources")
+    ap.add_argument("--counter-budget", type=float, default=75.0, help="seconds the in-run counter passes may take before they are abandoned")
+    ap.add_argument("--config3", action="store_true",
+                    help="also time BASELINE configs[3]'s per-GPU shard (1 query + 16 refs, batch 32/GPU) in the same line (default for --gpus > 1)")
     ap.add_argument("--measure-counters", action="store_true",
                     help="run the rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy: one pass each) over this script for --prec and "
                          "write profiles/counters_<prec>.json, which later default runs report as roofline.traffic / mfma_busy")
     args = ap.parse_args()
 
     maybe_respawn(args)
+    if args.counter_child:
+        return counter_child(args)
     if args.measure_counters:
         return measure_counters(args)
     _, rank0, _ = dist_env()
@@ -1192,8 +1301,8 @@ def run(args):
                               "what": "the package's DEFAULT mode.  Linears: one f16 MFMA pass + one e4m3 correction pass over a doubled K "
                                       "(BD_PREC_F16C8); BETR's QKV Linear split by column: q, k (RMS-normalised right away) as ONE f16 pass, v as "
                                       "the full F16C8 product; f16 attention where q/k are RMS-normalised, split-bf16 attention in DINOv2.  "
-                                      "Alternatives measured on the same box (profiles/r3_strict_modes.md): f16c8_qkv16 (round 2's: v columns "
-                                      "single-pass too) 5.9e-4 +1.7 %, f16c8 2.3e-4 -2 %, bf16x3 1.1e-4 -19 %",
+                                      "Alternatives measured on the same box (profiles/r3_strict_modes.md): f16c8 2.3e-4 -2 %, bf16x3 1.1e-4 -19 %; what a "
+                                      "third (single-f16) level per Linear or a cheaper DINOv2 attention would buy: profiles/r5_default_mode_levers.md",
                               "value": round(sres["value"], 2), "unit": "poses/s",
                               "poses_per_s_per_gpu": round(sres["value"] / world, 2),
                               "ms_per_step": round(sres["ms_per_step"], 3), "dtype": DTYPE_LABEL[STRICT_PREC],
@@ -1255,10 +1364,63 @@ def run(args):
                                              "(tests/test_gpu_path.py::test_fp8_mode_restated_tolerance); not a mode that meets the 1e-3 bar"}
         fres["run"].close()
         del fres
+    # ---- BASELINE configs[3]'s per-GPU shard in the same line: 1 query + 16 refs, batch 32 per GPU, headline mode;
+    # every rank takes part (same barriers, same corner gather); default for N > 1, `--config3` at N = 1
+    PROGRESS["stage"] = "configs[3] leg (T = 17)"
+    if rank == 0:
+        PROGRESS["line"] = dict(line)
+    if (world > 1 or args.config3) and T == 6 and not args.cache_refs:
+        torch.cuda.empty_cache()
+        T3 = 17
+        one3 = synth.make_batch(seed=500 + rank, B=B, T=T3)
+        img3, bb3 = one3["images"].to(torch.bfloat16).to(device), one3["bbox_feat"].to(torch.bfloat16).to(device)
+        mask3 = torch.zeros(B, T3, dtype=torch.bool, device=device); mask3[:, T3 - 1] = True
+        args3 = argparse.Namespace(**{**vars(args), "views": T3, "in_flight": 1})
+        cres = measure_mode(prec, args3, device, world, rank, dist, img3, bb3, mask3)
+        if rank == 0:
+            line["config3"] = {"workload": workload_name(B, T3, prec, world, False), "mode": prec, "value": round(cres["value"], 2), "unit": "poses/s",
+                               "poses_per_s_per_gpu": round(cres["value"] / world, 2), "ms_per_step": round(cres["ms_per_step"], 3),
+                               "global_batch": B * world, "views": T3, "gflop_per_pose": round(cres["fpp"] / 1e9, 2),
+                               "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in cres["per_rank"]],
+                               "sub_batch_lanes": cres["sub_lanes"],
+                               "roofline": {k: cres["roofline"][k] for k in ("achieved", "frac", "whole_path_achieved", "whole_path_frac", "attention_achieved")}}
+            line["config"].update(config3_value=line["config3"]["value"], config3_ms_per_step=line["config3"]["ms_per_step"],
+                                  config3_global_batch=B * world, config3_views=T3)
+        cres["run"].close()
+        del cres
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(T)
             line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+        # ---- MFMA-busy and HBM traffic of the headline and the default mode, counted IN THIS RUN
+        if world == 1 and not args.no_inline_counters and not args.cache_refs:
+            PROGRESS["stage"] = "in-run counters (rocprofv3)"
+            torch.cuda.empty_cache()
+            modes = [prec] + ([STRICT_PREC] if "strict" in line else [])
+            got, why = inline_counters(modes, B, T, args.counter_budget)
+            if got:
+                apply_counters(line["roofline"], got[prec])
+                if "strict" in line:
+                    apply_counters(line["strict"]["roofline"], got[STRICT_PREC])
+            else:
+                line["roofline"]["counters_in_this_run_skipped"] = why
+        # ---- the figures of record as flat scalars inside the dicts the driver's record keeps
+        par = line.get("parity") or {}
+        line["config"].update(value_mode=prec, value_meets_parity=par.get("meets_tolerance"),
+                              value_logits_max_abs_err=par.get("logits_max_abs_err"), value_top20_sets_equal_frac=par.get("top20_sets_equal_frac"))
+        st = line.get("strict")
+        if st:
+            sp, srf = st.get("parity") or {}, st["roofline"]
+            line["config"].update(parity_mode=st["mode"], parity_mode_value=st["value"], parity_mode_ms_per_step=st["ms_per_step"],
+                                  parity_mode_logits_max_abs_err=sp.get("logits_max_abs_err"), parity_mode_meets_parity=sp.get("meets_tolerance"),
+                                  parity_mode_top20_sets_equal_frac=sp.get("top20_sets_equal_frac"))
+            line["roofline"].update(parity_mode=st["mode"], parity_mode_value=st["value"], parity_mode_ms_per_step=st["ms_per_step"],
+                                    parity_mode_logits_max_abs_err=sp.get("logits_max_abs_err"), parity_mode_achieved=srf["achieved"],
+                                    parity_mode_frac=srf["frac"], parity_mode_whole_path_frac=srf["whole_path_frac"],
+                                    parity_mode_mfma_busy_gemm=srf.get("mfma_busy_gemm"), parity_mode_mfma_busy_whole_step=srf.get("mfma_busy_whole_step"),
+                                    parity_mode_passes_per_flop=srf["mfma_passes_per_algorithmic_flop"],
+                                    parity_mode_traffic_over_algorithmic=srf.get("traffic_over_algorithmic"),
+                                    parity_mode_counters_measured_in_this_run=srf.get("counters_measured_in_this_run"))
         PROGRESS["printed"] = True
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -16,18 +16,15 @@ LIB_PATH = os.environ.get("BOXDREAMER_HIP_LIB") or os.path.join(HERE, "libboxdre
 
 DTYPE_BF16, DTYPE_F16, DTYPE_F32 = 0, 1, 2
 PREC_BF16, PREC_F16, PREC_BF16X3, PREC_F16_OUT_BF16X3, PREC_FP8, PREC_BF16_OUT_FP8 = 0, 1, 2, 3, 4, 5
-PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16 = 6, 7      # whole-path only: attention policy of the strict family
+PREC_BF16X3_ATTN_X3 = 6                                # whole-path only: split-bf16 attention everywhere (7, 11, 12: removed in ABI 7)
 PREC_F16C8 = 8                                         # f16 + e4m3 corrections (include/boxdreamer_hip.h)
 PREC_F16_OUT_F16C8, PREC_BF16X3_OUT_F16C8 = 9, 10      # bd_attention[_q] only: f16 / split-bf16 attention, F16C8 operand out
-PREC_BF16X3_QKV16 = 11                                 # whole-path only: split-bf16, BETR's QKV Linear as one f16 pass
-PREC_F16C8_QKV16 = 12                                  # whole-path only: F16C8 Linears, BETR's QKV Linear as one f16 pass
 PREC_F16C8_QK16 = 13                                   # whole-path only: F16C8 Linears, BETR's QKV split: q, k one f16 pass, v F16C8
 PREC_F16X3, PREC_F16X3_ATTN_X3 = 14, 15                # split-f16 Linears (the promoted class); _ATTN_X3: split-bf16 attention everywhere
 PREC_F16_OUT_F16X3, PREC_BF16X3_OUT_F16X3 = 16, 17     # bd_attention[_q] only: split-f16 planes out
 F16C8_D = 11                                           # lo planes are scaled 2^D above their q plane
 PREC_NAMES = {"bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8,
-              "bf16x3_attn_x3": PREC_BF16X3_ATTN_X3, "bf16x3_attn_f16": PREC_BF16X3_ATTN_F16, "f16c8": PREC_F16C8,
-              "bf16x3_qkv16": PREC_BF16X3_QKV16, "f16c8_qkv16": PREC_F16C8_QKV16, "f16c8_qk16": PREC_F16C8_QK16,
+              "bf16x3_attn_x3": PREC_BF16X3_ATTN_X3, "f16c8": PREC_F16C8, "f16c8_qk16": PREC_F16C8_QK16,
               "f16x3": PREC_F16X3, "f16x3_attn_x3": PREC_F16X3_ATTN_X3}
 _F16X3_FAMILY = (PREC_F16X3, PREC_F16X3_ATTN_X3)
 # "fp8_mixed" (configs[4], usable form): the e4m3 class with the precision-critical Linears kept in bf16 through the per-Linear
@@ -48,9 +45,9 @@ def fp8_mixed_policy(depth: int, normed: bool):
     if normed:      # BETR
         return [PROMOTE_QKV | PROMOTE_PROJ] * depth, PROMOTE_ADAPTER_FC1 | PROMOTE_ADAPTER_FC2 | PROMOTE_BBOX_PROJ
     return [PROMOTE_PROJ] * depth, 0
-_X3_FAMILY = (PREC_BF16X3, PREC_BF16X3_ATTN_X3, PREC_BF16X3_ATTN_F16, 11)
+_X3_FAMILY = (PREC_BF16X3, PREC_BF16X3_ATTN_X3)
 ACT_NONE, ACT_GELU = 0, 1
-# per-Linear promotion of the F16C8 family to split-bf16 (include/boxdreamer_hip.h: BD_PROMOTE_*)
+# per-Linear promotion: F16C8 family -> split-f16, e4m3 -> bf16 (include/boxdreamer_hip.h: BD_PROMOTE_*)
 PROMOTE_QKV, PROMOTE_PROJ, PROMOTE_FC1, PROMOTE_FC2, PROMOTE_ATTN = 1, 2, 4, 8, 16
 PROMOTE_ADAPTER_FC1, PROMOTE_ADAPTER_FC2, PROMOTE_BBOX_EMB, PROMOTE_BBOX_PROJ = 1, 2, 4, 8
 PROMOTE_PATCH_EMBED = 1
@@ -181,7 +178,7 @@ def load() -> C.CDLL:
     lib.bd_solve_pnp_host.argtypes = [vp, vp, vp, i, i, i, vp, i]
     lib.bd_trace_begin.argtypes = [i]
     lib.bd_trace_end.argtypes = [C.POINTER(TraceRecord), i]
-    if lib.bd_abi_version() != 6:
+    if lib.bd_abi_version() != 7:
         raise HipLibraryError("libboxdreamer_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -219,7 +216,7 @@ def prec_id(prec) -> int:
 def operand_prec(prec) -> int:
     """Operand class of a (possibly whole-path) precision id: the value the unit operators and the weight packer take."""
     pid = prec_id(prec)
-    if pid in (PREC_F16C8_QKV16, PREC_F16C8_QK16):
+    if pid == PREC_F16C8_QK16:
         return PREC_F16C8
     if pid in _F16X3_FAMILY:
         return PREC_F16X3
@@ -230,7 +227,7 @@ def op_dtype(prec) -> torch.dtype:
     pid = prec_id(prec)
     if pid == PREC_FP8:
         return torch.float8_e4m3fn          # OCP e4m3 (gfx950), not MI300's fnuz
-    return torch.float16 if pid in (PREC_F16, PREC_F16C8, PREC_F16C8_QKV16, PREC_F16C8_QK16) + _F16X3_FAMILY else torch.bfloat16     # F16C8: plane 1 holds raw e4m3 bytes
+    return torch.float16 if pid in (PREC_F16, PREC_F16C8, PREC_F16C8_QK16) + _F16X3_FAMILY else torch.bfloat16     # F16C8: plane 1 holds raw e4m3 bytes
 
 
 def k_multiple(prec) -> int:
@@ -239,14 +236,14 @@ def k_multiple(prec) -> int:
 
 
 def planes(prec) -> int:
-    return 2 if prec_id(prec) in _X3_FAMILY + _F16X3_FAMILY or prec_id(prec) in (PREC_F16C8, PREC_F16C8_QKV16, PREC_F16C8_QK16) else 1
+    return 2 if prec_id(prec) in _X3_FAMILY + _F16X3_FAMILY or prec_id(prec) in (PREC_F16C8, PREC_F16C8_QK16) else 1
 
 
 AUTO_LANES_MIN_VIEWS = 24      # one batch runs as two sub-batch lanes from this many (sample, view) images on (profiles/r4_subbatch_lanes.md)
 
 
 def resolve_lanes(setting, views: int, samples: int, prec=None) -> int:
-    """Sub-batch lanes of one whole-path call (include/boxdreamer_hip.h, ABI v6): `setting` is "auto" or 1..4; `views` = images of
+    """Sub-batch lanes of one whole-path call (include/boxdreamer_hip.h, ABI v6+): `setting` is "auto" or 1..4; `views` = images of
     the call (B x T), `samples` = the units the batch can be cut at.  Bit-identical results for every value.  "auto": two lanes from
     AUTO_LANES_MIN_VIEWS images on, except in the e4m3 class, whose half-batch GEMMs lose more than the filled tail rounds win
     (measured: -2.7 % at batch 64, -4 % at batch 32; 16-bit classes +2 ... +9 %)."""

@@ -82,7 +82,7 @@ class BETR(nn.Module):
         self.box_dim = 8
         self.cat_dim = 3 + 8
         self.hip_precision = kwargs.get("hip_precision", os.environ.get("BOXDREAMER_HIP_PREC", _lib.DEFAULT_PREC))
-        # per-Linear promotion of the F16C8 family to split-bf16 (include/boxdreamer_hip.h: BD_PROMOTE_*): one mask per block and
+        # per-Linear promotion (F16C8 family -> split-f16, e4m3 -> bf16) (include/boxdreamer_hip.h: BD_PROMOTE_*): one mask per block and
         # one for the Linears outside the blocks; all zero until boxdreamer_amd/calibrate.py (or the caller) sets them
         self.hip_lanes = kwargs.get("hip_lanes", "auto")   # sub-batch lanes of one forward ("auto" | 1..4; bit-identical results)
         self.hip_promote = [0] * num_decoder_layers

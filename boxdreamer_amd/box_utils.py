@@ -41,12 +41,17 @@ def solve_poses_host(kp_px: np.ndarray, bbox_3d: np.ndarray, K: np.ndarray, work
     if not pnp._HAVE_CV2:
         # native host solver of the HIP library (csrc/pnp.hip: bd_solve_pnp_host, `workers` threads): the algorithm of
         # pnp.solve_pnp_batched step by step (which stays as its numpy cross-check, tests/test_host_logic.py)
-        lib = _lib.load()
-        kp32, p32, K32 = (np.ascontiguousarray(a, np.float32) for a in (kp_px, bbox_3d, K))
-        rc = lib.bd_solve_pnp_host(kp32.ctypes.data, p32.ctypes.data, K32.ctypes.data, n, kp32.shape[1], 30, out.ctypes.data, workers)
-        if rc != 0:
-            raise _lib.HipLibraryError(f"bd_solve_pnp_host rejected its arguments ({rc})")
-        return out
+        # The PnP post-solve is HOST work (north_star); on a host-only box without the built library (the GPU path itself has raised
+        # long before) or when the native solver rejects its arguments, the batched numpy form below solves the same problem.
+        try:
+            lib = _lib.load()
+            kp32, p32, K32 = (np.ascontiguousarray(a, np.float32) for a in (kp_px, bbox_3d, K))
+            rc = lib.bd_solve_pnp_host(kp32.ctypes.data, p32.ctypes.data, K32.ctypes.data, n, kp32.shape[1], 30, out.ctypes.data, workers)
+            if rc == 0:
+                return out
+            out[:] = 0.0
+        except (_lib.HipLibraryError, OSError):
+            pass
     try:
         ok, R, t = pnp.solve_pnp_batched(bbox_3d, kp_px, K)
     except Exception as e:  # noqa: BLE001  (reference: print and leave zeros, box_utils.py:192-195)

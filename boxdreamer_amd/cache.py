@@ -11,12 +11,22 @@ Usage (caller side):
     data["cached_rgb_feat"], data["cached_rgb_mask"] = cache.place(ref_feats, query_idx, T)
     model(data)                                               # encodes only the views whose mask is False
 Results are bit-identical to the uncached forward (tests/test_gpu_facade.py).
+
+The cached features carry the encoder state they were computed under (operand class + per-Linear promotion state, features.stamp_of).
+The facade's load-time calibration (model.py / calibrate.py) runs inside the FIRST forward and may promote encoder Linears: features cached
+BEFORE that are stale.  `merge_cached_features` notices (stamp mismatch), warns once, and encodes every view of the batch afresh instead --
+never a silent mix of two promotion states, never an exception in the middle of a sweep.  Call `model.calibrate(data)` (or one forward)
+before `cache.encode` to keep the saving.
 """
 from __future__ import annotations
+
+import warnings
 
 import torch
 
 from . import _lib, features
+
+_WARNED_STALE = False
 
 
 def _new_operand(pid: int, n_views: int, P: int, C: int, dtype, dev) -> torch.Tensor:
@@ -69,13 +79,23 @@ class RefFeatureCache:
         full16 = _new_operand(pid, B * T, P, C, f16.dtype, dev)
         for dst, src in zip(_plane_views(full16, pid, B * T, P, C), _plane_views(f16, pid, B * R, P, C)):
             dst.reshape(B, T, P, C)[valid] = src
-        return features.attach(full32, full16, pid), valid
+        return features.attach(full32, full16, pid, features.stamp_of(ref_feats)), valid
 
 
 def merge_cached_features(encoder, images: torch.Tensor, cached: torch.Tensor, valid: torch.Tensor) -> torch.Tensor:
     """Encode only the views with valid == False and write them into (a copy of) the cached layout."""
     B, T = images.shape[:2]
     f16, pid = RefFeatureCache._feats16_view(cached)
+    stamp, now = features.stamp_of(cached), encoder.model.state_stamp(encoder.prec)
+    if stamp is not None and stamp != now:
+        global _WARNED_STALE
+        if not _WARNED_STALE:
+            _WARNED_STALE = True
+            warnings.warn("BoxDreamer HIP path: the cached reference features were encoded under another precision / promotion state of the "
+                          "encoder (the load-time calibration ran, or calibrate.set_state was applied, after RefFeatureCache.encode); "
+                          "encoding every view afresh.  Re-encode the references after the first forward to keep the cache's saving.",
+                          stacklevel=2)
+        return encoder.predict(images)
     miss = ~valid
     new = encoder.predict(images[miss])                       # (n_miss, P, C), tagged
     n16, npid = RefFeatureCache._feats16_view(new)
@@ -88,4 +108,4 @@ def merge_cached_features(encoder, images: torch.Tensor, cached: torch.Tensor, v
     n_miss = int(new.shape[0])
     for dst, src in zip(_plane_views(out16, pid, B * T, P, C), _plane_views(n16, pid, n_miss, P, C)):
         dst.reshape(B, T, P, C)[miss] = src
-    return features.attach(out32, out16, pid)
+    return features.attach(out32, out16, pid, now)

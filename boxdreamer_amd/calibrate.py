@@ -65,6 +65,29 @@ def set_state(encoder, decoder, state: dict) -> None:
     encoder.model.feats_prec = _lib.PREC_F16X3 if decoder.hip_promote_misc & _lib.PROMOTE_ADAPTER_FC1 else 0
 
 
+def has_state(encoder, decoder) -> bool:
+    """True when some Linear is promoted already (a state applied through `set_state` / `load_state`, or an earlier calibration)."""
+    st = get_state(encoder, decoder)
+    return bool(any(st["enc"]) or st["enc_misc"] or any(st["dec"]) or st["dec_misc"])
+
+
+def sync_state_across_ranks(encoder, decoder, src: int = 0) -> bool:
+    """Multi-rank runs (one process per GPU, weights replicated): every rank calibrates on its own first batch, so the promotion sets
+    could differ from rank to rank -- and with them the bits of the result for the same sample.  Rank `src`'s state is broadcast and
+    applied everywhere (a few hundred bytes, once per checkpoint load).  No-op without an initialised process group.  Returns whether
+    this rank's state changed."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return False
+    mine = get_state(encoder, decoder)
+    box = [mine if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    if box[0] == mine:
+        return False
+    set_state(encoder, decoder, box[0])
+    return True
+
+
 def _state_of(units, promoted, n_enc, n_dec) -> dict:
     st = {"enc": [0] * n_enc, "enc_misc": 0, "dec": [0] * n_dec, "dec_misc": 0}
     for (name, where, idx, bits, _), on in zip(units, promoted):
@@ -106,6 +129,9 @@ def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUD
     `budget`, promote the cheapest sufficient set of units.  Returns (and stores in `decoder.hip_calibration`) the report; warns when
     promotion was needed or -- with promote=False -- when the self-check fails.
 
+    promote=True REPLACES whatever promotion state the pair was entered with by the measured one.  promote=False changes nothing: it
+    measures the all-unpromoted mode AND the state the pair was entered with (`delta_entry_state`), and leaves that state in place.
+
     images (B, T, 3, H, W), bbox_feat (B, T, 8, H, W), masks (B, T) bool: as `BETR.forward` / `DinoV2Wrapper.predict` take them."""
     rep = {"mode": str(decoder.hip_precision), "budget": budget, "applicable": applicable(encoder, decoder)}
     if not rep["applicable"]:
@@ -135,6 +161,12 @@ def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUD
         rep.update(delta_unpromoted=d0, samples=n, views=int(images.shape[1]),
                    reference="every Linear split-f16 + split-bf16 attention (bit-identical to f16x3_attn_x3)")
         chosen = [False] * nu
+        if not promote:
+            entry_promoted = any(entry_state["enc"]) or entry_state["enc_misc"] or any(entry_state["dec"]) or entry_state["dec_misc"]
+            if entry_promoted:
+                forwards += 1
+                set_state(encoder, decoder, entry_state)
+                rep["delta_entry_state"] = float((_logits(encoder, decoder, images, bbox_feat, masks) - ref).abs().max())
         if d0 > budget and promote:
             # e[u]: only unit u in the default class
             e = []
@@ -170,7 +202,13 @@ def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUD
             rep.update(delta_final=dfin, unit_errors={units[k][0]: round(e[k], 7) for k in sorted(range(nu), key=lambda k: -e[k])[:12]})
         else:
             rep.update(delta_final=d0)
-        set_state(encoder, decoder, _state_of(units, chosen, n_enc, n_dec))
+        if promote:
+            set_state(encoder, decoder, _state_of(units, chosen, n_enc, n_dec))
+        else:                                                   # measurement only: the pair leaves as it came
+            set_state(encoder, decoder, entry_state)
+            rep["delta_final"] = rep.get("delta_entry_state", d0)
+            cur = get_state(encoder, decoder)
+            chosen = [bool((cur[w] if i is None else cur[w][i]) & bits) for (_, w, i, bits, _) in units]
         rep.update(promoted=[units[k][0] for k in range(nu) if chosen[k]], units=nu, forwards=forwards,
                    promoted_cost_frac=round(sum(units[k][4] for k in range(nu) if chosen[k]) / sum(u[4] for u in units), 4),
                    state=get_state(encoder, decoder), ok=bool(rep["delta_final"] <= budget))
@@ -181,7 +219,7 @@ def calibrate(encoder, decoder, images, bbox_feat, masks, *, budget: float = BUD
         raise
     finally:
         decoder.validate_inputs = validate
-    if d0 > budget:
+    if d0 > budget and (promote or rep["delta_final"] > budget):
         msg = (f"BoxDreamer HIP path: the default precision mode '{decoder.hip_precision}' is {d0:.2e} off the split-f16 reference on the "
                f"heatmap logits of the calibration sample (budget {budget:.1e}); ")
         msg += (f"{len(rep['promoted'])} of {nu} units promoted to split-f16 -> {rep['delta_final']:.2e}" if promote else

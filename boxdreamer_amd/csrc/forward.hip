@@ -18,8 +18,7 @@ struct Carver {
 };
 
 inline int planes_of(int prec) {      // 2-byte units per element of a 16-bit operand buffer (F16C8: f16 plane + e4m3 plane)
-    return (prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_BF16X3_ATTN_F16 ||
-            prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16C8 || prec == BD_PREC_F16C8_QKV16 || prec == BD_PREC_F16C8_QK16 ||
+    return (prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_F16C8 || prec == BD_PREC_F16C8_QK16 ||
             prec == BD_PREC_F16X3 || prec == BD_PREC_F16X3_ATTN_X3) ? 2 : 1;
 }
 
@@ -46,25 +45,22 @@ inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const
 
 #define BD_TRY(expr) do { int rc__ = (expr); if (rc__ != BD_OK) return rc__; } while (0)
 
-// Attention policy of the strict (split-bf16 x3) family.  The three variants are separate `prec` values of the whole-path
+// Attention policy of the strict (split-bf16 x3) family.  The variants are separate `prec` values of the whole-path
 // entry points (no environment switches, no library state):
 //   BD_PREC_BF16X3           GEMMs split-bf16; attention as ONE f16 pass where q and k are RMS-normalised (BETR: the x3 QKV
 //                            GEMM stores q, k, v as a single f16 plane, q/k RMSNorm and attention run in f16, attention writes
 //                            (hi, lo) bf16 planes for the x3 proj GEMM); DINOv2's attention (un-normalised q.k) stays
 //                            split-bf16.  Measured 1.3e-4 on the logits at full depth, T = 6.
 //   BD_PREC_BF16X3_ATTN_X3   split-bf16 attention everywhere (8.2e-5, ~8 % slower)
-//   BD_PREC_BF16X3_ATTN_F16  f16 attention everywhere (1.18e-3: the f16 Q.K^T on DINOv2's un-normalised q/k eats the whole
-//                            1e-3 budget -- kept for measurement, misses the bar)
+// (f16 attention everywhere -- ABI <= 6's BD_PREC_BF16X3_ATTN_F16 -- measured 1.18e-3: the f16 Q.K^T on DINOv2's un-normalised
+// q / k eats the whole budget; removed in ABI 7.)
 inline int gemm_prec(int prec) {
-    if (prec == BD_PREC_F16C8_QKV16 || prec == BD_PREC_F16C8_QK16) return BD_PREC_F16C8;
+    if (prec == BD_PREC_F16C8_QK16) return BD_PREC_F16C8;
     if (prec == BD_PREC_F16X3_ATTN_X3) return BD_PREC_F16X3;
-    return (prec == BD_PREC_BF16X3_ATTN_X3 || prec == BD_PREC_BF16X3_ATTN_F16 || prec == BD_PREC_BF16X3_QKV16) ? BD_PREC_BF16X3 : prec;
+    return prec == BD_PREC_BF16X3_ATTN_X3 ? BD_PREC_BF16X3 : prec;
 }
-inline bool qkv_single_f16(int prec) { return prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16C8_QKV16; }
 inline bool qk_single_f16(int prec) { return prec == BD_PREC_F16C8_QK16; }
-inline bool x3_f16_attention(int prec, bool qk_normed) {
-    return prec == BD_PREC_BF16X3_ATTN_F16 || ((prec == BD_PREC_BF16X3 || prec == BD_PREC_BF16X3_QKV16 || prec == BD_PREC_F16X3) && qk_normed);
-}
+inline bool x3_f16_attention(int prec, bool qk_normed) { return (prec == BD_PREC_BF16X3 || prec == BD_PREC_F16X3) && qk_normed; }
 inline bool split16(int cls) { return cls == BD_PREC_BF16X3 || cls == BD_PREC_F16X3; }
 // operand class of a Linear whose BD_PROMOTE_* bit is set (include/boxdreamer_hip.h): F16C8 family -> split-f16, e4m3 -> bf16
 inline int promoted_class(int base) { return base == BD_PREC_F16C8 ? BD_PREC_F16X3 : (base == BD_PREC_FP8 ? BD_PREC_BF16 : base); }
@@ -76,13 +72,13 @@ inline int handoff_kind(int from, int to) {
     return from == to ? 0 : (to == BD_PREC_BF16 ? 3 /* e4m3 GEMM -> bf16 plane */ : 5 /* F16C8 GEMM -> split-f16 planes */);
 }
 
-// How one transformer block runs: the operand class of each Linear (F16C8 family: per-Linear promotion to split-bf16), the attention
+// How one transformer block runs: the operand class of each Linear (F16C8 family: per-Linear promotion to split-f16; e4m3: to bf16), the attention
 // form, and the 16-bit kinds in which producers hand their results on.
 struct BlockPlan {
     int base;                        // operand class of the un-promoted Linears
     int c_qkv, c_proj, c_fc1, c_fc2; // operand class per Linear
     bool hyb;                        // attention as ONE f16 pass on a single f16 q, k, v plane (q, k RMS-normalised)
-    bool qk16, qkv16;                // BETR's QKV Linear split by column (q, k one f16 pass) / as one f16 pass
+    bool qk16;                       // BETR's QKV Linear split by column (q, k one f16 pass on the f16 plane, v the full F16C8 product)
     int qkv_out;                     // output kind of the QKV GEMM
     int aprec_in;                    // class of the attention input (for the stand-alone q/k RMSNorm)
     int aprec;                       // bd_attention precision code (input form x class of proj's A operand)
@@ -99,7 +95,6 @@ inline BlockPlan plan_block(const bd_block_weights& w, int wprec) {
     p.hyb = (split16(p.base) && x3_f16_attention(wprec, normed)) || (c8 && normed && !(pm & BD_PROMOTE_ATTN));
     const bool plain_qkv = p.c_qkv == p.base;          // the special QKV forms exist for the un-promoted Linear only
     p.qk16 = qk_single_f16(wprec) && p.hyb && w.qkv16.w && plain_qkv;
-    p.qkv16 = qkv_single_f16(wprec) && p.hyb && w.qkv16.w && plain_qkv;
     if (p.hyb) { p.qkv_out = 2; p.aprec_in = BD_PREC_F16; }                                  // one f16 plane
     else if (f8) { p.qkv_out = p.c_qkv == BD_PREC_FP8 ? 3 : 0; p.aprec_in = BD_PREC_BF16; }   // one bf16 plane (an e4m3 or a bf16 GEMM's)
     else if (p.c_qkv == BD_PREC_F16C8 || p.c_qkv == BD_PREC_F16X3) { p.qkv_out = 4; p.aprec_in = BD_PREC_BF16X3; }   // split-bf16 planes for
@@ -140,14 +135,6 @@ int qkv_stage(const bd_block_weights& w, const BlockPlan& p, const BlockBufs& b,
             g.w_plane = (int64_t)3 * D * D;                           // plane 1 still lies one FULL weight plane behind plane 0
             BD_TRY(bd_gemm(&g, BD_PREC_F16C8, stream));
         }
-    } else if (p.qkv16) {
-        // the one Linear that may leave the split scheme: f16 LayerNorm output x f16 weights, one pass, f16 q, k, v out
-        BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, 0, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16, stream));
-        bd_gemm_args g = gemm_args(b.xn, D, 0, w.qkv16, D, 3 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);
-        g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
-        rms_fused = hd == 96 && bd_gemm_fuses_qk_rmsnorm(&g, BD_PREC_F16);
-        if (!rms_fused) g.rms_wq = g.rms_wk = nullptr;
-        BD_TRY(bd_gemm(&g, BD_PREC_F16, stream));
     } else {
         BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, p.c_qkv, stream));
         bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, p.qkv_out, M, D, BD_ACT_NONE);
@@ -257,8 +244,7 @@ DecBufs carve_decoder(const bd_betr_weights* w, int B, int T, int prec, void* ws
 
 inline bool bad_prec(int prec) {
     return prec != BD_PREC_BF16 && prec != BD_PREC_F16 && prec != BD_PREC_BF16X3 && prec != BD_PREC_FP8 &&
-           prec != BD_PREC_BF16X3_ATTN_X3 && prec != BD_PREC_BF16X3_ATTN_F16 && prec != BD_PREC_BF16X3_QKV16 &&
-           prec != BD_PREC_F16C8 && prec != BD_PREC_F16C8_QKV16 && prec != BD_PREC_F16C8_QK16 && prec != BD_PREC_F16X3 &&
+           prec != BD_PREC_BF16X3_ATTN_X3 && prec != BD_PREC_F16C8 && prec != BD_PREC_F16C8_QK16 && prec != BD_PREC_F16X3 &&
            prec != BD_PREC_F16X3_ATTN_X3;
 }
 

@@ -618,7 +618,8 @@ inline int64_t pc192_main_rows(const bd_gemm_args& a, int cus) {
     const int64_t tn = a.N / 192, mt = (a.M + 255) / 256, nt = mt * tn;
     const int64_t k = nt / cus, rem = nt % cus;
     if (k < 1 || k > 4 || rem == 0 || rem * 4 > cus) return a.M;  // the last round is at least a quarter full: leave it
-    return (k * cus / tn) * 256;
+    const int64_t rows = (k * cus / tn) * 256;      // 0 when cus < tn (a CU partition / mask narrower than one row of tiles): no split then
+    return rows > 0 ? rows : a.M;
 }
 
 // the F16C8 class has its own persistent kernel (gemm_f16c8.hip); every shape goes through it

@@ -51,7 +51,7 @@ class DinoV2Encoder:
         self._ws = None
         self._frozen_by = weakref.WeakSet()  # live GraphedPaths that captured raw pointers into _packed / _ws (graph.py)
         depth = 1 + max(int(k.split(".")[1]) for k in self.sd if k.startswith("blocks."))
-        # per-Linear promotion of the F16C8 family to split-bf16 (include/boxdreamer_hip.h: BD_PROMOTE_*), set by calibrate.py
+        # per-Linear promotion (F16C8 family -> split-f16, e4m3 -> bf16) (include/boxdreamer_hip.h: BD_PROMOTE_*), set by calibrate.py
         self.lanes = "auto"          # sub-batch lanes of one predict() call ("auto" | 1..4; bit-identical results, _lib.resolve_lanes)
         self.promote = [0] * depth
         self.promote_misc = 0
@@ -95,6 +95,14 @@ class DinoV2Encoder:
                 self._check_not_frozen("changing the per-Linear promotion")
                 pk.set_promote(self.promote, self.promote_misc, self.feats_prec)
         return pk
+
+    def state_stamp(self, prec=None):
+        """What, beyond the operand class, decides the bits of the features: the per-Linear promotion state (calibrate.py moves Linears
+        between operand classes at load time).  Travels with every feature tensor `predict` returns (features.attach)."""
+        cls = _lib.operand_prec(self.prec if prec is None else prec)
+        if cls not in (_lib.PREC_F16C8, _lib.PREC_FP8):
+            return (cls,)
+        return (cls, tuple(m | _lib.PROMOTE_FC2 if m & _lib.PROMOTE_FC1 else m for m in self.promote), int(self.promote_misc), int(self.feats_prec))
 
     def feats_class(self, prec=None) -> int:
         """Operand class of the 16-bit feature copy `patch_tokens` hands to the decoder."""
@@ -197,4 +205,4 @@ class DinoV2Wrapper(PretrainedModelWrapper):
         with torch.no_grad():
             feats32, feats16 = self.model.patch_tokens(input_tensor, self.prec)
             ret = feats32.view(B, T, *feats32.shape[1:]) if flag else feats32
-            return features.attach(ret, feats16, self.model.feats_class(self.prec))   # explicit hand-off to BETR (features.py)
+            return features.attach(ret, feats16, self.model.feats_class(self.prec), self.model.state_stamp(self.prec))   # explicit hand-off to BETR (features.py)

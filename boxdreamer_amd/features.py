@@ -22,8 +22,10 @@ def _version(t: torch.Tensor):
     return None if t.is_inference() else t._version
 
 
-def attach(feats32: torch.Tensor, feats16: torch.Tensor, pid: int) -> torch.Tensor:
-    setattr(feats32, _ATTR, (feats16, int(pid), feats32.data_ptr(), feats32.numel(), _version(feats32)))
+def attach(feats32: torch.Tensor, feats16: torch.Tensor, pid: int, stamp=None) -> torch.Tensor:
+    """`stamp`: what produced the features beyond the operand class -- the encoder's per-Linear promotion state (calibrate.py): two
+    feature sets of the same class computed under different promotion states are NOT interchangeable (cache.py checks it)."""
+    setattr(feats32, _ATTR, (feats16, int(pid), feats32.data_ptr(), feats32.numel(), _version(feats32), stamp))
     return feats32
 
 
@@ -32,7 +34,7 @@ def operand_of(feats32: torch.Tensor, pid: int):
     tag = getattr(feats32, _ATTR, None)
     if tag is None:
         return None
-    f16, tpid, ptr, numel, version = tag
+    f16, tpid, ptr, numel, version = tag[:5]
     if tpid != int(pid) or ptr != feats32.data_ptr() or numel != feats32.numel() or version != _version(feats32):
         return None
     return f16
@@ -46,9 +48,15 @@ def tag_of(feats32: torch.Tensor):
     return tag[0], tag[1]
 
 
+def stamp_of(feats32: torch.Tensor):
+    """The producer stamp `attach` recorded (None: none recorded / no tag)."""
+    tag = getattr(feats32, _ATTR, None)
+    return tag[5] if tag is not None and len(tag) > 5 else None
+
+
 def carry(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     """Move src's operand copy onto dst when dst aliases exactly the same elements (same storage start, same count)."""
     tag = getattr(src, _ATTR, None)
     if tag is not None and dst is not src and dst.data_ptr() == tag[2] and dst.numel() == tag[3] and dst.is_contiguous():
-        setattr(dst, _ATTR, (tag[0], tag[1], tag[2], tag[3], _version(dst)))
+        setattr(dst, _ATTR, (tag[0], tag[1], tag[2], tag[3], _version(dst), tag[5] if len(tag) > 5 else None))
     return dst

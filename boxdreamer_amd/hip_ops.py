@@ -104,13 +104,15 @@ def from_operand(t: torch.Tensor, prec) -> torch.Tensor:
     return t.float() if planes(prec) == 1 else t[0].float() + t[1].float()
 
 
-_OUT_DTYPES = {2: torch.float16, 3: torch.bfloat16}      # 4: split-bf16 planes [2, rows, N]
+_OUT_DTYPES = {2: torch.float16, 3: torch.bfloat16}      # single planes; 4 / 5: split-bf16 / split-f16 planes [2, rows, N]
+_OUT_SPLIT = {4: torch.bfloat16, 5: torch.float16}
 
 
 def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, addtab=None, out=None,
          out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0), wscale=None, out_mode=None, w_qexp=0, rms=None):
     """out[map(r)] = act(wscale * (A W^T) + bias) + addtab[r % rows(addtab)] + resid[map(r)].
-    out_mode: None -> operand dtype (or fp32 with out_f32), 2 -> f16 single plane, 3 -> bf16 single plane."""
+    out_mode: None -> operand dtype (or fp32 with out_f32), 2 -> f16 single plane, 3 -> bf16 single plane, 4 -> split-bf16 (hi, lo)
+    planes, 5 -> split-f16 (hi, lo) planes (bd_gemm_args.out_f32, include/boxdreamer_hip.h)."""
     lib = _lib.load()
     np_ = planes(prec)
     A2 = a16[0] if np_ == 2 else a16
@@ -124,8 +126,8 @@ def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, add
             out = torch.empty((rows_out, N), dtype=torch.float32, device=A2.device)
         elif mode in _OUT_DTYPES:
             out = torch.empty((rows_out, N), dtype=_OUT_DTYPES[mode], device=A2.device)
-        elif mode == 4:
-            out = torch.empty((2, rows_out, N), dtype=torch.bfloat16, device=A2.device)
+        elif mode in _OUT_SPLIT:
+            out = torch.empty((2, rows_out, N), dtype=_OUT_SPLIT[mode], device=A2.device)
         else:
             out = _alloc16(rows_out, N, prec, A2.device)
     g = _lib.GemmArgs()
@@ -135,9 +137,9 @@ def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, add
     g.wscale = ptr(wscale)
     g.resid, g.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
     g.addtab, g.tab_rows = ptr(addtab), (addtab.shape[0] if addtab is not None else 0)
-    o2 = out[0] if (mode == 4 or (not mode and np_ == 2)) else out
+    o2 = out[0] if (mode in _OUT_SPLIT or (not mode and np_ == 2)) else out
     g.out, g.ldo, g.out_f32 = ptr(out), o2.stride(0), mode
-    g.out_plane = out[0].numel() if mode == 4 else (0 if mode else _plane(out, prec))
+    g.out_plane = out[0].numel() if mode in _OUT_SPLIT else (0 if mode else _plane(out, prec))
     g.w_qexp = int(w_qexp)
     if rms is not None:                      # (wq, wk, eps[, parts]): fused q/k RMSNorm of a QKV Linear ([q | k | v] columns, or [q | k])
         g.rms_wq, g.rms_wk, g.rms_eps = ptr(rms[0]), ptr(rms[1]), float(rms[2])

@@ -96,10 +96,20 @@ class BoxDreamer(nn.Module):
             self._calibrated_for = self.decoder._signature()
             return self.decoder.hip_calibration
         rep = calibrate.calibrate(self.rgb_encoder, self.decoder, images, data["bbox_feat"], mask, promote=self.hip_calibrate)
+        # one process per GPU: every rank measured its own first batch; rank 0's promotion set is the one all ranks run (same bits for
+        # the same sample on every rank)
+        if calibrate.sync_state_across_ranks(self.rgb_encoder, self.decoder):
+            rep = dict(rep, state=calibrate.get_state(self.rgb_encoder, self.decoder), synced_from_rank=0)
+            self.decoder.hip_calibration = rep
         self._calibrated_for = self.decoder._signature()
         if self.hip_promotion_file and self.hip_calibrate and rep.get("applicable"):
             calibrate.save_state(self.hip_promotion_file, self.rgb_encoder, self.decoder, rep)
         return rep
+
+    def mark_calibrated(self) -> None:
+        """Keep the promotion state that is in place (applied through `calibrate.set_state` / `calibrate.load_state`): the first forward
+        will not measure and replace it."""
+        self._calibrated_for = self.decoder._signature()
 
     def _precision_record(self) -> dict:
         rep = self.decoder.hip_calibration or {}
@@ -122,7 +132,10 @@ class BoxDreamer(nn.Module):
         if isinstance(self.decoder, BETR):     # (tests swap the decoder for a stub: nothing to check then)
             if (self._calibrated_for != self.decoder._signature() and images.is_cuda and not torch.cuda.is_current_stream_capturing()
                     and calibrate.applicable(self.rgb_encoder, self.decoder)):
-                self.calibrate(data)
+                if self._calibrated_for is None and calibrate.has_state(self.rgb_encoder, self.decoder):
+                    self.mark_calibrated()       # a state the caller applied before the first forward is kept, not measured over
+                else:
+                    self.calibrate(data)
             data["hip_precision"] = self._precision_record()
             # sub-batch lanes this batch runs as (bit-identical for every value; `hip_lanes` in the decoder / encoder cfg, default "auto")
             data["hip_precision"]["sub_batch_lanes"] = _lib.resolve_lanes(self.decoder.hip_lanes, B * T, B, self.decoder.hip_precision)

@@ -162,7 +162,7 @@ class Packed:
         return self._cache[key]
 
     def set_promote(self, masks=None, misc: int = 0, feats_prec: int = 0) -> None:
-        """Write the per-Linear operand classes into the struct: bit set -> that Linear's weight in split-bf16 planes."""
+        """Write the per-Linear operand classes into the struct: bit set -> that Linear's weight in the promoted class's layout (F16C8 family: split-f16 planes; e4m3: bf16)."""
         depth = len(self.block_names)
         masks = [0] * depth if masks is None else [int(m) for m in masks]
         if len(masks) != depth:
@@ -215,7 +215,7 @@ def _pack_block(pk: Packed, sd: dict, p: str, prec, device, ls: bool, qk_norm: b
     if qk_norm:
         bw.q_norm_w = pk.keep(sd[p + "attn.q_norm.weight"].float(), device)
         bw.k_norm_w = pk.keep(sd[p + "attn.k_norm.weight"].float(), device)
-        if _lib.prec_id(prec) in (_lib.PREC_BF16X3, _lib.PREC_F16C8):   # f16 single-plane copy for the *_QKV16 modes (3.5 MB per block)
+        if _lib.prec_id(prec) == _lib.PREC_F16C8:   # f16 single-plane copy whose q, k rows BD_PREC_F16C8_QK16 reads (3.5 MB per block)
             bw.qkv16 = pk.linear(pack_linear_weight(sd[p + "attn.qkv.weight"], "fp16"), pack_bias(sd[p + "attn.qkv.bias"]), device)
     return bw
 

@@ -104,7 +104,7 @@ def test_workload_label_names_the_config_actually_run():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     assert m.workload_name(32, 6, "bf16", 1, False).startswith("configs[1]:")
-    assert m.workload_name(32, 6, "f16c8_qkv16", 8, False).startswith("configs[1]:")
+    assert m.workload_name(32, 6, "f16c8_qk16", 8, False).startswith("configs[1]:")
     assert m.workload_name(32, 17, "bf16", 8, False).startswith("configs[3]:")
     assert m.workload_name(32, 17, "bf16", 1, False).startswith("configs[3] shape")
     assert m.workload_name(64, 6, "fp8", 1, False).startswith("configs[4]:")
@@ -112,7 +112,7 @@ def test_workload_label_names_the_config_actually_run():
     assert m.workload_name(32, 6, "bf16", 1, True).startswith("SURVEY 8f1")
     # algorithmic GEMM bytes: 101 bd_gemm calls per step at T = 6, ~0.4 GB per call in bf16, more in the strict classes
     b16, calls = m.algorithmic_gemm_bytes("bf16", 32, 6)
-    bs, _ = m.algorithmic_gemm_bytes("f16c8_qkv16", 32, 6)
+    bs, _ = m.algorithmic_gemm_bytes("f16c8", 32, 6)
     assert calls == 101 and m.algorithmic_gemm_bytes("f16c8_qk16", 32, 6)[1] == 113 and 3.5e8 < b16 / calls < 4.5e8 and b16 < bs < 2 * b16
 
 
@@ -133,6 +133,11 @@ def test_two_rank_flow_with_the_real_kernels_on_one_gpu():
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and j["config"]["parallelism"] == "dp2"
     assert len(j["per_rank_ms_per_step"]) == 2 and j["corner_allgather_ms"] > 0 and j["value"] > 0
     assert j["config"]["workload"].startswith("configs[1]:")
+    # the same command emits BASELINE configs[3]'s per-GPU shard next to the weak-scaled configs[1] value
+    c3 = j["config3"]
+    assert c3["views"] == 17 and c3["global_batch"] == 64 and c3["value"] > 0 and len(c3["per_rank_ms_per_step"]) == 2
+    assert c3["workload"].startswith("configs[3] shape") and j["config"]["config3_value"] == c3["value"]
+    assert j["distributed"]["world_size_seen_by_the_collective"] == 2
 
 
 @pytest.mark.gpu
@@ -147,6 +152,67 @@ def test_rank_failure_on_the_gpu_box_is_reported():
     assert r.returncode != 0
     j = _one_line(r)
     assert j["n_gpus"] == 2 and j["value"] is None and "error" in j
+
+
+def test_counter_passes_attribute_only_the_marked_steps(tmp_path, monkeypatch):
+    """bench.py's in-run counter measurement: one child process runs several modes, each mode's measured steps
+    bracketed by a marker kernel; the parser must attribute exactly those dispatches (not packing / calibration / warm-up) to the
+    mode, per kernel class, and apply the gfx950 FETCH_SIZE correction.  Fed with a synthetic rocprofv3 CSV (no GPU)."""
+    import csv
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    steps = 2
+
+    def fake_pass(group, child, timeout_s=600):
+        assert "--counter-child" in child and child[child.index("--counter-child") + 1] == "bf16,f16c8_qk16"
+        path = tmp_path / ("_".join(group) + ".csv")
+        rows, did = [], 0
+
+        def disp(name, values, dur=1000):
+            nonlocal did
+            did += 1
+            for c in group:
+                rows.append({"Dispatch_Id": did, "Kernel_Name": name, "Counter_Name": c, "Counter_Value": values.get(c, 0.0),
+                             "Start_Timestamp": did * 10000, "End_Timestamp": did * 10000 + dur})
+        for mode_scale in (1.0, 2.0):                              # two modes: the second moves twice the bytes
+            disp("void at::native::pack_kernel", {"FETCH_SIZE": 999, "WRITE_SIZE": 999})             # load-time packing: not counted
+            disp("gemm_kernel_pc<warmup>", {"FETCH_SIZE": 777, "SQ_VALU_MFMA_BUSY_CYCLES": 5e5, "SQ_BUSY_CYCLES": 1e3})   # warm-up: not counted
+            disp("void at::native::erfinv_kernel", {})
+            for _ in range(steps):
+                disp("gemm_kernel_pc<x>", {"FETCH_SIZE": 100 * mode_scale, "WRITE_SIZE": 50 * mode_scale,
+                                           "SQ_VALU_MFMA_BUSY_CYCLES": 512.0 * 1024, "SQ_BUSY_CYCLES": 32.0 * 1024}, dur=2000)
+                disp("attn_kernel<y>", {"FETCH_SIZE": 10, "WRITE_SIZE": 5, "SQ_VALU_MFMA_BUSY_CYCLES": 256.0 * 1024, "SQ_BUSY_CYCLES": 32.0 * 1024})
+                disp("decode_kernel<true>", {})
+            disp("void at::native::erfinv_kernel", {})
+        with open(path, "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0]))
+            w.writeheader(); w.writerows(rows)
+        return str(path)
+
+    monkeypatch.setattr(b, "_rocprof_pass", fake_pass)
+    res = b.collect_counters(["bf16", "f16c8_qk16"], 32, 6, b.BASIC_GROUPS, steps=steps)
+    g1, g2 = res["bf16"]["per_kernel_class"]["gemm"], res["f16c8_qk16"]["per_kernel_class"]["gemm"]
+    assert g1["launches_per_step"] == 1 and g1["fetch_bytes_per_step"] == 2 * 100 * 1024 and g1["write_bytes_per_step"] == 50 * 1024
+    assert g2["fetch_bytes_per_step"] == 2 * g1["fetch_bytes_per_step"]
+    assert g1["mfma_busy"] == 0.5 and res["bf16"]["per_kernel_class"]["attention"]["mfma_busy"] == 0.25
+    assert g1["ms_per_step"] == 0.002 and "harness (one-off torch / runtime kernels: weight packing, uploads)" not in res["bf16"]["per_kernel_class"]
+    calls = res["bf16"]["gemm_calls_per_step"]
+    assert res["bf16"]["gemm_hbm_bytes_per_call"] == round((2 * 100 + 50) * 1024 / calls)
+    # a roofline block takes the figures over and says where they came from
+    rf = {"traffic": None, "mfma_busy": None}
+    res["bf16"]["measured_in_this_run"] = True
+    b.apply_counters(rf, res["bf16"])
+    assert rf["counters_measured_in_this_run"] is True and rf["mfma_busy_gemm"] == 0.5 and rf["traffic_source"].startswith("measured in THIS run")
+    # a child that dies between the markers must not yield half a measurement
+    def broken(group, child, timeout_s=600):
+        p = fake_pass(group, child)
+        lines = open(p).read().splitlines()
+        open(p, "w").write("\n".join(lines[: len(lines) // 2]) + "\n")
+        return p
+    monkeypatch.setattr(b, "_rocprof_pass", broken)
+    with pytest.raises(RuntimeError):
+        b.collect_counters(["bf16", "f16c8_qk16"], 32, 6, b.BASIC_GROUPS, steps=steps)
 
 
 def test_power_probe_degrades_without_a_card():

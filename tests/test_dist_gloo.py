@@ -29,6 +29,16 @@ def _worker(rank, world, port, n_total):
         marker = mine["bbox_proj_crop"][:, 0].contiguous()                 # (B_local, 8, 2)
         allm = gather_corners(marker, world)
         assert torch.equal(allm, data["bbox_proj_crop"][:, 0])
+        # the per-Linear promotion state is rank 0's on every rank (each rank calibrates on its own first batch): stub modules,
+        # host logic only
+        from types import SimpleNamespace
+        from boxdreamer_amd import calibrate
+        enc = SimpleNamespace(model=SimpleNamespace(promote=[0, rank * 3], promote_misc=rank, feats_prec=0))
+        dec = SimpleNamespace(hip_promote=[rank * 5, 2], hip_promote_misc=0)
+        changed = calibrate.sync_state_across_ranks(enc, dec)
+        assert changed == (rank != 0)
+        assert calibrate.get_state(enc, dec) == {"enc": [0, 0], "enc_misc": 0, "dec": [0, 2], "dec_misc": 0}
+        assert calibrate.has_state(enc, dec)
     finally:
         dist.destroy_process_group()
 

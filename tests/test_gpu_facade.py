@@ -25,18 +25,16 @@ def _config(prec, depth=2):
 
 
 def _config_with(prec, depth=2):
-    return {"modules": {
-        "use_keypoints": False, "use_matching": False, "use_tracking": False, "use_rgb": True, "use_pp": True,
-        "ref_type": "all", "regression_intri": True, "rotation_type": None, "coordinate": "object",
-        "pose_representation": "bb8", "bbox_representation": "heatmap", "patchify_rays": True, "stage": "decoder_only",
-        "dense_cfg": {"enable": False},
-        "decoder": {"d_model": 768, "nhead": 8, "num_decoder_layers": depth, "camera_emb": "MLP", "track_emb": None,
-                    "match_emb": None, "decoder_only": True, "patch_size": 14, "img_size": 224, "diff_emb": False,
-                    "nvs_supervision": False, "ray_supervision": True, "use_mask": False, "hip_precision": prec},
-        "encoder": {"name": "dino", "dino": {"ckpt_path": None, "cfg": {"model_type": "dinov2_vitb14_reg", "freeze": True,
-                                                                        "synthetic_seed": 4321, "depth": depth,
-                                                                        "hip_precision": prec}}},
-    }}
+    """The constructor's `config`: the reference's OWN YAML resolved to data (tests/golden/model_modules_config.json, written by
+    oracle/make_model_config.py from configs/model/transformer.yaml:10-71 + configs/test.yaml:8-24 -- not a hand-typed dict), with the
+    three things a test must add on top: the layer count of the reduced-depth cases, seeded synthetic DINOv2 weights in place of the hub
+    download, and the HIP precision mode."""
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_modules_config.json")
+    mods = copy.deepcopy(json.load(open(path))["modules"])
+    mods["decoder"].update(num_decoder_layers=depth, hip_precision=prec)
+    mods["encoder"]["dino"]["cfg"].update(synthetic_seed=4321, depth=depth, hip_precision=prec)
+    return {"modules": mods}
 
 
 @pytest.mark.parametrize("prec", [None, "bf16x3"])
@@ -102,7 +100,7 @@ def test_unsupported_configs_raise():
 def test_reference_feature_cache_is_bit_identical(hip):
     """"next" row f1: encoding the references once and only the query per pose gives the same bits."""
     from boxdreamer_amd.cache import RefFeatureCache
-    for prec in ("bf16", "bf16x3", "f16c8_qk16", "f16c8_qkv16", "f16c8"):
+    for prec in ("bf16", "bf16x3", "f16c8_qk16", "f16c8"):
         model = BoxDreamer(_config(prec))
         model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
         model = model.cuda().eval()
@@ -142,6 +140,39 @@ def test_reference_feature_cache_is_bit_identical(hip):
     d2["cached_rgb_feat"], d2["cached_rgb_mask"] = cache.place(feats, dev["query_idx"], T)
     model(d2)
     assert torch.equal(model.decoder.last_logits, logits_ref) and model.decoder.recast_count == 0
+    # the documented flow encodes the references BEFORE the first forward -- i.e. before the load-time calibration may
+    # have promoted ENCODER Linears while the adapter (and with it the features' operand class) stays as it was.  Such features are stale
+    # in a way the operand class cannot show; the producer stamp on the tag does: the forward warns once and encodes every view afresh,
+    # bit-identical to the uncached forward, instead of silently mixing two promotion states.
+    import warnings
+    from boxdreamer_amd import cache as cache_mod
+    model = BoxDreamer(_config("f16c8_qk16"))
+    model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
+    model = model.cuda().eval()
+    cache = RefFeatureCache(model.rgb_encoder)
+    stale = cache.encode(dev["images"][~ref["camera_mask"]].reshape(B, T - 1, 3, 224, 224))      # un-promoted encoder
+    st = calibrate.get_state(model.rgb_encoder, model.decoder)
+    st["enc"][0] = _lib.PROMOTE_QKV | _lib.PROMOTE_FC1 | _lib.PROMOTE_FC2                          # what a calibration may find necessary
+    calibrate.set_state(model.rgb_encoder, model.decoder, st)
+    model._calibrated_for = model.decoder._signature()
+    want = model(dict(dev))
+    logits_want = model.decoder.last_logits.clone()
+    d3 = dict(dev)
+    d3["cached_rgb_feat"], d3["cached_rgb_mask"] = cache.place(stale, dev["query_idx"], T)
+    cache_mod._WARNED_STALE = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = model(d3)
+    assert any("encoding every view afresh" in str(x.message) for x in w)
+    assert torch.equal(model.decoder.last_logits, logits_want) and torch.equal(got["pred_bbox"], want["pred_bbox"])
+    fresh = cache.encode(dev["images"][~ref["camera_mask"]].reshape(B, T - 1, 3, 224, 224))      # re-encoded under the new state: cached path again
+    d4 = dict(dev)
+    d4["cached_rgb_feat"], d4["cached_rgb_mask"] = cache.place(fresh, dev["query_idx"], T)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        model(d4)
+    assert not any("encoding every view afresh" in str(x.message) for x in w)
+    assert torch.equal(model.decoder.last_logits, logits_want)
 
 
 def test_hip_graph_replay_matches_eager(hip):
@@ -468,6 +499,22 @@ def test_facade_self_check_and_promotion_on_trained_like_weights(hip):
         out2 = model2(dev())
     assert any("promotion is disabled" in str(x.message) for x in w2)
     assert out2["hip_precision"]["self_check_ok"] is False and out2["hip_precision"]["promoted_units"] == 0
+    # a promotion state the caller applied is neither measured over by the first forward nor wiped by a measuring-only
+    # calibration -- the measured state of `model` moved to a fresh facade keeps its bits and its error
+    from boxdreamer_amd import calibrate
+    good = calibrate.get_state(model.rgb_encoder, model.decoder)
+    model3 = _facade_with(bsd, dsd, depth)
+    calibrate.set_state(model3.rgb_encoder, model3.decoder, good)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")              # no calibration, hence no "promoted N units" warning
+        model3(dev())
+    assert calibrate.get_state(model3.rgb_encoder, model3.decoder) == good and torch.equal(model3.decoder.last_logits, lg)
+    model4 = _facade_with(bsd, dsd, depth, hip_calibrate=False)
+    calibrate.set_state(model4.rgb_encoder, model4.decoder, good)
+    model4._calibrated_for = None
+    rep4 = model4.calibrate(dev())                   # measuring only: reports the applied state's error and leaves it in place
+    assert calibrate.get_state(model4.rgb_encoder, model4.decoder) == good
+    assert rep4["delta_unpromoted"] > 4e-4 and rep4["delta_entry_state"] <= 4e-4 and rep4["ok"] and len(rep4["promoted"]) == rec["promoted_units"]
     # an explicit mode outside the F16C8 family is recorded as such and not touched
     cfg = _config("bf16", 2)
     m3 = BoxDreamer(cfg).cuda().eval()

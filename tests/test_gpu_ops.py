@@ -82,6 +82,13 @@ def test_gemm_f16c8(hip, M, N, K):
         assert (o.float().cpu() - ref.float()).abs().max().item() < 2.0 ** -10 * max(1.0, ref.abs().max().item())
         o = hip_ops.gemm(a16, w16, b.cuda(), prec="f16c8", out_mode=4, w_qexp=e)                 # split-bf16 planes
         assert ((o[0].float() + o[1].float()).cpu() - ref.float()).abs().max().item() < 2.0 ** -15 * max(1.0, ref.abs().max().item()) + 2e-5 * K ** 0.5
+        # kind 5: split-f16 planes (an F16C8 Linear feeding a PROMOTED one; ADVICE r4: the wrapper used to lay this kind out wrongly and
+        # no op-level test covered it) -- plain and with GELU (the fc1 -> promoted fc2 hand-off), hi / lo consistent (lo = f16(x - hi))
+        for act, want in ((_lib.ACT_NONE, ref.float()), (_lib.ACT_GELU, g)):
+            o = hip_ops.gemm(a16, w16, b.cuda(), prec="f16c8", out_mode=5, act=act, w_qexp=e)
+            assert o.dtype == torch.float16 and tuple(o.shape) == (2, M, N)
+            assert ((o[0].float() + o[1].float()).cpu() - want).abs().max().item() < 2.0 ** -20 * max(1.0, want.abs().max().item()) + 2e-5 * K ** 0.5
+            assert (o[1].float().abs() <= o[0].float().abs() * 2.0 ** -10 + 2.0 ** -24).all()
 
 
 @pytest.mark.parametrize("prec", PRECS_LIN + ["fp8"])
@@ -652,6 +659,9 @@ def test_gemm_fp8(hip, M, N, K):
         g = F.gelu(ref.float())
         assert o8.dtype == torch.float8_e4m3fn
         assert (o8.float().cpu() - g).abs().max().item() <= 2.0 ** -4 * g.abs().max().item() + 2.0 ** -9
+        # kind 3 WITH GELU: an e4m3 fc1 feeding a PROMOTED (bf16) fc2 -- the hand-off of the mixed e4m3 policy
+        og = hip_ops.gemm(a8, w8.cuda(), b.cuda(), prec="fp8", wscale=sc.cuda(), act=1, out_mode=3)
+        assert og.dtype == torch.bfloat16 and (og.float().cpu() - g).abs().max().item() <= 2.0 ** -8 * g.abs().max().item() + 1e-3
 
 
 def test_layernorm_and_layout_fp8(hip):

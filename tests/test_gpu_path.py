@@ -23,10 +23,25 @@ from boxdreamer_amd.encoder import DinoV2Wrapper
 from oracle import boxdreamer_oracle as orc
 
 pytestmark = pytest.mark.gpu
-LOGIT_TOL = {"f16x3": 1e-3, "f16x3_attn_x3": 1e-3, "f16c8_qk16": 1e-3, "f16c8_qkv16": 1e-3, "f16c8": 1e-3, "bf16x3_qkv16": 1e-3, "bf16x3": 1e-3, "bf16x3_attn_x3": 1e-3, "fp16": 2.5e-2, "bf16": 1e-1}
-FEAT_TOL = {"f16x3": 1e-3, "f16x3_attn_x3": 1e-3, "f16c8_qk16": 1e-3, "f16c8_qkv16": 1e-3, "f16c8": 1e-3, "bf16x3_qkv16": 1e-3, "bf16x3": 1e-3, "bf16x3_attn_x3": 1e-3, "fp16": 2.5e-2, "bf16": 1e-1}
-STRICT = ("f16x3", "f16x3_attn_x3", "f16c8_qk16", "f16c8_qkv16", "f16c8", "bf16x3_qkv16", "bf16x3", "bf16x3_attn_x3")
+LOGIT_TOL = {"f16x3": 1e-3, "f16x3_attn_x3": 1e-3, "f16c8_qk16": 1e-3, "f16c8": 1e-3, "bf16x3": 1e-3, "bf16x3_attn_x3": 1e-3, "fp16": 2.5e-2, "bf16": 1e-1}
+FEAT_TOL = {"f16x3": 1e-3, "f16x3_attn_x3": 1e-3, "f16c8_qk16": 1e-3, "f16c8": 1e-3, "bf16x3": 1e-3, "bf16x3_attn_x3": 1e-3, "fp16": 2.5e-2, "bf16": 1e-1}
+STRICT = ("f16x3", "f16x3_attn_x3", "f16c8_qk16", "f16c8", "bf16x3", "bf16x3_attn_x3")
 REPORT = {}
+
+
+def assert_identical_topk_sets(idx, o, err, tag):
+    """north_star: "identical argmax corner indices" (the reference decodes the top-20 SET of every corner map, box_utils.py:87-95).
+    Every map's set must equal the oracle's.  The one computed exemption: a map where the ORACLE's own 20th and 21st logits are
+    closer than 2 x the measured logit error of this run -- there the reference's choice is itself decided below the error any
+    finite-precision forward carries (random-weight heatmaps are noise: such near-ties exist).  The gap is printed.  Returns the
+    fraction of identical maps."""
+    eq = (idx.sort(-1)[0] == o["topk_idx"].sort(-1)[0]).all(-1)            # (B, 8)
+    for b, c in (~eq).nonzero().tolist():
+        top = o["logits"][b, c].flatten().topk(21)[0]
+        gap = (top[19] - top[20]).item()
+        print(f"[{tag}] sample {b} corner {c}: top-20 set differs; the oracle's 20th / 21st logits are {gap:.3e} apart (this run's logit error: {err:.3e})")
+        assert gap <= 2.0 * err, (tag, b, c, gap, err)
+    return eq.float().mean().item()
 
 
 def _build(prec, dino_depth, betr_depth):
@@ -63,7 +78,7 @@ def _oracle(data, dino_depth, betr_depth):
     return _ORACLE[key]
 
 
-@pytest.mark.parametrize("prec", ["f16c8_qk16", "f16c8_qkv16", "f16c8", "f16x3", "f16x3_attn_x3", "bf16x3_qkv16", "bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["f16c8_qk16", "f16c8", "f16x3", "f16x3_attn_x3", "bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("case", ["tiny_d2_T2", "tiny_d2_T3_B2", "full_T2", "full_T6"])
 def test_path_vs_oracle_and_golden(hip, golden_dir, prec, case):
     g = np.load(os.path.join(golden_dir, f"case_{case}.npz"))
@@ -90,17 +105,18 @@ def test_path_vs_oracle_and_golden(hip, golden_dir, prec, case):
     assert e_gold <= LOGIT_TOL[prec] + 1e-4, e_gold
     assert e_gold_feat <= FEAT_TOL[prec] + 1e-4
     if prec in STRICT:
-        # a swapped index moves a corner by <= 224/20 px; sets are expected identical up to fp32-level near-ties
-        assert same >= 0.9 and e_kp <= 224 / 20 * 2, (same, e_kp)
+        # identical top-20 index sets (computed exemption for oracle near-ties only); a swapped index moves a corner by <= 224/20 px
+        assert_identical_topk_sets(idx, o, e_logit, f"{case} {prec}")
+        assert e_kp <= 224 / 20 * 2, (same, e_kp)
         gk = np.abs(kp.numpy() - g["corners_px"]).max()
         assert gk <= 224 / 20 * 2
 
 
-@pytest.mark.parametrize("prec,tol", [("bf16x3_attn_x3", 1e-3), ("bf16x3_attn_f16", 5e-3)])
+@pytest.mark.parametrize("prec,tol", [("bf16x3_attn_x3", 1e-3)])
 def test_strict_attention_policies_full_T6(hip, golden_dir, prec, tol):
     """The attention policies of the strict family are `prec` values of the whole-path entry points (they used to be an
-    environment switch inside the library): split-bf16 attention everywhere meets the 1e-3 bar with the largest margin;
-    f16 attention everywhere does NOT (f16 Q.K^T on DINOv2's un-normalised q/k: ~1.2e-3) and is bounded at 5e-3 only."""
+    environment switch inside the library): split-bf16 attention everywhere meets the 1e-3 bar with the largest margin.
+    (f16 attention everywhere -- ABI <= 6's bf16x3_attn_f16 -- measured ~1.2e-3 and was removed in ABI 7.)"""
     g = np.load(os.path.join(golden_dir, "case_full_T6.npz"))
     meta = json.loads(str(g["meta"]))
     data, feats, logits, heat, kp, kn, idx = _run(prec, meta["B"], meta["T"], meta["dino_depth"], meta["betr_depth"],
@@ -111,7 +127,7 @@ def test_strict_attention_policies_full_T6(hip, golden_dir, prec, tol):
     assert e_gold <= tol, e_gold
 
 
-@pytest.mark.parametrize("prec", ["f16c8_qk16", "f16c8_qkv16", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f16c8_qk16", "bf16x3"])
 def test_views17_reduced_depth(hip, prec):
     """BASELINE configs[3] shape: 1 query + 16 references (T = 17, one BETR sequence of 4352 tokens = 68 key tiles per
     attention row block) at reduced depth (2 + 2 layers, so the CPU oracle finishes in seconds), in the default (strict) mode and
@@ -128,7 +144,8 @@ def test_views17_reduced_depth(hip, prec):
     err = (dec.last_logits.cpu() - o["logits"]).abs().max().item()
     same = (idx.cpu().long().sort(-1)[0] == o["topk_idx"].sort(-1)[0]).all(-1).float().mean().item()
     print(f"[T17 d2 {prec}] logits err {err:.3e} top-20 sets equal {same:.2f}")
-    assert err <= 1e-3 and same >= 0.9
+    assert err <= 1e-3
+    assert_identical_topk_sets(idx.cpu().long(), o, err, f"T17 d2 {prec}")
     assert dec.recast_count == 0          # the operand copy of the features arrived through features.attach
 
 
@@ -150,7 +167,8 @@ def test_views17_full_depth_default_mode(hip):
     same = (idx.cpu().long().sort(-1)[0] == o["topk_idx"].sort(-1)[0]).all(-1).float().mean().item()
     print(f"[T17 full depth {prec}] logits err {err:.3e} top-20 sets equal {same:.2f}")
     REPORT[f"full_T17/{prec}"] = dict(logits=err, top20_sets_equal=same)
-    assert err <= 1e-3 and same >= 0.87          # (one of 8 maps may differ at an oracle near-tie)
+    assert err <= 1e-3
+    assert_identical_topk_sets(idx.cpu().long(), o, err, f"T17 full depth {prec}")
 
 
 @pytest.mark.parametrize("in_dtype", [torch.bfloat16, torch.float16])
@@ -296,7 +314,7 @@ def _run_full(enc, dec, img, bf, qpos):
     return dec.last_logits.clone(), heat.clone(), kp.clone(), idx.clone().long()
 
 
-@pytest.mark.parametrize("prec", ["f16c8_qk16", "f16c8_qkv16", "bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["f16c8_qk16", "bf16x3", "bf16"])
 def test_full_size_properties(hip, prec):
     """The oracle cannot run B=32 x full depth in seconds, so the full-size step is checked through properties that do not
     depend on size:
@@ -434,12 +452,12 @@ def _margin_oracle(ws_b, ws_d, datas, bsd, dsd):
     return _MARGIN_ORACLE[key]
 
 
-@pytest.mark.parametrize("prec", ["f16c8_qk16", "f16c8_qkv16"])
+@pytest.mark.parametrize("prec", ["f16c8_qk16"])
 def test_strict_mode_margin_over_seeds(hip, prec):
     """the strict mode's distance to the 1e-3 bar on MORE than a handful of seeds -- 8 input seeds x 2 weight
     seeds at FULL depth, T = 6, each pose against the fp32 CPU oracle (~1 s each).  Every pose must meet the bar with identical
-    top-20 sets; the distribution goes to gpurun_out/strict_margin_<mode>.json (and from there to profiles/).  Both the default
-    mode (f16c8_qk16) and round 2's (f16c8_qkv16: thinner margin) are recorded."""
+    top-20 sets; the distribution goes to gpurun_out/strict_margin_<mode>.json (and from there to profiles/).  The bound asserted is
+    5e-4 -- half the bar ("<= 5e-4 on the 16-pose margin test")."""
     errs, sets_equal, near_ties = [], [], []
     for ws_b, ws_d in MARGIN_WEIGHT_SEEDS:
         enc = DinoV2Wrapper(None, {"model_type": "dinov2_vitb14_reg", "synthetic_seed": ws_d, "depth": 12, "hip_precision": prec})
@@ -482,8 +500,8 @@ def test_strict_mode_margin_over_seeds(hip, prec):
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/strict_margin_{prec}.json", "w") as f:
         json.dump(rep, f, indent=1)
-    assert max(errs) <= 1e-3, errs
-    assert sum(sets_equal) >= len(sets_equal) - 2, sets_equal          # (each exception was checked to be an oracle near-tie above)
+    assert max(errs) <= 5e-4, errs
+    # every differing set was checked above to sit at an oracle near-tie (gap <= 2 x that pose's error); anything else failed there
 
 
 # ---------------------------------------------------------------- operand-range robustness
@@ -505,7 +523,7 @@ def _run_with(prec, bsd, dsd, data, depth):
     return feats.cpu(), dec.last_logits.cpu(), idx.cpu().long()
 
 
-@pytest.mark.parametrize("prec", ["f16c8_qk16", "f16c8_qkv16", "f16c8", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f16c8_qk16", "f16c8", "bf16x3"])
 @pytest.mark.parametrize("case", ["full_T2", "full_T6"])
 def test_range_stress_function_preserving_rescale(hip, golden_dir, prec, case):
     """Every range limit of the strict operand classes, with the network's FUNCTION unchanged (synth.rescale_function_preserving:

@@ -47,7 +47,7 @@ def _logits(enc, dec, img, bf, mask):
     return dec.last_logits.clone()
 
 
-@pytest.mark.parametrize("base", ["f16c8_qk16", "f16c8_qkv16", "f16c8"])
+@pytest.mark.parametrize("base", ["f16c8_qk16", "f16c8"])
 @pytest.mark.parametrize("dd,bd,T", [(2, 2, 3), (12, 12, 2)])
 def test_all_promoted_is_bit_identical_to_f16x3_attn_x3(hip, base, dd, bd, T):
     _, img, bf, mask = _inputs(7, 2, T)
