@@ -171,6 +171,37 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (x > 0.f ? 2.0f - erfc_abs : erfc_abs);
 }
 
+// The same arithmetic for TWO elements per instruction where the VALU has a packed fp32 form (v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32: IEEE results, bit-identical to the scalar instructions): 18 regular + 4 quarter-rate instructions per pair instead of
+// 2 x (16 + 2).  The strict classes' fc1 epilogue spends ~9k of its ~12k VALU cycles per wave and tile in gelu_erf (round 5:
+// profiles/r5_gelu_packed.md); every operation below is the scalar form's, in the scalar form's order, so gelu_erf2(x).x == gelu_erf(x.x).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+#pragma clang fp contract(off)
+    auto c2 = [](float c) { return (f32x2){c, c}; };
+    f32x2 z;
+    z.x = fabsf(x.x) * 0.70710678118654752f;
+    z.y = fabsf(x.y) * 0.70710678118654752f;
+    const f32x2 d = __builtin_elementwise_fma(c2(0.3275911f), z, c2(1.0f));
+    f32x2 t;
+    t.x = __builtin_amdgcn_rcpf(d.x);
+    t.y = __builtin_amdgcn_rcpf(d.y);
+    f32x2 poly = __builtin_elementwise_fma(t, c2(1.061405429f), c2(-1.453152027f));
+    poly = __builtin_elementwise_fma(t, poly, c2(1.421413741f));
+    poly = __builtin_elementwise_fma(t, poly, c2(-0.284496736f));
+    poly = __builtin_elementwise_fma(t, poly, c2(0.254829592f));
+    const f32x2 a = (-z * z) * c2(1.4426950408889634f);
+    f32x2 ex;
+    ex.x = __builtin_amdgcn_exp2f(a.x);
+    ex.y = __builtin_amdgcn_exp2f(a.y);
+    const f32x2 erfc_abs = (poly * t) * ex;
+    const f32x2 two_minus = c2(2.0f) - erfc_abs;
+    f32x2 sel;
+    sel.x = x.x > 0.f ? two_minus.x : erfc_abs.x;
+    sel.y = x.y > 0.f ? two_minus.y : erfc_abs.y;
+    return (c2(0.5f) * x) * sel;
+}
+
 // GELU for results that are about to be rounded to 16 (or 8) bits:  x * Phi(x)  with  Phi(x) ~ 1 / (1 + 2^(-x p(x^2))),
 // p minimax-fitted against the exact erf form on [-9, 9] (tools/fit_gelu.py): |abs err| <= 5.4e-5, below half an ulp of
 // bf16 for |gelu| > 0.03 and of f16 for |gelu| > 0.2.  7 VALU + v_exp + v_rcp per element against 15 + 2 for the erfc
@@ -189,7 +220,6 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // |abs err| <= 1.6e-4 in fp32 arithmetic = half a bf16 ulp at |gelu| = 0.08.  v_exp_f32 / v_rcp_f32 issue at quarter
 // rate, so gelu_fast spends most of its time in them; this form is ~2x cheaper.  fp16 results keep gelu_fast (an f16 ulp
 // is 8x finer), fp32 / split-bf16 results keep gelu_erf.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
 #pragma clang fp contract(off)
     f32x2 xc;
@@ -212,6 +242,12 @@ template <int KIND, int N> __device__ __forceinline__ void gelu_n(float (&v)[N])
 #pragma unroll
         for (int e = 0; e < N; e += 2) {
             const f32x2 y = gelu_poly2((f32x2){v[e], v[e + 1]});
+            v[e] = y.x; v[e + 1] = y.y;
+        }
+    } else if constexpr (KIND == 0 && N % 2 == 0) {
+#pragma unroll
+        for (int e = 0; e < N; e += 2) {
+            const f32x2 y = gelu_erf2((f32x2){v[e], v[e + 1]});
             v[e] = y.x; v[e + 1] = y.y;
         }
     } else {
