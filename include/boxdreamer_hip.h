@@ -359,7 +359,13 @@ int bd_decoder_forward(const bd_betr_weights* w /*[host]*/, const void* bbox_fea
  * result does not depend on the launch geometry, so the outputs are BIT-identical to the plain form; what changes is that the
  * kernels of one lane fill the CUs the other lane's ragged last round leaves idle.  `lanes` <= 1 (or more lanes than samples)
  * IS the plain form.  The workspace is the sum of the lanes' workspaces (*_workspace_bytes_lanes).  bd_lanes_prepare creates
- * the current device's side streams / events ahead of a stream capture (they are otherwise created on first use). */
+ * the current device's side streams / events ahead of a stream capture (they are otherwise created on first use).
+ * CONCURRENCY.  The side streams and the fork / join events are PROCESS-GLOBAL per device, and the host-side enqueue of a laned
+ * call holds one mutex for its whole duration.  Consequences: (1) laned calls from several host threads on one device serialise
+ * on the host and share the side streams -- correct, every call forks from and joins into ITS caller's stream; (2) a thread that
+ * is CAPTURING `stream` into a HIP graph while another thread enqueues a laned call eagerly on the same device would pull that
+ * thread's side-stream work into its capture (the side streams join the capture at the event wait): capture from one thread at a
+ * time, or have the other threads call with lanes <= 1 (the plain, re-entrant form) while a capture is open. */
 int bd_lanes_prepare(void);
 size_t bd_encoder_workspace_bytes_lanes(const bd_dino_weights* w /*[host]*/, int n_images, int prec, int lanes);
 int bd_encoder_forward_lanes(const bd_dino_weights* w /*[host]*/, const void* images, int img_dtype,
