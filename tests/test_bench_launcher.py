@@ -141,6 +141,31 @@ def test_two_rank_flow_with_the_real_kernels_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_single_gpu_line_carries_the_parity_mode_and_counters_of_this_run():
+    """The driver's record keeps `config`, `roofline` and `cpu_baseline` of the line (scalars only): the parity-meeting mode's figures must
+    be flat scalars there next to the bf16 headline, and MFMA-busy / traffic must come from counters measured in THIS
+    run when rocprofv3 is on the box (item 4) -- else from the stamped file, and the line says which."""
+    import shutil
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-fp8", "--no-trained-like",
+                        "--no-cpu-baseline", "--no-h2d", "--no-pnp", "--no-power"], capture_output=True, text=True, env=_env(), timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _one_line(r)
+    cfg, rf = j["config"], j["roofline"]
+    assert j["value_mode"] == "bf16" and cfg["value_mode"] == "bf16" and cfg["value_meets_parity"] is False
+    assert cfg["parity_mode"] == "f16c8_qk16" and cfg["parity_mode_meets_parity"] is True and cfg["parity_mode_top20_sets_equal_frac"] == 1.0
+    assert 0 < cfg["parity_mode_value"] < j["value"] and cfg["parity_mode_logits_max_abs_err"] <= 5e-4 < cfg["value_logits_max_abs_err"]
+    assert rf["parity_mode"] == "f16c8_qk16" and rf["parity_mode_value"] == cfg["parity_mode_value"] and 0 < rf["parity_mode_frac"] < rf["frac"] < 1
+    assert rf["parity_mode_passes_per_flop"] == 1.93 and rf["bound"] == "mfma" and rf["peak"] == 2500.0
+    if shutil.which("rocprofv3"):
+        assert rf["counters_measured_in_this_run"] is True and rf["parity_mode_counters_measured_in_this_run"] is True, rf.get("counters_in_this_run_skipped")
+        assert rf["traffic_source"].startswith("measured in THIS run") and len(rf["counter_pass_seconds"]) == 3
+        assert 0.3 < rf["mfma_busy_gemm"] < 0.9 and 0.3 < rf["parity_mode_mfma_busy_gemm"] < 0.9
+        assert 1.0 <= rf["traffic_over_algorithmic"] < 3.0 and rf["traffic"] > rf["algorithmic_bytes_per_launch"]
+    else:
+        assert rf["counters_measured_in_this_run"] is False and "counters_in_this_run_skipped" in rf
+
+
+@pytest.mark.gpu
 def test_rank_failure_on_the_gpu_box_is_reported():
     """`--gpus 2` on a box with ONE GPU: rank 1 cannot take cuda:1 and dies while rank 0 blocks in the RCCL rendezvous (a C++ call).
     The launch must end at once with ONE JSON line carrying n_gpus and `error`, and a non-zero rc (the sigwait watcher of bench.py)."""
