@@ -848,7 +848,8 @@ def roofline_block(prec, recs, ms_per_step, trace_runs, value_per_gpu, fpp, coun
          "peak_note": "peak = dense MFMA rate at 2.4 GHz (MI355X_MICROARCH.md).  Under its 1400 W cap the part does not hold that clock in a dense "
                       "GEMM: the same persistent kernels on HALF the CUs deliver 72-82 % of the full-chip rate (profiles/r4_cu_limit_probe.md), every "
                       "MFMA-heavy launch draws 1398-1400 W at a reported 1.73-1.93 GHz (profiles/r4_power_by_kernel.md; this run's board power: the "
-                      "`power` block of the line), a pure MFMA loop without memory traffic sustains 1.9-2.0 PFLOP/s (profiles/r2_mfma_util.md)",
+                      "`power` block of the line); a pure MFMA loop without memory traffic sustains 1.9-2.0 PFLOP/s on CONSTANT operands (profiles/r2_mfma_util.md) "
+                      "and 1.75-1.8 PFLOP/s at 1.53-1.68 GHz when its operands change every instruction (profiles/r5_mfma_toggle.md)",
          "whole_path_achieved": round(value_per_gpu * fpp / 1e12, 2),
          "whole_path_frac": round(value_per_gpu * fpp / 1e12 / peak, 4)}
     return r
