@@ -10,8 +10,23 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _usable_cpus() -> int:
+    """CPUs this process may really use: min(affinity, cgroup cpu.max quota).  The GPU box shows 256 logical CPUs under a 16-CPU quota;
+    torch's default of one thread per logical CPU makes every CPU-oracle forward of the suite crawl there (bench.py: usable_cpus)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+    import torch
+    torch.set_num_threads(_usable_cpus())
 
 
 @pytest.fixture(scope="session")
