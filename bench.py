@@ -484,6 +484,7 @@ def counter_child(args) -> None:
     marker kernels, so that the parent attributes exactly the measured steps' dispatches to the mode -- no weight packing, no
     calibration forwards, no warm-up in the figures."""
     from boxdreamer_amd import synth
+    torch.set_num_threads(usable_cpus())
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
     tiny = torch.full((64,), 0.25, device=device)
@@ -1213,6 +1214,9 @@ def run(args):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     world, rank, local_rank, dist = init_dist(args)
+    # host threads: torch defaults to one per LOGICAL CPU (256 on the GPU box, under a 16-CPU quota): the seeded-weight generation, the
+    # weight packing and rank 0's CPU-oracle parity probes crawl when oversubscribed.  Rank 0 (which runs the oracle) takes the quota.
+    torch.set_num_threads(usable_cpus() if rank == 0 else max(1, usable_cpus() // world))
 
     from boxdreamer_amd import synth
     B, T, prec = args.batch, args.views, args.prec
