@@ -1,0 +1,63 @@
+"""Margin of the default mode on MANY poses (TEST INFRASTRUCTURE: imports the oracle; GPU box): W weight seeds x P input seeds at FULL depth,
+T = 6, varying query position, every pose against the fp32 CPU oracle -- the distribution of the heatmap-logit error, the number of
+identical top-20 sets and, for every differing set, the oracle's own 20th / 21st logit gap (tests/test_gpu_path.py runs the same check on
+2 x 8 poses inside the suite; this is the long form for profiles/).
+    python tools/strict_margin_soak.py [mode] [n_weight_seeds] [n_input_seeds] [out.json]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from boxdreamer_amd import hip_ops, synth
+from boxdreamer_amd.betr import BETR
+from boxdreamer_amd.encoder import DinoV2Wrapper
+from oracle import boxdreamer_oracle as orc
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "f16c8_qk16"
+NW = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+NP = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+out = sys.argv[4] if len(sys.argv) > 4 else "gpurun_out/strict_margin_soak.json"
+try:
+    q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), int(int(q) / int(p)))) if q != "max" else len(os.sched_getaffinity(0)))
+except Exception:
+    pass
+T = 6
+errs, equal, gaps, t0 = [], 0, [], time.time()
+for wi in range(NW):
+    ws_b, ws_d = 1234 + 1111 * wi, 4321 + 777 * wi
+    bsd, dsd = synth.betr_state_dict(seed=ws_b, depth=12), synth.dino_state_dict(seed=ws_d, depth=12)
+    enc = DinoV2Wrapper(None, {"model_type": "dinov2_vitb14_reg", "state_dict": dsd, "hip_precision": mode})
+    enc.to_device("cuda")
+    dec = BETR(d_model=768, nhead=8, num_decoder_layers=12, decoder_only=True, patch_size=14, img_size=224, diff_emb=False, nvs_supervision=False,
+               ray_supervision=True, use_mask=False, use_pretrained=True, patchify_rays=True, pose_representation="bb8",
+               bbox_representation="heatmap", hip_precision=mode)
+    dec.load_state_dict(bsd, strict=True)
+    dec = dec.cuda().eval()
+    datas = [synth.make_batch(seed=500 + 37 * wi + i, B=1, T=T) for i in range(NP)]
+    for i, d in enumerate(datas):
+        d["query_idx"] = torch.tensor([(i * 5 + wi) % T])
+    batch = {k: torch.cat([d[k] for d in datas]) for k in ("images", "bbox_feat", "query_idx")}
+    mask = torch.zeros(NP, T, dtype=torch.bool); mask[torch.arange(NP), batch["query_idx"]] = True
+    img, bf = batch["images"].cuda(), batch["bbox_feat"].cuda()
+    heat = dec(bf, img, mask.cuda(), enc.predict(img), None)
+    _, _, idx = hip_ops.decode_topk(heat)
+    logits, idx = dec.last_logits.cpu(), idx.cpu().long()
+    with torch.no_grad():
+        o = orc.boxdreamer_forward(batch, bsd, dsd)
+    for i in range(NP):
+        e = (logits[i] - o["logits"][i]).abs().max().item()
+        errs.append(e)
+        eq = (idx[i].sort(-1)[0] == o["topk_idx"][i].sort(-1)[0]).all(-1)
+        equal += int(eq.all())
+        for c in (~eq).nonzero().flatten().tolist():
+            top = o["logits"][i, c].flatten().topk(21)[0]
+            gaps.append({"pose": wi * NP + i, "corner": c, "oracle_gap_20_21": (top[19] - top[20]).item(), "pose_err": e})
+    print(f"weights {wi}: max err so far {max(errs):.3e}, identical sets {equal} / {len(errs)} ({time.time() - t0:.0f} s)", flush=True)
+rep = {"mode": mode, "poses": len(errs), "weight_seed_pairs": NW, "input_seeds_per_pair": NP,
+       "logits_max_abs_err": {"max": max(errs), "median": float(np.median(errs)), "p95": float(np.percentile(errs, 95)), "min": min(errs)},
+       "poses_with_all_8_top20_sets_identical": equal, "differing_sets": gaps,
+       "every_differing_set_is_an_oracle_near_tie": all(g["oracle_gap_20_21"] <= 2.0 * g["pose_err"] for g in gaps), "bar": 1e-3,
+       "margin_x": 1e-3 / max(errs), "all_errors": [round(e, 7) for e in errs]}
+os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+json.dump(rep, open(out, "w"), indent=1)
+print(json.dumps({k: v for k, v in rep.items() if k != "all_errors"}))
