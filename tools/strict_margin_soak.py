@@ -2,7 +2,7 @@
 T = 6, varying query position, every pose against the fp32 CPU oracle -- the distribution of the heatmap-logit error, the number of
 identical top-20 sets and, for every differing set, the oracle's own 20th / 21st logit gap (tests/test_gpu_path.py runs the same check on
 2 x 8 poses inside the suite; this is the long form for profiles/).
-    python tools/strict_margin_soak.py [mode] [n_weight_seeds] [n_input_seeds] [out.json]"""
+    python tools/strict_margin_soak.py [mode] [n_weight_seeds] [n_input_seeds] [out.json] [views]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -21,7 +21,7 @@ try:
     torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), int(int(q) / int(p)))) if q != "max" else len(os.sched_getaffinity(0)))
 except Exception:
     pass
-T = 6
+T = int(sys.argv[5]) if len(sys.argv) > 5 else 6
 errs, equal, gaps, t0 = [], 0, [], time.time()
 for wi in range(NW):
     ws_b, ws_d = 1234 + 1111 * wi, 4321 + 777 * wi
