@@ -1409,6 +1409,12 @@ def run(args):
                     apply_counters(line["strict"]["roofline"], got[STRICT_PREC])
             else:
                 line["roofline"]["counters_in_this_run_skipped"] = why
+            if got and "fp8" in line:                      # the configs[4] leg at ITS batch size (three more passes)
+                got8, why8 = inline_counters(["fp8"], 64, T, args.counter_budget)
+                if got8:
+                    apply_counters(line["fp8"]["roofline"], got8["fp8"])
+                else:
+                    line["fp8"]["roofline"]["counters_in_this_run_skipped"] = why8
         # ---- the figures of record as flat scalars inside the dicts the driver's record keeps
         par = line.get("parity") or {}
         line["config"].update(value_mode=prec, value_meets_parity=par.get("meets_tolerance"),
