@@ -469,7 +469,10 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
     const bool kc_two = kc_col < DCH - 8;
     const int vm_kq = tid / DCH, vm_dc = tid % DCH;
     const bool vm_active = tid < VMT;
-    const bool ragged = (seq % KT) != 0;
+    // The host launches this kernel for whole key tiles only (dispatch: q_len % 256 == 0 and seq % 64 == 0).  K / V tiles are fetched with
+    // BUFFER loads: one wave-uniform descriptor over this (sample, head)'s rows, the tile / row origin in the SCALAR offset, and ONE
+    // loop-invariant 32-bit byte offset per lane for K and one for V -- no vector address arithmetic per tile (round 5: the flat form
+    // cost five 64-bit multiply-adds + shifts per tile and wave in a loop whose VALU is the bound; MI355X guide T8 / T20).
     int vdst;
     {
         const int g = vm_kq >> 2, qi = vm_kq & 3;
@@ -477,21 +480,22 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
         vdst = ((g * 2 + (qp >> 1)) << 4) | ((qp & 1) << 3);
     }
     u128 rk[2], rv[4];
+    __amdgpu_buffer_rsrc_t rsrc;
+    {
+        const uintptr_t a = (uintptr_t)base;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(seq * ld * (int)sizeof(T)), 0x00020000);
+    }
+    const int k_voff = (kc_row * ld + kc_col * 8 + heads * HD) * (int)sizeof(T);
+    const int v_voff = (vm_kq * 4 * ld + vm_dc * 8 + 2 * heads * HD) * (int)sizeof(T);
+    const int row_bytes = __builtin_amdgcn_readfirstlane(ld * (int)sizeof(T));
     auto load_tile = [&](int kt) {
-        {
-            int row = kt * KT + kc_row;
-            if (ragged && row >= seq) row = seq - 1;
-            const T* src = kbase + (unsigned)(row * ld + kc_col * 8);
-            rk[0] = *(const u128*)src;
-            if (kc_two) rk[1] = *(const u128*)(src + 64);
-        }
+        const int t_off = kt * KT * row_bytes;                        // scalar
+        rk[0] = __builtin_bit_cast(u128, __builtin_amdgcn_raw_buffer_load_b128(rsrc, k_voff, t_off, 0));
+        if (kc_two) rk[1] = __builtin_bit_cast(u128, __builtin_amdgcn_raw_buffer_load_b128(rsrc, k_voff + 128, t_off, 0));
         if (vm_active) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int row = kt * KT + vm_kq * 4 + j;
-                if (ragged && row >= seq) row = seq - 1;
-                rv[j] = *(const u128*)(vbase + (unsigned)(row * ld + vm_dc * 8));
-            }
+            for (int j = 0; j < 4; ++j) rv[j] = __builtin_bit_cast(u128, __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_voff, t_off + j * row_bytes, 0));
         }
     };
     auto store_tile = [&](int kt, int kbi, int vbi) {
@@ -585,13 +589,6 @@ __global__ __launch_bounds__(512, 1) void attn_kernel_pp(const AttnArgs p) {
         if (t >= 4 && t < 16) AP((t - 4) * 5)                                                                     \
         const bool stage = t + 2 < nt;                                                                            \
         if (stage) load_tile(t + 2);                                                                              \
-        if ((t + 1) * KT > seq) {      /* tail mask of tile t (before anything reads the scores) */               \
-            _Pragma("unroll") for (int km = 0; km < 2; ++km)                                                      \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
-                    const int key = t * KT + km * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;                           \
-                    if (key >= seq) S[TI & 1][km][r] = -INFINITY;                                                 \
-                }                                                                                                 \
-        }                                                                                                         \
         vec8 fr[4];                                                                                               \
         float tmax = -INFINITY, psum = 0.f, mneg = 0.f, alpha = 1.f;                                              \
         bool moved = false;                                                                                       \
@@ -756,7 +753,7 @@ template <class T, int NS, int OUTMODE = 0> int dispatch(const AttnArgs& a, int 
     const bool use3 = waste3 < waste4;
     if constexpr (NS == 1) {
         // ping-pong kernel where its 256-query blocks tile the query range without waste (BETR: 1536 = 6 x 256; last block: 256)
-        if (head_dim == 96 && a.q_len % 256 == 0) return launch_pp<T, 96, OUTMODE>(a, s);
+        if (head_dim == 96 && a.q_len % 256 == 0 && a.seq % KT == 0) return launch_pp<T, 96, OUTMODE>(a, s);      // (whole key tiles only: the kernel has no tail mask)
     }
     if (head_dim == 96) return use3 ? launch<T, NS, 96, 3, OUTMODE>(a, s) : launch<T, NS, 96, 4, OUTMODE>(a, s);
     if (head_dim == 64) return use3 ? launch<T, NS, 64, 3, OUTMODE>(a, s) : launch<T, NS, 64, 4, OUTMODE>(a, s);
