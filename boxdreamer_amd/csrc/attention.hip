@@ -145,21 +145,34 @@ __global__ __launch_bounds__(NW * 64, NS == 1 && HD == 64 ? 3 : 2) void attn_ker
     }
 
     u128 rk[NS][KCPT], rv[NS][4];
+    // K / V tiles by BUFFER loads (round 5, as attn_kernel_pp): one wave-uniform descriptor per plane over this (sample, head)'s seq rows, the
+    // tile / row origin in the scalar offset, loop-invariant 32-bit per-lane offsets.  Rows past a ragged sequence's end are OUT OF RANGE of the
+    // descriptor and read as ZERO (hardware bounds check) -- no per-lane row clamp; their scores are masked to -inf and their P is exactly 0,
+    // so every valid output keeps its bits (the clamped form read row seq - 1 there, equally without effect).
+    __amdgpu_buffer_rsrc_t rsrc[NS];
+    {
+        const int bytes = __builtin_amdgcn_readfirstlane(seq * ld * (int)sizeof(T));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uintptr_t a = (uintptr_t)(base + s * plane);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+            rsrc[s] = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, bytes, 0x00020000);
+        }
+    }
+    const int row_bytes = __builtin_amdgcn_readfirstlane(ld * (int)sizeof(T));
+    int k_voff[KCPT];
+#pragma unroll
+    for (int i = 0; i < KCPT; ++i) k_voff[i] = ((int)kc_off[i] + heads * HD) * (int)sizeof(T);
+    const int v_voff = ((int)vm_off + 2 * heads * HD) * (int)sizeof(T);
 #define LOAD_TILE(kt)                                                                         \
     _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                          \
         _Pragma("unroll") for (int i = 0; i < KCPT; ++i) {                                    \
-            if (KCH % NT == 0 || tid + NT * i < KCH) {                                        \
-                unsigned off = kc_off[i] + (unsigned)((kt) * KT * ld);                        \
-                if (ragged && (kt) * KT + kc_row[i] >= seq) off = (unsigned)((seq - 1) * ld + kc_col[i] * 8); \
-                rk[s][i] = *(const u128*)(kbase + s * plane + off);                           \
-            }                                                                                 \
+            if (KCH % NT == 0 || tid + NT * i < KCH)                                          \
+                rk[s][i] = __builtin_bit_cast(u128, __builtin_amdgcn_raw_buffer_load_b128(rsrc[s], k_voff[i], (kt) * KT * row_bytes, 0)); \
         }                                                                                     \
         if (vm_active) {                                                                      \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                   \
-                unsigned off = vm_off + (unsigned)(((kt) * KT + j) * ld);                     \
-                if (ragged && (kt) * KT + vm_kq * 4 + j >= seq) off = (unsigned)((seq - 1) * ld + vm_dc * 8); \
-                rv[s][j] = *(const u128*)(vbase + s * plane + off);                           \
-            }                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
+                rv[s][j] = __builtin_bit_cast(u128, __builtin_amdgcn_raw_buffer_load_b128(rsrc[s], v_voff, ((kt) * KT + j) * row_bytes, 0)); \
         }                                                                                     \
     }
 #define STORE_TILE(buf)                                                                        \
