@@ -773,6 +773,11 @@ template <class T, int NS, int OUTMODE = 0> int dispatch(const AttnArgs& a, int 
     return BD_ERR_SHAPE;
 }
 
+// the K / V buffer descriptors span ONE sample's rows with a 32-bit byte count (and 32-bit per-lane offsets inside it)
+inline bool sample_bytes_out_of_range(int seq, int heads, int head_dim) {
+    return head_dim <= 0 || (int64_t)seq * 3 * heads * head_dim * 2 >= ((int64_t)1 << 31);
+}
+
 }  // namespace
 
 extern "C" int bd_attention_q(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch, int seq,
@@ -781,6 +786,7 @@ extern "C" int bd_attention_q(const void* qkv, int64_t qkv_plane, void* out, int
     if (!qkv || !out) return BD_ERR_NULL;
     if (batch <= 0 || seq <= 0 || heads <= 0) return BD_ERR_SHAPE;
     if (q_view ? (q_len <= 0 || q_len > seq || seq % q_len) : (q_len != seq)) return BD_ERR_SHAPE;
+    if (sample_bytes_out_of_range(seq, heads, head_dim)) return BD_ERR_SHAPE;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return BD_ERR_ALIGN;
     AttnArgs a{qkv, qkv_plane, out, out_plane, batch, seq, heads, scale * 1.4426950408889634f, q_view, q_len, 0, q_len};
     hipStream_t s = (hipStream_t)stream;
@@ -817,6 +823,7 @@ extern "C" int bd_attention_prefix(const void* qkv, int64_t qkv_plane, void* out
                                    int head_dim, float scale, int n_prefix, int prefix_queries, int prec, void* stream) {
     if (!qkv || !out) return BD_ERR_NULL;
     if (batch <= 0 || seq <= 0 || heads <= 0 || n_prefix <= 0 || n_prefix >= seq) return BD_ERR_SHAPE;
+    if (sample_bytes_out_of_range(seq, heads, head_dim)) return BD_ERR_SHAPE;
     // With the prefix queries wanted, one launch over all seq queries IS the fastest form measured (profiles/r4_attention.md: a separate
     // launch for the prefix rows re-reads the pair's K / V -- 154 MB per DINOv2 launch -- and costs more than the ninth query wave it
     // saves); without them, the patch queries alone tile exactly.

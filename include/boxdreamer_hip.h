@@ -180,7 +180,8 @@ int bd_qk_rmsnorm(void* qkv, int64_t plane, const float* wq, const float* wk, fl
                   int heads, int head_dim, int prec, void* stream);
 
 /* Multi-head self-attention softmax(scale * Q K^T) V on packed qkv [batch, seq, 3, heads, head_dim]
- * -> out [batch, seq, heads*head_dim] (16-bit).  head_dim in {64, 96}.
+ * -> out [batch, seq, heads*head_dim] (16-bit).  head_dim in {64, 96}.  One sample's qkv rows (seq * 3 * heads * head_dim * 2 bytes)
+ * must stay below 2 GiB (the kernels reach them through 32-bit buffer descriptors): BD_ERR_SHAPE otherwise.
  * Replaces flash_attn.flash_attn_func / F.scaled_dot_product_attention (blocks.py:259-285) and
  * xformers.ops.memory_efficient_attention / the naive softmax path (DINOv2 layers/attention.py:56-89). */
 int bd_attention(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch, int seq,

@@ -629,6 +629,20 @@ def test_attention_query_range(hip, prec):
         assert torch.equal(got[b], full[b, qv[b] * P:(qv[b] + 1) * P])       # bit-identical to the full-width kernel
 
 
+def test_attention_refuses_a_sample_beyond_the_descriptor_range(hip):
+    """The K / V tiles are fetched through 32-bit buffer descriptors spanning ONE sample's rows: a sample of 2 GiB or more must be refused
+    (BD_ERR_SHAPE) before anything is launched -- the arguments are validated first, so a small dummy buffer is enough here."""
+    lib = _lib.load()
+    t = torch.zeros(4096, dtype=torch.bfloat16, device="cuda")
+    heads, hd = 8, 96
+    seq = (1 << 31) // (3 * heads * hd * 2) + 1
+    with pytest.raises(_lib.HipLibraryError, match="BD_ERR_SHAPE"):
+        _lib.check(lib.bd_attention(_lib.ptr(t), 0, _lib.ptr(t), 0, 1, seq, heads, hd, hd ** -0.5, _lib.PREC_BF16, _lib.stream()), "bd_attention")
+    with pytest.raises(_lib.HipLibraryError, match="BD_ERR_SHAPE"):
+        _lib.check(lib.bd_attention_prefix(_lib.ptr(t), 0, _lib.ptr(t), 0, 1, seq, heads, hd, hd ** -0.5, 5, 1, _lib.PREC_BF16, _lib.stream()),
+                   "bd_attention_prefix")
+
+
 # ----------------------------------------------------------------------------- fp8 (e4m3) mode, BASELINE configs[4]
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1500, 1536, 256), (300, 200, 384), (2048, 768, 3072)])
