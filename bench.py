@@ -452,6 +452,14 @@ STALL_COUNTERS = ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIV
                   "SQ_INSTS_MFMA", "SQ_VALU_MFMA_COEXEC_CYCLES")
 
 
+# request-size pass (TCC block): the L2 -> fabric read requests by size.  FETCH_SIZE's expression tallies every request that is not a
+# 32-byte one at 64 bytes (rocprofv3 -L: "(TCC_BUBBLE*128 + (RDREQ - BUBBLE - RDREQ_32B)*64 + RDREQ_32B*32) / 1024", BUBBLE = 0 on this
+# part), which is what the guide's "x 2" correction repairs for streams of 128-byte requests; summing the sizes themselves needs no correction
+# and is kept NEXT to the corrected figure as a check of it on this access pattern (MI355X_MICROARCH.md: "calibrate ... in your own
+# access pattern").  `traffic` stays the guide's figure.
+REQSIZE_COUNTERS = ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_sum")
+
+
 def _available_counters(names):
     """The subset of `names` this rocprofv3 / device lists (`rocprofv3 -L`); [] when the listing itself fails."""
     import subprocess
@@ -574,6 +582,12 @@ def collect_counters(modes, B: int, T: int, groups, steps: int = 2, deadline: fl
                       "hbm_gb_per_s": round((fetch + write) / max(dur_ns[m][k] / steps, 1), 1),
                       "mfma_busy": round(A["SQ_VALU_MFMA_BUSY_CYCLES"][k] / max(cyc * 1024.0, 1.0), 4),
                       "delivered_clock_ghz": round(cyc / max(dur_ns[m][k], 1), 3)}
+            if all(c in A for c in REQSIZE_COUNTERS):
+                n32, n64, n128, nall = (A[c][k] / steps for c in REQSIZE_COUNTERS)
+                exact = 32.0 * n32 + 64.0 * n64 + 128.0 * n128
+                per[k]["fetch_by_request_size"] = {"requests_32B": round(n32), "requests_64B": round(n64), "requests_128B": round(n128),
+                                                   "requests_all": round(nall), "bytes_per_step": round(exact),
+                                                   "over_corrected_FETCH_SIZE": round(exact / fetch, 4) if fetch else None}
             if lds_group:
                 wc = A["SQ_WAVE_CYCLES"][k]
                 per[k]["lds"] = {c: round(A[c][k] / steps) for c in lds_group}
@@ -606,7 +620,9 @@ def collect_counters(modes, B: int, T: int, groups, steps: int = 2, deadline: fl
                             + " ".join(child) + "` (un-graphed, one batch at a time as ONE lane; only the dispatches between the child's "
                             "marker kernels count: no packing, calibration or warm-up); bytes = counter KB x 1024, FETCH_SIZE x 2 (gfx950 "
                             "correction, MI355X_MICROARCH.md HBM section: L2 -> fabric requests, MALL hits included, i.e. an UPPER bound on "
-                            "HBM bytes), WRITE_SIZE as is; MFMA busy = MFMA-busy SIMD-cycles / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs)"}
+                            "HBM bytes), WRITE_SIZE as is; MFMA busy = MFMA-busy SIMD-cycles / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs)"
+                            + ("; fetch_by_request_size = 32 / 64 / 128-byte read requests summed at their own sizes (no correction needed), the check "
+                               "of the corrected FETCH_SIZE on this access pattern" if all(c in names for c in REQSIZE_COUNTERS) else "")}
     return result
 
 
@@ -615,7 +631,10 @@ def measure_counters(args) -> None:
     prec, B, T = args.prec, args.batch, args.views
     lds_group = _available_counters(LDS_COUNTERS)
     stall_group = _available_counters(STALL_COUNTERS)
+    req_group = _available_counters(REQSIZE_COUNTERS)
     groups = list(BASIC_GROUPS) + ([tuple(lds_group)] if lds_group else []) + ([tuple(stall_group)] if stall_group else [])
+    if len(req_group) == len(REQSIZE_COUNTERS):
+        groups.append(tuple(req_group))
     out = collect_counters([prec], B, T, groups)[prec]
     path = os.path.join(ROOT, "profiles", f"counters_{prec}.json")
     json.dump(out, open(path, "w"), indent=1)

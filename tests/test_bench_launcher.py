@@ -207,7 +207,9 @@ def test_counter_passes_attribute_only_the_marked_steps(tmp_path, monkeypatch):
             disp("void at::native::erfinv_kernel", {})
             for _ in range(steps):
                 disp("gemm_kernel_pc<x>", {"FETCH_SIZE": 100 * mode_scale, "WRITE_SIZE": 50 * mode_scale,
-                                           "SQ_VALU_MFMA_BUSY_CYCLES": 512.0 * 1024, "SQ_BUSY_CYCLES": 32.0 * 1024}, dur=2000)
+                                           "SQ_VALU_MFMA_BUSY_CYCLES": 512.0 * 1024, "SQ_BUSY_CYCLES": 32.0 * 1024,
+                                           "TCC_EA0_RDREQ_32B_sum": 16, "TCC_EA0_RDREQ_64B_sum": 8, "TCC_EA0_RDREQ_128B_sum": 1592 * mode_scale,
+                                           "TCC_EA0_RDREQ_sum": 1616}, dur=2000)
                 disp("attn_kernel<y>", {"FETCH_SIZE": 10, "WRITE_SIZE": 5, "SQ_VALU_MFMA_BUSY_CYCLES": 256.0 * 1024, "SQ_BUSY_CYCLES": 32.0 * 1024})
                 disp("decode_kernel<true>", {})
             disp("void at::native::erfinv_kernel", {})
@@ -225,6 +227,12 @@ def test_counter_passes_attribute_only_the_marked_steps(tmp_path, monkeypatch):
     assert g1["ms_per_step"] == 0.002 and "harness (one-off torch / runtime kernels: weight packing, uploads)" not in res["bf16"]["per_kernel_class"]
     calls = res["bf16"]["gemm_calls_per_step"]
     assert res["bf16"]["gemm_hbm_bytes_per_call"] == round((2 * 100 + 50) * 1024 / calls)
+    # the optional request-size pass: bytes summed by size, next to (never instead of) the corrected FETCH_SIZE
+    assert "fetch_by_request_size" not in g1
+    res4 = b.collect_counters(["bf16", "f16c8_qk16"], 32, 6, list(b.BASIC_GROUPS) + [b.REQSIZE_COUNTERS], steps=steps)
+    q = res4["bf16"]["per_kernel_class"]["gemm"]["fetch_by_request_size"]
+    assert q["bytes_per_step"] == 32 * 16 + 64 * 8 + 128 * 1592 == 2 * 100 * 1024 and q["over_corrected_FETCH_SIZE"] == 1.0
+    assert res4["bf16"]["per_kernel_class"]["gemm"]["fetch_bytes_per_step"] == g1["fetch_bytes_per_step"]
     # a roofline block takes the figures over and says where they came from
     rf = {"traffic": None, "mfma_busy": None}
     res["bf16"]["measured_in_this_run"] = True
