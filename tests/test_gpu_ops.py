@@ -632,6 +632,7 @@ def test_attention_query_range(hip, prec):
 def test_attention_refuses_a_sample_beyond_the_descriptor_range(hip):
     """The K / V tiles are fetched through 32-bit buffer descriptors spanning ONE sample's rows: a sample of 2 GiB or more must be refused
     (BD_ERR_SHAPE) before anything is launched -- the arguments are validated first, so a small dummy buffer is enough here."""
+    from boxdreamer_amd import _lib
     lib = _lib.load()
     t = torch.zeros(4096, dtype=torch.bfloat16, device="cuda")
     heads, hd = 8, 96
