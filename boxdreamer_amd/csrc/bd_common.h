@@ -433,6 +433,11 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
     ln_row_finish<T, NS>(t, gamma, beta, eps, out16, out16_plane, out32_row, orow, cols, lane);
 }
 
+// gemm_f16c8.hip: how many launches of the same shape the calling thread is enqueueing SIDE BY SIDE on different streams (forward.hip's
+// sub-batch lanes set it around their per-lane calls; 1 otherwise).  A host-side hint for tile-form choices that count free CUs; it never
+// changes a result (every row is independent of the tile form).
+int& bd_concurrent_launches();
+
 // trace.hip
 int bd_trace_open(hipStream_t s, int kind, int M, int N, int K);
 void bd_trace_close(hipStream_t s, int slot);

@@ -421,12 +421,14 @@ template <class F> int run_lanes(int lanes, hipStream_t main, F&& lane_call) {
     hipError_t e = hipEventRecord(L->fork, main);
     if (e != hipSuccess) return (int)e;
     int rc = BD_OK;
+    bd_concurrent_launches() = lanes;          // the lanes' launches run side by side: tile-form choices count a lane's share of the CUs
     for (int l = 0; l < lanes; ++l) {
         hipStream_t s = l == 0 ? main : L->side[l - 1];
         if (l > 0 && (e = hipStreamWaitEvent(s, L->fork, 0)) != hipSuccess && rc == BD_OK) rc = (int)e;
         const int r = lane_call(l, s);
         if (r != BD_OK && rc == BD_OK) rc = r;
     }
+    bd_concurrent_launches() = 1;
     for (int l = 1; l < lanes; ++l) {
         if ((e = hipEventRecord(L->join[l - 1], L->side[l - 1])) != hipSuccess && rc == BD_OK) rc = (int)e;
         if ((e = hipStreamWaitEvent(main, L->join[l - 1], 0)) != hipSuccess && rc == BD_OK) rc = (int)e;

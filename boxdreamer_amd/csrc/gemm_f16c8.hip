@@ -21,17 +21,30 @@ namespace {
 //     slab in this operand class, is off the critical path.  NSTAGE = 2 (scratch separate) serves the other K.
 //   * the e4m3 image q8 of an f16 fragment derived in registers (v_cvt_scalef32_pk_fp8_f16, 4 per fragment), so the
 //     correction pass costs one extra ds_read_b128 per 32-row fragment pair instead of two.
-template <int NSTAGE, int EP, int OUTK, bool GELU>
-__global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_args p) {
-    constexpr int WM = 4, WN = 2, MI = 2, NI = 3, NPW = 4, NCW = WM * WN;
+//   * (round 5) a SMALL form of the same kernel -- 128 x 192 tiles, 4 consumer + 4 producer waves: ONE consumer wave per SIMD instead of two --
+//     for launches whose 256 x 192 tiles would fill their rounds badly (one pose at a time: M = 1536 is 24-96 tiles on 256 CUs): twice the
+//     workgroups, each done in half the time.  Same wave tile, same K order, same epilogue arithmetic: a row's result does not depend on the
+//     form (tests/test_gpu_ops.py::test_gemm_f16c8_small_form_rows_equal_the_large_form).  (A 128 x 96 form on 2 + 2 waves, two workgroups
+//     per CU -- the template takes it: <.., 2, 1, 2> -- is 17 % faster still on fc2 below 3072 rows and slower everywhere else:
+//     profiles/r5_f16c8_small_form.md.)
+template <int NSTAGE, int EP, int OUTK, bool GELU, int WM = 4, int WN = 2, int NPW = 4>
+__global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1) void gemm_kernel_pc_f16c8(const bd_gemm_args p) {
+    constexpr int MI = 2, NI = 3, NCW = WM * WN;
     constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32, BK = 32;
     constexpr int A0 = TBM * 64, W0 = TBN * 64, A1 = TBM * 32, W1 = TBN * 64;     // W's e4m3 plane carries q8 AND lo8 (weights: packed once)
     constexpr int OFF_W0 = A0, OFF_A1 = A0 + W0, OFF_W1 = A0 + W0 + A1, STAGE = A0 + W0 + A1 + W1;
-    constexpr int SR = 16, SCRATCH = NCW * SR * NI * 32 * 4;
-    static_assert(SCRATCH == STAGE, "the epilogue scratch overlays stage 2 exactly");
+    constexpr int SR = 16, SCRATCH = NCW * SR * NI * 32 * 4, S2 = SCRATCH > STAGE ? SCRATCH : STAGE;
+    static_assert(SCRATCH <= STAGE, "the epilogue scratch overlays stage 2");
+    // producers: every plane of a stage is fetched in 1-KiB pieces (one wave instruction: 16 rows of 64 B, or 32 rows of 32 B), dealt round-robin
+    constexpr int GA0 = TBM / 16, GW0 = TBN / 16, GA1 = TBM / 32, GW1 = TBN / 16;
+    constexpr int IA0 = (GA0 + NPW - 1) / NPW, IW0 = (GW0 + NPW - 1) / NPW, IA1 = (GA1 + NPW - 1) / NPW, IW1 = (GW1 + NPW - 1) / NPW;
+    static_assert(GA0 % NPW == 0 && GW0 % NPW == 0 && GA1 % NPW == 0 && GW1 % NPW == 0, "every producer wave issues the same number of pieces (counted vmcnt)");
+    constexpr int PIECES = IA0 + IW0 + IA1 + IW1;      // per slab and producer wave: 12 (256 x 192 on 4 producers), 9 (128 x 192)
+    // s_waitcnt vmcnt(PIECES) with expcnt / lgkmcnt left alone (gfx9 encoding: vmcnt [3:0] and [15:14], expcnt [6:4], lgkmcnt [11:8])
+    constexpr int WAIT_ONE_SLAB = (PIECES & 15) | ((PIECES >> 4) << 14) | 0x70 | 0xF00;
     // side buffer behind the ring + scratch (gemm_kernel_pc): per-column vectors of the current / next tile, q / k RMSNorm weights
-    constexpr int AUX_COLP = 2 * STAGE + SCRATCH, AUX_RMS = AUX_COLP + 4096, AUX_BYTES = EP == 0 ? 0 : 6144;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE + SCRATCH + AUX_BYTES];   // stages at 0, STAGE, 2*STAGE; scratch at 2*STAGE
+    constexpr int AUX_COLP = 2 * STAGE + S2, AUX_RMS = AUX_COLP + 4096, AUX_BYTES = EP == 0 ? 0 : 6144;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE + S2 + AUX_BYTES];   // stages at 0, STAGE, 2*STAGE; scratch at 2*STAGE
 
     bd_saturating_conversions();      // q8 images (K loop) and F16C8 / f16 results (epilogue) saturate instead of turning NaN / inf
     const int tid = threadIdx.x, lane = tid & 63;
@@ -59,15 +72,15 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
         // ------------------------------------------------------------------ producers
         const int pw = wid - NCW;
         const unsigned lda0 = (unsigned)(p.lda * 2), ldw0 = (unsigned)(p.ldw * 2), lda1 = (unsigned)p.lda, ldw1 = (unsigned)(p.ldw * 2);
-        unsigned oA0[4], oW0[3], oA1[2], oW1[3];
+        unsigned oA0[IA0], oW0[IW0], oA1[IA1], oW1[IW1];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int row = (pw + 4 * i) * 16 + lane / 4; oA0[i] = row * lda0 + swz_chunk<4>(row, lane % 4) * 16; }
+        for (int i = 0; i < IA0; ++i) { const int row = (pw + NPW * i) * 16 + lane / 4; oA0[i] = row * lda0 + swz_chunk<4>(row, lane % 4) * 16; }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { const int row = (pw + 4 * i) * 16 + lane / 4; oW0[i] = row * ldw0 + swz_chunk<4>(row, lane % 4) * 16; }
+        for (int i = 0; i < IW0; ++i) { const int row = (pw + NPW * i) * 16 + lane / 4; oW0[i] = row * ldw0 + swz_chunk<4>(row, lane % 4) * 16; }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { const int row = (pw + 4 * i) * 32 + lane / 2; oA1[i] = row * lda1 + swz_chunk<2>(row, lane % 2) * 16; }
+        for (int i = 0; i < IA1; ++i) { const int row = (pw + NPW * i) * 32 + lane / 2; oA1[i] = row * lda1 + swz_chunk<2>(row, lane % 2) * 16; }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { const int row = (pw + 4 * i) * 16 + lane / 4; oW1[i] = row * ldw1 + swz_chunk<4>(row, lane % 4) * 16; }
+        for (int i = 0; i < IW1; ++i) { const int row = (pw + NPW * i) * 16 + lane / 4; oW1[i] = row * ldw1 + swz_chunk<4>(row, lane % 4) * 16; }
         const unsigned char* pA0 = (const unsigned char*)p.A;
         const unsigned char* pW0 = (const unsigned char*)p.W;
         const unsigned char* pA1 = pA0 + p.a_plane * 2;
@@ -82,13 +95,13 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
             const unsigned char* ba1 = pA1 + (int64_t)m0 * lda1 + (int64_t)kt * 32;
             const unsigned char* bw1 = pW1 + (int64_t)n0 * ldw1 + (int64_t)kt * 64;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) glds16_s(oA0[i] < la0 ? oA0[i] : la0, ba0, st + i * 4096);
+            for (int i = 0; i < IA0; ++i) glds16_s(oA0[i] < la0 ? oA0[i] : la0, ba0, st + i * (NPW * 1024));
 #pragma unroll
-            for (int i = 0; i < 3; ++i) glds16_s(oW0[i] < lw0 ? oW0[i] : lw0, bw0, st + OFF_W0 + i * 4096);
+            for (int i = 0; i < IW0; ++i) glds16_s(oW0[i] < lw0 ? oW0[i] : lw0, bw0, st + OFF_W0 + i * (NPW * 1024));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) glds16_s(oA1[i] < la1 ? oA1[i] : la1, ba1, st + OFF_A1 + i * 4096);
+            for (int i = 0; i < IA1; ++i) glds16_s(oA1[i] < la1 ? oA1[i] : la1, ba1, st + OFF_A1 + i * (NPW * 1024));
 #pragma unroll
-            for (int i = 0; i < 3; ++i) glds16_s(oW1[i] < lw1 ? oW1[i] : lw1, bw1, st + OFF_W1 + i * 4096);
+            for (int i = 0; i < IW1; ++i) glds16_s(oW1[i] < lw1 ? oW1[i] : lw1, bw1, st + OFF_W1 + i * (NPW * 1024));
         };
         // issue cursor over this workgroup's slab sequence (all tiles, slab by slab); slab number ig goes to stage ig % NSTAGE
         int ig = 0, ist = 0, it = t_begin + (bid >> 3), ikt = 0, im0 = 0, in0 = 0, itn = 0;
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
         // wait until at most `slabs` of this wave's most recent slab fetches are still in flight (12 pieces each)
         auto wait_landed = [&](int slabs) {
             if (slabs <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else { __builtin_amdgcn_s_waitcnt(WAIT_ONE_SLAB); asm volatile("" ::: "memory"); }
         };
 #ifdef BD_GEMM_PROBE
         unsigned probe_ts = 0;
@@ -278,6 +291,11 @@ __global__ __launch_bounds__(768, 1) void gemm_kernel_pc_f16c8(const bd_gemm_arg
 
 }  // namespace
 
+int& bd_concurrent_launches() {
+    static thread_local int n = 1;
+    return n;
+}
+
 // F16C8 has its own persistent kernel; every shape goes through it
 int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     if (!wide_epilogue_ok(a, 2) || 256 * a.lda * 2 >= ((int64_t)1 << 31) || 256 * a.ldw * 2 >= ((int64_t)1 << 31)) return BD_ERR_ALIGN;
@@ -288,7 +306,6 @@ int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     const int cus = cu_count();
     const int tiles = ((a.M + 255) / 256) * ((a.N + 191) / 192);
-    const int grid = tiles < cus ? tiles : cus;
     // epilogue specialisation (gemm_kernel_pc's header): native / f16 / split-bf16 16-bit results, fp32 (+ residual)
     int ep = 0, outk = a.out_f32;
     const bool gelu = a.act == BD_ACT_GELU;
@@ -298,9 +315,18 @@ int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     }
     if (ep == 1 && gelu && outk != OUT_OPERAND) ep = 0;
     const bool s3 = (a.K / 32) % 3 == 0;
-    const dim3 g(grid), b(768);
+    // The SMALL form (128 x 192 tiles, one consumer wave per SIMD) where the large tiles would occupy at most half of the CUs -- one pose at
+    // a time: M = 1536 is 24-96 large tiles on 256 CUs; with sub-batch lanes, of the CUs' share of one lane.  Measured per shape and row count (profiles/r5_f16c8_small_form.md): up to 128 large
+    // tiles the small form is 5-35 % faster, from 144 on it is slower (a lone consumer wave per SIMD needs ~1400 cycles per slab where two
+    // need ~2000 for twice the work).  Three-stage ring (K / 32 a multiple of 3: every K of the path) and specialised epilogues only.
+    // Every row's result is unchanged.
+    const int tiles_small = ((a.M + 127) / 128) * ((a.N + 191) / 192);
+    const bool small = s3 && ep != 0 && 2 * tiles * bd_concurrent_launches() <= cus;      // (sub-batch lanes: their launches share the CUs)
+    const int grid = small ? (tiles_small < cus ? tiles_small : cus) : (tiles < cus ? tiles : cus);
+    const dim3 g(grid), b(small ? 512 : 768);
 #define BD_C8_LAUNCH(EP_, OUTK_, GELU_)                                                                     \
-    { if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_>), g, b, 0, s, a);                 \
+    { if (small) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_, 2, 2, 4>), g, b, 0, s, a);     \
+      else if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_>), g, b, 0, s, a);            \
       else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, EP_, OUTK_, GELU_>), g, b, 0, s, a); }
     if (ep == 3) BD_C8_LAUNCH(3, OUT_F32, false)
     else if (ep == 2 && outk == OUT_OPERAND) BD_C8_LAUNCH(2, OUT_OPERAND, false)
@@ -310,7 +336,8 @@ int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     else if (ep == 1 && outk == OUT_OPERAND) BD_C8_LAUNCH(1, OUT_OPERAND, false)
     else if (ep == 1 && outk == OUT_F16) BD_C8_LAUNCH(1, OUT_F16, false)
     else if (ep == 1) BD_C8_LAUNCH(1, OUT_BF16X2, false)
-    else BD_C8_LAUNCH(0, OUT_OPERAND, false)
+    else if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 0, OUT_OPERAND, false>), g, b, 0, s, a);      // generic epilogue: the big form only
+    else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, 0, OUT_OPERAND, false>), g, b, 0, s, a);
 #undef BD_C8_LAUNCH
     bd_trace_close(s, slot);
     BD_CHECK_LAUNCH();

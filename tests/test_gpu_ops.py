@@ -224,6 +224,48 @@ def test_gemm_row_result_independent_of_tile_shape(hip, prec, N, K, kind):
         assert torch.equal(head.contiguous().view(torch.uint8), small.contiguous().view(torch.uint8)), (prec, kind, rows)
 
 
+@pytest.mark.parametrize("N,K,kind", [(768, 768, "resid"), (768, 3072, "resid"), (3072, 768, "gelu"), (2304, 768, "plain"), (2304, 768, "rms_f16"),
+                                      (2304, 768, "rms_operand"), (2304, 768, "split_bf16"), (768, 768, "f32")])
+def test_gemm_f16c8_small_form_rows_equal_the_large_form(hip, N, K, kind):
+    """The F16C8 class's persistent kernel has two forms (round 5): 256 x 192 tiles on 8 + 4 waves, and -- for launches whose large tiles would
+    fill their rounds badly (one pose at a time: 1536 rows) -- 128 x 192 tiles on 4 + 4 waves, one consumer wave per SIMD.  Same wave tile, K
+    order and epilogue arithmetic: the first rows of a 49152-row launch (large form) must equal, bit for bit, the same rows launched alone at
+    1536 / 300 / 4096 rows (small form; ragged last tile at 300), for every specialised epilogue of the path."""
+    M = 49152
+    a, w, b = _rand("a", (M, K)).cuda(), _rand("w", (N, K), 0.05).cuda(), _rand("b", (N,), 0.5).cuda()
+    e = hip_ops.f16c8_qexp(w)
+    w16 = hip_ops.f16c8_encode(w, e, True)
+    res = _rand("r", (M, N)).cuda() if kind == "resid" else None
+    rms = ((_rand("wq", (96,), 0.1) + 1).cuda(), (_rand("wk", (96,), 0.1) + 1).cuda(), 1e-6)
+
+    def go(rows):
+        kw = {"w_qexp": e}
+        if kind == "resid":
+            kw.update(resid=res[:rows].clone(), out_f32=True)
+        elif kind == "f32":
+            kw.update(out_f32=True)
+        elif kind == "gelu":
+            kw.update(act=1)
+        elif kind == "rms_f16":
+            kw.update(rms=rms, out_mode=2)
+        elif kind == "rms_operand":
+            kw.update(rms=rms)
+        elif kind == "split_bf16":
+            kw.update(out_mode=4)
+        return hip_ops.gemm(hip_ops.f16c8_encode(a[:rows], 0, False), w16, b, prec="f16c8", **kw)
+
+    big = go(M)
+    for rows in (1536, 300, 4096):
+        small = go(rows)
+        if kind in ("rms_operand", "gelu", "plain"):                      # F16C8 operand out: f16 plane + the byte plane's first rows * N bytes
+            assert torch.equal(big[0][:rows], small[0]), (kind, rows, "f16 plane")
+            nb = rows * N
+            assert torch.equal(big[1].view(torch.uint8).reshape(-1)[:nb], small[1].view(torch.uint8).reshape(-1)[:nb]), (kind, rows, "lo8 plane")
+        else:
+            head = big[:, :rows] if big.dim() == 3 else big[:rows]
+            assert torch.equal(head.contiguous().view(torch.uint8), small.contiguous().view(torch.uint8)), (kind, rows)
+
+
 @pytest.mark.parametrize("prec", ["bf16", "f16x3", "fp8", "f16c8"])
 @pytest.mark.parametrize("K", [768, 3072])
 def test_gemm_rows_of_a_sparse_last_round_take_smaller_tiles(hip, prec, K):
