@@ -328,7 +328,12 @@ int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     { if (small) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_, 2, 2, 4>), g, b, 0, s, a);     \
       else if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_>), g, b, 0, s, a);            \
       else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, EP_, OUTK_, GELU_>), g, b, 0, s, a); }
-    if (ep == 3) BD_C8_LAUNCH(3, OUT_F32, false)
+    // fc2 (deep K, 4 column tiles) below ~4096 rows: 128 x 96 tiles on 2 + 2 waves -- four times the workgroups of the large form, still at most
+    // one per CU -- is another 17 % faster than the 128 x 192 form (52 vs 63 us at 1536 rows; everywhere else it is slower:
+    // profiles/r5_f16c8_small_form.md).  One instance.
+    if (ep == 3 && small && a.K >= 2048 && a.N % 96 == 0 && 4 * tiles * bd_concurrent_launches() <= cus)
+        hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 3, OUT_F32, false, 2, 1, 2>), dim3(((a.M + 127) / 128) * (a.N / 96)), dim3(256), 0, s, a);
+    else if (ep == 3) BD_C8_LAUNCH(3, OUT_F32, false)
     else if (ep == 2 && outk == OUT_OPERAND) BD_C8_LAUNCH(2, OUT_OPERAND, false)
     else if (ep == 2 && outk == OUT_F16) BD_C8_LAUNCH(2, OUT_F16, false)
     else if (ep == 2) BD_C8_LAUNCH(2, OUT_BF16X2, false)
