@@ -1152,6 +1152,7 @@ def main():
                          "bit-identical results for every value")
     ap.add_argument("--no-strict", action="store_true", help="skip the second (strict-mode) timing")
     ap.add_argument("--no-trained-like", action="store_true", help="skip the strict-mode leg on the trained-like outlier weights")
+    ap.add_argument("--no-latency", action="store_true", help="skip the one-pose (B = 1) latency leg of the default single-GPU run")
     ap.add_argument("--no-fp8", action="store_true", help="skip the configs[4] leg (fp8 Linears, batch 64) of the default single-GPU run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -1388,6 +1389,28 @@ def run(args):
                                              "(tests/test_gpu_path.py::test_fp8_mode_restated_tolerance); not a mode that meets the 1e-3 bar"}
         fres["run"].close()
         del fres
+    # ---- one pose at a time (B = 1: the reference demo's per-frame call, 1 query + 5 references), both modes, HIP graph; single GPU, default
+    # workload only.  A latency figure next to the throughput ones; never `value`.
+    PROGRESS["stage"] = "one-pose latency leg (B = 1)"
+    if rank == 0:
+        PROGRESS["line"] = dict(line)
+    if world == 1 and not args.no_latency and not args.cache_refs and B == 32 and T == 6:
+        lat = {}
+        one1 = synth.make_batch(seed=700, B=1, T=T)
+        img1, bb1 = one1["images"].to(torch.bfloat16).to(device), one1["bbox_feat"].to(torch.bfloat16).to(device)
+        mask1 = torch.zeros(1, T, dtype=torch.bool, device=device); mask1[:, T - 1] = True
+        args1 = argparse.Namespace(**{**vars(args), "batch": 1, "in_flight": 1, "steps": max(args.steps, 30), "warmup": max(args.warmup, 8)})
+        for m in dict.fromkeys([prec] + ([] if args.no_strict else [STRICT_PREC])):
+            torch.cuda.empty_cache()
+            lres = measure_mode(m, args1, device, world, rank, dist, img1, bb1, mask1)
+            lat[m] = {"ms_per_pose": round(lres["ms_per_step"], 3), "poses_per_s": round(lres["value"], 1), "hip_graph": lres["run"].graphed is not None}
+            lres["run"].close()
+            del lres
+        line["one_pose_latency"] = {"workload": "B = 1: 1 query + 5 references, 224x224, one forward at a time (HIP graph), inputs resident in HBM",
+                                    "modes": lat}
+        line["config"].update(one_pose_ms=lat[prec]["ms_per_pose"])
+        if STRICT_PREC in lat:
+            line["config"].update(parity_mode_one_pose_ms=lat[STRICT_PREC]["ms_per_pose"])
     # ---- BASELINE configs[3]'s per-GPU shard in the same line: 1 query + 16 refs, batch 32 per GPU, headline mode;
     # every rank takes part (same barriers, same corner gather); default for N > 1, `--config3` at N = 1
     PROGRESS["stage"] = "configs[3] leg (T = 17)"

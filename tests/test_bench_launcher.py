@@ -156,6 +156,10 @@ def test_single_gpu_line_carries_the_parity_mode_and_counters_of_this_run():
     assert 0 < cfg["parity_mode_value"] < j["value"] and cfg["parity_mode_logits_max_abs_err"] <= 5e-4 < cfg["value_logits_max_abs_err"]
     assert rf["parity_mode"] == "f16c8_qk16" and rf["parity_mode_value"] == cfg["parity_mode_value"] and 0 < rf["parity_mode_frac"] < rf["frac"] < 1
     assert rf["parity_mode_passes_per_flop"] == 1.93 and rf["bound"] == "mfma" and rf["peak"] == 2500.0
+    # one pose at a time (B = 1) of both modes, as flat scalars too: a latency far below a batch's step, the parity mode the slower one
+    lat = j["one_pose_latency"]["modes"]
+    assert cfg["one_pose_ms"] == lat["bf16"]["ms_per_pose"] and cfg["parity_mode_one_pose_ms"] == lat["f16c8_qk16"]["ms_per_pose"]
+    assert 0.5 < cfg["one_pose_ms"] < cfg["parity_mode_one_pose_ms"] < j["ms_per_step"]
     if rf["counters_measured_in_this_run"]:
         assert shutil.which("rocprofv3") and rf["parity_mode_counters_measured_in_this_run"] is True
         assert rf["traffic_source"].startswith("measured in THIS run") and len(rf["counter_pass_seconds"]) == 3

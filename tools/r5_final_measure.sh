@@ -10,7 +10,7 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a $out/
 ( cd /tmp && export TMPDIR=/tmp
   for pr in bf16 f16c8_qk16 fp8; do
     b=32; [ $pr = fp8 ] && b=64
-    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_$pr -- python $R/bench.py --prec $pr --batch $b --in-flight 1 --lanes 1 --steps 5 --warmup 2 --no-graph --no-strict --no-fp8 --no-cpu-baseline --no-pnp --no-h2d --no-parity --no-inline-counters --no-power > /dev/null 2>&1
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_$pr -- python $R/bench.py --prec $pr --batch $b --in-flight 1 --lanes 1 --steps 5 --warmup 2 --no-graph --no-strict --no-fp8 --no-cpu-baseline --no-pnp --no-h2d --no-parity --no-inline-counters --no-power --no-latency > /dev/null 2>&1
     echo "rocprof $pr rc $?"
     f=$(find $R/$out/prof_$pr -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/$out/${tag}_bench_${pr}_kernel_stats.csv
   done )
@@ -18,8 +18,8 @@ for pr in bf16 f16c8_qk16; do timeout 900 python bench.py --measure-counters --p
 timeout 900 python bench.py --measure-counters --prec fp8 --batch 64 > $out/counters_fp8.log 2>&1; echo "counters fp8 rc $?" | tee -a $out/status
 cp profiles/counters_*.json $out/ 2>/dev/null
 ( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > $out/bench_default.json 2> $out/bench_default.err; echo "bench default rc $?" | tee -a $out/status
-python bench.py --config3 --no-strict --no-fp8 --no-cpu-baseline --no-pnp --no-h2d --no-inline-counters --no-trained-like > $out/bench_config3.json 2> $out/bench_config3.err; echo "bench config3 rc $?" | tee -a $out/status
-python bench.py --prec f16c8_qk16 --views 17 --no-strict --no-fp8 --no-cpu-baseline --no-pnp --no-h2d --no-inline-counters --no-trained-like > $out/bench_T17_default.json 2> /dev/null; echo "bench T17 default rc $?" | tee -a $out/status
+python bench.py --config3 --no-strict --no-fp8 --no-cpu-baseline --no-pnp --no-h2d --no-inline-counters --no-trained-like --no-latency > $out/bench_config3.json 2> $out/bench_config3.err; echo "bench config3 rc $?" | tee -a $out/status
+python bench.py --prec f16c8_qk16 --views 17 --no-strict --no-fp8 --no-cpu-baseline --no-pnp --no-h2d --no-inline-counters --no-trained-like --no-latency > $out/bench_T17_default.json 2> /dev/null; echo "bench T17 default rc $?" | tee -a $out/status
 python - <<PY
 import json
 j=json.loads(open('$out/bench_default.json').read().strip().splitlines()[-1]); s=j['strict']; f=j.get('fp8',{})
