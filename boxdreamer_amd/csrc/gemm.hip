@@ -678,7 +678,8 @@ inline bool uses_pc192(const bd_gemm_args& a, int ns, int esz, int cus) {
     if (a.rms_wq) return true;       // a fused q/k RMSNorm pins the tile shape for EVERY batch size: a sample's q, k must not
                                      // depend on whether its batch filled the CUs (bit-exact batch independence is tested)
     if (a.N % 192 || a.M < 1024) return false;
-    const int64_t t192 = (int64_t)((a.M + 255) / 256) * (a.N / 192);
+    // (sub-batch lanes enqueue this launch once per lane, side by side: the round their tiles fill is the round of all of them)
+    const int64_t t192 = (int64_t)((a.M + 255) / 256) * (a.N / 192) * bd_concurrent_launches();
     // (0.75: DINOv2's N = 768 GEMMs at M = 50112 are 784 tiles = 3.06 rounds, fill 0.77.  One batch at a time the persistent kernel
     // is then +1.8 % on the step against the one-tile kernels' hybrid split; with two batches in flight -- the other batch's kernels
     // run on the CUs this kernel's tail leaves idle -- +5 %: 1221 -> 1282 poses/s same box.)
