@@ -240,15 +240,19 @@ def planes(prec) -> int:
 
 
 AUTO_LANES_MIN_VIEWS = 24      # one batch runs as two sub-batch lanes from this many (sample, view) images on (profiles/r4_subbatch_lanes.md)
+# ... earlier in the classes whose small launches were re-measured in round 5 (profiles/r5_small_experiments.md: lanes at batch 2 / 3):
+# bf16 / f16 from batch 2 at T = 6 (-7.5 % / -4 % per step), the F16C8 class from batch 3 (-6 %; at batch 2 two lanes cost 9 %)
+AUTO_LANES_MIN_VIEWS_BY_CLASS = {PREC_BF16: 12, PREC_F16: 12, PREC_F16C8: 18}
 
 
 def resolve_lanes(setting, views: int, samples: int, prec=None) -> int:
     """Sub-batch lanes of one whole-path call (include/boxdreamer_hip.h, ABI v6+): `setting` is "auto" or 1..4; `views` = images of
     the call (B x T), `samples` = the units the batch can be cut at.  Bit-identical results for every value.  "auto": two lanes from
-    AUTO_LANES_MIN_VIEWS images on, except in the e4m3 class, whose half-batch GEMMs lose more than the filled tail rounds win
+    AUTO_LANES_MIN_VIEWS images on (per class: AUTO_LANES_MIN_VIEWS_BY_CLASS), except in the e4m3 class, whose half-batch GEMMs lose more than the filled tail rounds win
     (measured: -2.7 % at batch 64, -4 % at batch 32; 16-bit classes +2 ... +9 %)."""
     if setting in (None, "auto"):
-        n = 2 if views >= AUTO_LANES_MIN_VIEWS and not (prec is not None and operand_prec(prec) == PREC_FP8) else 1
+        cls = operand_prec(prec) if prec is not None else None
+        n = 2 if views >= AUTO_LANES_MIN_VIEWS_BY_CLASS.get(cls, AUTO_LANES_MIN_VIEWS) and cls != PREC_FP8 else 1
     else:
         n = int(setting)
         if not 1 <= n <= 4:

@@ -476,6 +476,10 @@ def test_sub_batch_lane_resolution():
     assert _lib.resolve_lanes(4, 24, 3) == 3 and _lib.resolve_lanes(1, 1000, 100) == 1 and _lib.resolve_lanes("2", 12, 2) == 2
     assert _lib.resolve_lanes("auto", 64 * 6, 64, "fp8") == 1 and _lib.resolve_lanes(2, 64 * 6, 64, "fp8") == 2     # e4m3 class: auto stays at one
     assert _lib.resolve_lanes("auto", 32 * 6, 32, "f16c8_qk16") == 2 and _lib.resolve_lanes("auto", 32 * 6, 32, "bf16") == 2
+    # per-class thresholds (round 5): bf16 / f16 from 12 views, the F16C8 class from 18, the others from 24
+    assert [_lib.resolve_lanes("auto", B * 6, B, "bf16") for B in (1, 2, 3, 4)] == [1, 2, 2, 2]
+    assert [_lib.resolve_lanes("auto", B * 6, B, "f16c8_qk16") for B in (1, 2, 3, 4)] == [1, 1, 2, 2]
+    assert [_lib.resolve_lanes("auto", B * 6, B, "bf16x3") for B in (1, 2, 3, 4)] == [1, 1, 1, 2]
     for bad in (0, 5, -1):
         with pytest.raises(ValueError):
             _lib.resolve_lanes(bad, 100, 100)
