@@ -683,7 +683,9 @@ inline bool uses_pc192(const bd_gemm_args& a, int ns, int esz, int cus) {
     // (0.75: DINOv2's N = 768 GEMMs at M = 50112 are 784 tiles = 3.06 rounds, fill 0.77.  One batch at a time the persistent kernel
     // is then +1.8 % on the step against the one-tile kernels' hybrid split; with two batches in flight -- the other batch's kernels
     // run on the CUs this kernel's tail leaves idle -- +5 %: 1221 -> 1282 poses/s same box.)
-    return (double)t192 / (double)(((t192 + cus - 1) / cus) * cus) >= 0.75;       // last-round occupancy of the CUs
+    // Round 5 re-measured the threshold over batch sizes 2 ... 32 with the lanes' tiles counted together (profiles/r5_small_experiments.md):
+    // 0.45 is never slower than 0.75 and 5-11 % faster at batch 5, 6, 12, 14 (0.35 loses 2 % at batch 3).
+    return (double)t192 / (double)(((t192 + cus - 1) / cus) * cus) >= 0.45;       // occupancy of the CUs over the launch's rounds
 }
 // a fused q/k RMSNorm needs: 16-bit output of a plain Linear, N = 3 x heads x 96, row-identity output map, and N a multiple of
 // the 192-column workgroup tile: with an odd head count (N = 288 h, h odd) the last column tile's second wave tile would lie
