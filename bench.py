@@ -26,6 +26,7 @@ import json
 import os
 import signal
 import statistics
+import subprocess
 import sys
 import threading
 import time
@@ -210,9 +211,12 @@ def init_dist(args):
                          f"`python bench.py --gpus {world}` (it spawns the ranks itself) or matching torchrun arguments")
     dist = None
     PROGRESS["line"].update(n_gpus=world)
-    if world > 1:
+    if world > 1 or getattr(args, "force_dist", False):
+        # (--force-dist: the SAME process-group / collective path at world size 1 -- the one-GPU box's only way to execute RCCL)
         import datetime
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # a finite collective timeout: a rank that died must surface as an error on the others, not as a hang
@@ -224,6 +228,59 @@ def init_dist(args):
         if rank == 0 and not _WATCH_SIGTERM:
             signal.signal(signal.SIGTERM, _on_sigterm)      # torch.distributed.run terminates the survivors when a rank fails
     return world, rank, local_rank, dist
+
+
+def rccl_probe(args) -> None:
+    """Child of `rccl_world1_block` (under torch.distributed.run, one rank): the N > 1 sweep's process-group path executed on RCCL at
+    world size 1 -- init_process_group("nccl", device_id=...), the polled barrier, the corner all-gather on a device tensor, the
+    float64 timing gather -- and ONE JSON line with what the collective layer saw.  Replaces the reference's pickle + gloo gather
+    (/root/reference/src/utils/comm.py:84-92, 179-219)."""
+    from boxdreamer_amd.dist import gather_corners, gather_corners_ragged
+    args.force_dist, args.backend = True, "nccl"
+    _, _, local_rank = dist_env()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    t0 = time.perf_counter()
+    world, rank, _, dist = init_dist(args)
+    kp = torch.arange(32 * 16, dtype=torch.float32, device=device).reshape(32, 8, 2)
+    out = gather_corners(kp, world)                 # the first collective creates the communicator
+    torch.cuda.synchronize()
+    init_s = time.perf_counter() - t0
+    ok = bool(torch.equal(out, kp))
+    ragged_ok = bool(torch.equal(gather_corners_ragged(kp[:29].clone(), 29), kp[:29]))
+    lat = gather_latency_ms(kp, world, dist, gather_corners, reps=200)
+    dt, per_rank, _ = timed_steps(lambda: gather_corners(kp, world), 20, 3, world, dist, interruptible_sync(device), device)
+    if rank == 0:
+        print(json.dumps({"rccl_probe": True, "backend": dist.get_backend(), "world_size_seen_by_the_collective": dist.get_world_size(),
+                          "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                          "device": torch.cuda.get_device_name(device), "gather_ok": ok, "ragged_gather_ok": ragged_ok,
+                          "corner_allgather_ms": round(lat, 4), "init_plus_first_collective_s": round(init_s, 3),
+                          "timed_steps_ms_per_step": round(dt / 20 * 1e3, 4), "per_rank": len(per_rank),
+                          "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def rccl_world1_block(timeout_s: float = 240.0) -> dict:
+    """Run `rccl_probe` under the launcher the N > 1 sweep uses (torch.distributed.run, --nproc-per-node 1) and return its line."""
+    port = str(free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__), "--rccl-probe"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"executed": False, "error": f"timed out after {timeout_s:.0f} s"}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and "rccl_probe" in l]
+    if r.returncode != 0 or not lines:
+        return {"executed": False, "rc": r.returncode, "error": (r.stderr or r.stdout)[-600:]}
+    j = json.loads(lines[-1])
+    j.update(executed=True, wall_s=round(time.perf_counter() - t0, 1),
+             what="the sweep's process-group path on RCCL at world size 1 (one GPU per box here): same launcher, backend, device_id, "
+                  "barrier and all_gather_into_tensor calls as --gpus N; not a scaling figure")
+    return j
 
 
 # ------------------------------------------------------------------------------------------------ failure reporting
@@ -291,18 +348,18 @@ def timed_steps(step, steps: int, warmup: int, world: int, dist, sync, device=No
     out = None
     for _ in range(warmup):
         out = step()
-    if world > 1:
+    if dist is not None:
         barrier(dist, device)
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
     sync()
-    if world > 1:
+    if dist is not None:
         barrier(dist, device)
     dt = time.perf_counter() - t0
     per_rank = [dt]
-    if world > 1:
+    if dist is not None:
         on_host = device is None or dist.get_backend() == "gloo"      # (gloo gathers host tensors only: CPU plumbing / --single-device-test)
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if on_host else device)
         gathered = [torch.zeros_like(t) for _ in range(world)]
@@ -742,7 +799,7 @@ class ModeRun:
                     print(f"bench: second in-flight lane not available ({type(e).__name__}: {e}); timing one batch at a time", file=sys.stderr)
                     break
                 self.lanes.append({"g": g2, "s": torch.cuda.Stream(device=device), "done": torch.cuda.Event(), "free": torch.cuda.Event()})
-            if world > 1:           # every rank must time the same number of lanes (the single-stream leg has its own barriers)
+            if dist is not None:    # every rank must time the same number of lanes (the single-stream leg has its own barriers)
                 n = torch.tensor([len(self.lanes)], dtype=torch.int32, device=device)
                 dist.all_reduce(n, op=dist.ReduceOp.MIN)
                 self.lanes = self.lanes[: int(n.item())]
@@ -783,7 +840,7 @@ class ModeRun:
 
     def step_single(self):
         kp = self.graphed.replay()[1] if self.graphed is not None else self.eager()
-        return self.gather(kp, self.world) if self.world > 1 else kp
+        return self.gather(kp, self.world) if self.dist is not None else kp
 
     def step(self):
         if len(self.lanes) <= 1:
@@ -795,7 +852,7 @@ class ModeRun:
             ln["s"].wait_event(ln["free"])           # the lane's previous corners have been gathered / consumed
             kp = ln["g"].replay()[1]
             ln["done"].record(ln["s"])
-        if self.world > 1:                           # the one collective of the sweep stays on the main stream, in batch order
+        if self.dist is not None:                    # the one collective of the sweep stays on the main stream, in batch order
             main.wait_event(ln["done"])
             out = self.gather(kp, self.world)
             ln["free"].record(main)
@@ -902,7 +959,7 @@ def measure_mode(prec, args, device, world, rank, dist, images, bbox, mask, weig
     from boxdreamer_amd import _lib
     lib = _lib.load()
     run = ModeRun(prec, args, device, world, rank, dist, images, bbox, mask, weights)
-    sync = torch.cuda.synchronize if world == 1 else interruptible_sync(device)
+    sync = torch.cuda.synchronize if dist is None else interruptible_sync(device)
     B, T = run.B, run.T
     sub_lanes = run.effective_lanes()
     one_lane = None
@@ -1166,6 +1223,12 @@ def main():
                     help="TEST ONLY: every rank uses cuda:0 and the collectives go through gloo -- exercises the whole N > 1 bench flow "
                          "(sharded seeds, lane agreement, barriers, corner gather, failure report) with the real kernels on a 1-GPU box; "
                          "not a measurement (the ranks share one GPU) and not RCCL")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run every collective of the sweep (barriers, the corner all-gather, the per-rank "
+                         "timing gather) even at world size 1: what a one-GPU box can execute of the RCCL path (tests/test_gpu_rccl.py, the "
+                         "`rccl_world1` block of the default line)")
+    ap.add_argument("--rccl-probe", action="store_true", help=argparse.SUPPRESS)        # child of rccl_world1_block
+    ap.add_argument("--no-rccl-probe", action="store_true", help="skip the `rccl_world1` block of the default single-GPU line")
     ap.add_argument("--dry-run", action="store_true",
                     help="print the exact launch command + environment `--gpus N` turns into (JSON) and exit")
     ap.add_argument("--dist-timeout", type=int, default=600, help="collective timeout in seconds (a dead rank must not hang the others)")
@@ -1186,6 +1249,8 @@ def main():
     args = ap.parse_args()
 
     maybe_respawn(args)
+    if args.rccl_probe:
+        return rccl_probe(args)
     if args.counter_child:
         return counter_child(args)
     if args.measure_counters:
@@ -1253,7 +1318,7 @@ def run(args):
     main_res = measure_mode(prec, args, device, world, rank, dist, images, bbox, mask)
     line = None
     rank_devices = None
-    if world > 1:              # every rank reports the device it ran on (an object collective: all ranks take part)
+    if dist is not None:       # every rank reports the device it ran on (an object collective: all ranks take part)
         rank_devices = [None] * world
         dist.all_gather_object(rank_devices, f"rank {rank}: {torch.cuda.get_device_name(device)} (cuda:{device.index})")
     if rank == 0:
@@ -1284,14 +1349,14 @@ def run(args):
         if "single_stream" in main_res:
             line["single_stream"] = main_res["single_stream"]
             line["value_single_stream"] = main_res["single_stream"]["value"]       # the batch as ONE lane on one stream (rounds 1-3's step)
-        if world > 1:          # what the collective layer itself saw (not the CLI argument): the first SCALE record must prove N ranks
+        if dist is not None:   # what the collective layer itself saw (not the CLI argument): the first SCALE record must prove N ranks
             names = rank_devices
             line["distributed"] = {"backend": dist.get_backend(), "world_size_seen_by_the_collective": dist.get_world_size(),
                                    "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None,
                                    "devices": names}
         PROGRESS["line"] = dict(line)
     PROGRESS["stage"] = "corner all-gather latency"
-    if world > 1:
+    if dist is not None:
         lat = gather_latency_ms(main_res["run"].kp_all, world, dist, main_res["run"].gather, sync=interruptible_sync(device))
         if rank == 0:
             line["corner_allgather_ms"] = round(lat, 4)
@@ -1300,6 +1365,8 @@ def run(args):
     PROGRESS["stage"] = "parity / side measurements"
     if rank == 0:
         run = main_res["run"]
+        if world == 1 and dist is None and not args.no_rccl_probe and not args.cache_refs and B == 32 and T == 6:
+            line["rccl_world1"] = rccl_world1_block()
         if not args.no_parity:
             line["parity"] = parity_probe(prec, T, device, (run.enc, run.dec) if B >= 2 else None)   # a captured B = 1 path is frozen
             line["parity_meets_tolerance"] = line["parity"]["meets_tolerance"]
@@ -1476,7 +1543,7 @@ def run(args):
                                     parity_mode_counters_measured_in_this_run=srf.get("counters_measured_in_this_run"))
         PROGRESS["printed"] = True
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

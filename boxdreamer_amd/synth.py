@@ -300,7 +300,8 @@ def make_batch(seed: int = 7, B: int = 1, T: int = 2, size: int = 224,
     (/root/reference/src/models/BoxDreamerModel.py:193-215, 268-270, 364).
 
     images: U[0,1) with a zeroed 16-px border band (the dataset masks background to 0);
-    bbox_feat: rendered from 8 seeded corners in [30, size-30)^2; query_idx = T-1.
+    bbox_feat: rendered from 8 seeded corners in [m, size-m)^2 with m = 30 px at 224 (scaled with `size`: a fixed
+    30-px margin is an EMPTY range at 56 px and rendered NaN maps there); query_idx = T-1.
     Values are rounded through `quantize` (the dataset casts every tensor to the run
     precision, /root/reference/src/datasets/base.py:715-752) and returned in `dtype`."""
     img = uniform_np("images", (B, T, 3, size, size), 0.0, 1.0, seed)
@@ -309,8 +310,11 @@ def make_batch(seed: int = 7, B: int = 1, T: int = 2, size: int = 224,
     img[..., -band:, :] = 0.0
     img[..., :, :band] = 0.0
     img[..., :, -band:] = 0.0
-    corners = uniform_np("corners", (B, T, 8, 2), 30.0, float(size - 30), seed)
+    margin = 30.0 * size / 224.0                      # == 30.0 exactly at the default size (golden checksums unchanged)
+    corners = uniform_np("corners", (B, T, 8, 2), margin, float(size) - margin, seed)
     heat = corner_heatmaps_np(corners, size)
+    if not np.isfinite(heat).all():
+        raise ValueError(f"synth.make_batch(seed={seed}, size={size}): a corner coincides with the box centroid (0/0 in the renderer)")
 
     def q(a):
         t = torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))

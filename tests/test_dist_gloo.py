@@ -24,7 +24,7 @@ def _worker(rank, world, port, n_total):
         rg = gather_corners_ragged(full[lo:hi].clone(), n_total)
         assert torch.equal(rg, full)
         # a sharded batch dict keeps per-sample alignment
-        data = synth.make_batch(5, B=4, T=2, size=28)
+        data = synth.make_batch(5, B=4, T=2, size=56)
         mine = shard_batch(data, rank, world)
         marker = mine["bbox_proj_crop"][:, 0].contiguous()                 # (B_local, 8, 2)
         allm = gather_corners(marker, world)

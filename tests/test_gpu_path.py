@@ -234,8 +234,10 @@ def test_other_crop_sizes_and_view_counts(hip, size, T, B, prec):
     assert heat.shape == (B, 8, size, size)
     assert (dec.last_logits.cpu() - o["logits"]).abs().max().item() <= 1e-3
     assert (heat.cpu() - o["heat"]).abs().max().item() <= 1e-3
-    same = (idx.cpu().long().sort(-1)[0] == o["topk_idx"].sort(-1)[0]).all(-1).float().mean().item()
-    assert same >= 0.9
+    assert torch.isfinite(data["bbox_feat"]).all()          # (round 5's synth rendered NaN maps at 56 px: an empty corner range)
+    err = (dec.last_logits.cpu() - o["logits"]).abs().max().item()
+    assert_identical_topk_sets(idx.cpu().long(), o, err, f"size{size}_T{T}_B{B}/{prec}")
+    assert torch.equal(kp.cpu(), o["corners_px"]) or (kp.cpu() - o["corners_px"]).abs().max().item() <= 1e-3
 
 
 def test_fp8_mode_restated_tolerance(hip):
