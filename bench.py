@@ -1065,6 +1065,57 @@ def h2d_inclusive(run: "ModeRun", steps: int) -> dict:
             "how": "measured: pinned host buffers, copy stream + 2 device buffer sets, events between copy and compute"}
 
 
+def facade_block(args, device, one: dict, prec: str, reference_value: float | None) -> dict:
+    """the throughput of the surface the north_star says to keep -- `boxdreamer_amd.model.BoxDreamer(config).eval()(batch)`,
+    what callers of `self.BoxDreamer(batch)` get (/root/reference/src/lightning/BoxDreamer_lightning_model.py:228, src/demo/demo.py:1501-1506)
+    from INTEGRATION.md's 3-line patch: the configs[1] batch dict in, corners + host PnP out, default mode, bf16 inputs.  Eager (every launch
+    from the host) and with `hip_graph: true` (the step replayed from one captured graph behind the facade); the constructor's `config` is the
+    reference's own YAML as data (tests/golden/model_modules_config.json)."""
+    import copy
+    from boxdreamer_amd.model import BoxDreamer
+    path = os.path.join(ROOT, "tests", "golden", "model_modules_config.json")
+    if not os.path.exists(path):
+        return {"skipped": "tests/golden/model_modules_config.json (the reference's YAML as data) is not in this tree"}
+    bsd, dsd = state_dicts("plain")
+    B, T = one["images"].shape[:2]
+    batch = {k: ((v.to(torch.bfloat16) if v.is_floating_point() else v).to(device) if torch.is_tensor(v) else v) for k, v in one.items()}
+    out, res = {}, {}
+    for tag, graph in (("eager", False), ("hip_graph", True)):
+        mods = copy.deepcopy(json.load(open(path))["modules"])
+        mods["decoder"].update(num_decoder_layers=12, hip_precision=prec)
+        mods["encoder"]["dino"]["cfg"].update(state_dict=dsd, hip_precision=prec)
+        mods["hip_graph"] = graph
+        model = BoxDreamer({"modules": mods})
+        model.load_state_dict({"decoder." + k: v for k, v in bsd.items()}, strict=True)
+        model = model.to(device).eval()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(max(2, args.warmup)):      # (the first forward runs the load-time calibration; with hip_graph also the capture)
+                ret = model(dict(batch))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ret = model(dict(batch))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[tag] = ret
+        res[tag] = {"poses_per_s": round(B * args.steps / dt, 2), "ms_per_forward": round(dt / args.steps * 1e3, 3)}
+        if reference_value:
+            res[tag]["vs_parity_mode_value"] = round(B * args.steps / dt / reference_value, 4)
+        syncs, solver, lanes = list(model.host_syncs_per_forward or []), ret.get("pose_solver"), ret["hip_precision"].get("sub_batch_lanes")
+        del model
+        torch.cuda.empty_cache()
+    same = all(torch.equal(out["eager"][k], out["hip_graph"][k]) for k in ("pred_bbox", "pred_poses", "regression_boxes", "pred_corners_px"))
+    return {"what": "BoxDreamer(config).eval()(batch) on the configs[1] dict (1 query + 5 refs, batch %d, bf16 tensors on the device): encoder + decoder + "
+                    "corner decode + ONE D2H + host PnP + the dict's outputs, per call; K = %d calls back to back" % (B, args.steps),
+            "mode": prec, "eager": res["eager"], "hip_graph": res["hip_graph"], "poses_per_s": res["hip_graph"]["poses_per_s"],
+            "outputs_bit_identical_eager_vs_graph": bool(same), "sub_batch_lanes": lanes, "pose_solver": solver,
+            "host_syncs_per_forward": syncs,
+            "not_overlapped": "the host PnP of batch i runs before the call returns (pred_poses is part of the returned dict); "
+                              "`pnp_inclusive` shows what overlapping it with batch i + 1 buys a caller that defers it"}
+
+
 def _hwmon_of(device) -> str | None:
     """hwmon directory (power1_input / power1_cap / freq1_input) of the amdgpu card behind a HIP device, matched by PCI address."""
     import glob
@@ -1213,6 +1264,7 @@ def main():
     ap.add_argument("--no-fp8", action="store_true", help="skip the configs[4] leg (fp8 Linears, batch 64) of the default single-GPU run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-facade", action="store_true", help="skip the `facade` block (BoxDreamer.forward on the batch dict, eager and hip_graph) of the default single-GPU run")
     ap.add_argument("--no-pnp", action="store_true", help="skip the PnP-inclusive side measurement (host PnP, SURVEY 8d / 8f3)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-buffer (PCIe-inclusive) side measurement")
     ap.add_argument("--no-power", action="store_true", help="skip the board-power / clock probe (sysfs hwmon, 1.5 s of back-to-back steps per mode)")
@@ -1414,6 +1466,15 @@ def run(args):
                 line["value_meeting_parity_meets_tolerance"] = line["strict"]["parity"]["meets_tolerance"]
         sres["run"].close()
         del sres
+        # ---- the drop-in surface itself: BoxDreamer.forward on the batch dict, default mode
+        if rank == 0 and world == 1 and not args.no_facade and B == 32 and T == 6:
+            PROGRESS["stage"] = "facade (BoxDreamer.forward)"
+            torch.cuda.empty_cache()
+            try:
+                line["facade"] = facade_block(args, device, one, STRICT_PREC, line["strict"]["value"])
+                line["config"].update(facade_poses_per_s=line["facade"].get("poses_per_s"))
+            except Exception as e:               # noqa: BLE001 -- a side measurement must not take the line down
+                line["facade"] = {"error": f"{type(e).__name__}: {e}"}
     # ---- what the default mode costs on a checkpoint with outlier channels: the same step on the trained-like weight set, after the
     # load-time calibration promoted what it had to (one batch at a time; single GPU, default workload only)
     PROGRESS["stage"] = "strict mode on trained-like outlier weights"

@@ -102,7 +102,11 @@ class BETR(nn.Module):
         self._ws = None
         self._frozen_by = weakref.WeakSet()   # live GraphedPaths that captured raw pointers into _packed / _ws (graph.py)
         self.last_logits = None
-        self.validate_inputs = True   # one-hot check of `masks` costs a device sync; graph capture and bench turn it off
+        # one-hot check of `masks`: True = checked here (costs a device sync per forward); "deferred" = the verdict is left ON THE DEVICE in
+        # `self.mask_error` (a 0-dim bool tensor) for a caller that moves it to the host with data it transfers anyway (model.py: with the
+        # corners' one D2H); False = no check (graph capture does this by itself)
+        self.validate_inputs = True
+        self.mask_error = None
         self.recast_count = 0         # forwards that had to re-cast features lacking an operand copy (features.py)
 
     # -- packed-weight cache: invalidated by CONTENT, not by hooks.  The key carries every parameter's storage address
@@ -189,7 +193,10 @@ class BETR(nn.Module):
         if self.validate_inputs and not torch.cuda.is_current_stream_capturing():
             # the reference writes the query token through `pose_feat[masks] = ...` (betr.py:286-290), which fails unless
             # every sample marks exactly one view; argmax below would silently pick view 0 for an empty row
-            if not bool((masks.sum(dim=1) == 1).all()):
+            bad = (masks.sum(dim=1) != 1).any()
+            if self.validate_inputs == "deferred":
+                self.mask_error = bad                  # stays on the device; the caller raises (no sync here)
+            elif bool(bad):
                 raise ValueError("masks must mark exactly one query view per sample")
         query_idx = masks.to(torch.int32).argmax(dim=1).to(torch.int32).contiguous()
         np_ = _lib.planes(prec)

@@ -28,6 +28,7 @@ struct BlockBufs {
     void* qkv;       // 16-bit               [M, 3D]
     void* ao;        // 16-bit attention out [M, D]
     void* h;         // 16-bit MLP hidden    [M, 4D]
+    float* st;       // LayerNorm fold: (mean, M2) per row and 96-column group [M, D / 96, 2] fp32 (F16C8 family)
 };
 
 inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const bd_linear& lin, int64_t ldw, int N,
@@ -108,66 +109,112 @@ inline BlockPlan plan_block(const bd_block_weights& w, int wprec) {
     return p;
 }
 
+// ---- LayerNorm fold (ABI 8, include/boxdreamer_hip.h bd_gemm_args.ln_*): between a residual Linear (proj, fc2) and the Linear(s) behind the
+// next LayerNorm (fc1; the next block's QKV) of the F16C8 family the LayerNorm launch is replaced by (a) the residual Linear's epilogue
+// emitting the raw row as the F16C8 operand + per-wave-tile (mean, M2) pairs and (b) the consumer's epilogue applying the row statistics to a
+// product with the gain-folded weight (bd_block_weights.qkv_f / fc1_f / qkv16_f).  A hand-off folds only when EVERY launch on both sides has a
+// kernel form for it (bd_gemm_takes_ln_fold) -- un-promoted F16C8 Linears, D = 768; everything else keeps the bd_layernorm launch.  The
+// first LayerNorm of a stack (no residual Linear in front of it) and the stacks' final norms stay kernels.
+inline void ln_consumer(bd_gemm_args& g, const BlockBufs& b, const float* colsum, float eps) { g.ln_stats_in = b.st; g.ln_colsum = colsum; g.ln_eps = eps; }
+inline void ln_producer(bd_gemm_args& g, const BlockBufs& b, int64_t plane, int D) { g.ln_stats_out = b.st; g.ln_op_out = b.xn; g.ln_op_plane = plane; g.ln_op_ld = D; }
+// launch, or (check) only ask whether the launch's kernel form takes the fold fields that are set
+inline int gemm_or_check(bd_gemm_args& g, int cls, void* stream, bool check) {
+    if (check) return bd_gemm_takes_ln_fold(&g, cls) ? BD_OK : BD_ERR_SHAPE;
+    return bd_gemm(&g, cls, stream);
+}
+
 // LayerNorm 1 + QKV Linear (+ q/k RMSNorm) of a block on M rows: leaves q, k, v in b.qkv in the form the plan's attention reads.
 // BD_PREC_F16C8_QK16: the QKV Linear of a block whose q, k are RMS-normalised, split by output column (include/boxdreamer_hip.h):
 // LayerNorm 1 emits the F16C8 operand; launch 1 multiplies its f16 plane with the f16 copy of the q, k weight rows (one MFMA pass,
 // q/k RMSNorm fused where the launch allows it), launch 2 is the full F16C8 product for the v rows.  q, k, v land in one f16
 // [M, 3D] buffer exactly as the single-launch forms lay them out.
+// folded: LayerNorm 1 is folded -- b.xn / b.st already hold the raw operand copy and the row statistics of b.x (the previous block's fc2
+// wrote them); check: launch nothing, return BD_OK iff every launch of the folded form has a kernel form.
 int qkv_stage(const bd_block_weights& w, const BlockPlan& p, const BlockBufs& b, int M, int D, int heads, float ln_eps, float rms_eps,
-              void* stream) {
+              void* stream, bool folded = false, bool check = false) {
     const int hd = D / heads;
     const int64_t pD = (int64_t)M * D, p3D = (int64_t)M * 3 * D;
     bool rms_fused = false;
     if (p.qk16) {
-        BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16C8, stream));
+        if (!folded) BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, BD_PREC_F16C8, stream));
         {
-            bd_gemm_args g = gemm_args(b.xn, D, 0, w.qkv16, D, 2 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);      // rows [0, 2D) of the f16 copy
+            bd_gemm_args g = gemm_args(b.xn, D, 0, folded ? w.qkv16_f : w.qkv16, D, 2 * D, b.qkv, 3 * D, 0, 0, M, D, BD_ACT_NONE);      // rows [0, 2D) of the f16 copy
             g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps; g.rms_parts = 2;
             rms_fused = hd == 96 && bd_gemm_fuses_qk_rmsnorm(&g, BD_PREC_F16);
             if (!rms_fused) { g.rms_wq = g.rms_wk = nullptr; g.rms_parts = 0; }
-            BD_TRY(bd_gemm(&g, BD_PREC_F16, stream));
+            if (folded) ln_consumer(g, b, w.qkv16_s, ln_eps);
+            BD_TRY(gemm_or_check(g, BD_PREC_F16, stream, check));
         }
         {
-            bd_linear v = w.qkv;                                      // rows [2D, 3D) of the F16C8 weight: both planes advance by 2D rows
-            v.w = (const unsigned short*)w.qkv.w + (int64_t)2 * D * D;
-            v.b = w.qkv.b + 2 * D;
+            bd_linear v = folded ? w.qkv_f : w.qkv;                   // rows [2D, 3D) of the F16C8 weight: both planes advance by 2D rows
+            v.w = (const unsigned short*)v.w + (int64_t)2 * D * D;
+            v.b = v.b + 2 * D;
             bd_gemm_args g = gemm_args(b.xn, D, pD, v, D, D, (unsigned short*)b.qkv + 2 * D, 3 * D, 0, 2 /* f16 plane */, M, D, BD_ACT_NONE);
             g.w_plane = (int64_t)3 * D * D;                           // plane 1 still lies one FULL weight plane behind plane 0
-            BD_TRY(bd_gemm(&g, BD_PREC_F16C8, stream));
+            if (folded) ln_consumer(g, b, w.qkv_s + 2 * D, ln_eps);
+            BD_TRY(gemm_or_check(g, BD_PREC_F16C8, stream, check));
         }
     } else {
-        BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, p.c_qkv, stream));
-        bd_gemm_args g = gemm_args(b.xn, D, pD, w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, p.qkv_out, M, D, BD_ACT_NONE);
+        if (!folded) BD_TRY(bd_layernorm(b.x, D, w.ln1_w, w.ln1_b, ln_eps, b.xn, pD, nullptr, 0, M, D, 0, 0, 0, p.c_qkv, stream));
+        bd_gemm_args g = gemm_args(b.xn, D, pD, folded ? w.qkv_f : w.qkv, D, 3 * D, b.qkv, 3 * D, p3D, p.qkv_out, M, D, BD_ACT_NONE);
         if (w.q_norm_w && hd == 96) {            // q/k RMSNorm in the QKV epilogue where the launch allows it
             g.rms_wq = w.q_norm_w; g.rms_wk = w.k_norm_w; g.rms_eps = rms_eps;
             rms_fused = bd_gemm_fuses_qk_rmsnorm(&g, p.c_qkv);
             if (!rms_fused) g.rms_wq = g.rms_wk = nullptr;
         }
-        BD_TRY(bd_gemm(&g, p.c_qkv, stream));
+        if (folded) ln_consumer(g, b, w.qkv_s, ln_eps);
+        BD_TRY(gemm_or_check(g, p.c_qkv, stream, check));
     }
+    if (check) return BD_OK;
     if (w.q_norm_w && !rms_fused) BD_TRY(bd_qk_rmsnorm(b.qkv, p3D, w.q_norm_w, w.k_norm_w, rms_eps, M, heads, hd, p.aprec_in, stream));
     return BD_OK;
 }
 
-// x += proj(ao); x += fc2(gelu(fc1(LN2 x)))  on Mr rows (the whole stream, or the query view's compact rows of the last block)
-int proj_mlp_stage(const bd_block_weights& w, const BlockPlan& p, const BlockBufs& b, float* x, int Mr, int D, float ln_eps, void* stream) {
+// may LayerNorm 1 of block `w` be folded (its QKV launches on M rows)?
+inline bool ln1_foldable(const bd_block_weights& w, const BlockPlan& p, const BlockBufs& b, int M, int D, int heads, float ln_eps, float rms_eps) {
+    if (!w.qkv_f.w || !w.qkv_s || p.c_qkv != BD_PREC_F16C8 || D != 768) return false;
+    if (p.qk16 && (!w.qkv16_f.w || !w.qkv16_s)) return false;
+    return qkv_stage(w, p, b, M, D, heads, ln_eps, rms_eps, nullptr, true, true) == BD_OK;
+}
+
+// x += proj(ao); x += fc2(gelu(fc1(LN2 x)))  on Mr rows (the whole stream, or the query view's compact rows of the last block).
+// emit_next: the NEXT block's LayerNorm 1 is folded -- fc2 also writes the operand copy / row statistics of the rows it completes.
+int proj_mlp_stage(const bd_block_weights& w, const BlockPlan& p, const BlockBufs& b, float* x, int Mr, int D, float ln_eps, void* stream,
+                   bool emit_next = false) {
     const int64_t rD = (int64_t)Mr * D, r4D = (int64_t)Mr * 4 * D;
-    {
-        bd_gemm_args g = gemm_args(b.ao, D, rD, w.proj, D, D, x, D, 0, 1, Mr, D, BD_ACT_NONE);
-        g.resid = x; g.ldr = D;
-        BD_TRY(bd_gemm(&g, p.c_proj, stream));
+    bd_gemm_args gp = gemm_args(b.ao, D, rD, w.proj, D, D, x, D, 0, 1, Mr, D, BD_ACT_NONE);
+    gp.resid = x; gp.ldr = D;
+    bd_gemm_args g1 = gemm_args(b.xn, D, rD, w.fc1, D, 4 * D, b.h, 4 * D, r4D, handoff_kind(p.c_fc1, p.c_fc2), Mr, D, BD_ACT_GELU);
+    // LayerNorm 2 folds when proj can emit and fc1 can apply
+    bool fold2 = false;
+    if (w.fc1_f.w && w.fc1_s && p.c_proj == BD_PREC_F16C8 && p.c_fc1 == BD_PREC_F16C8 && p.c_fc2 == BD_PREC_F16C8 && D == 768) {
+        bd_gemm_args cp = gp, c1 = gemm_args(b.xn, D, rD, w.fc1_f, D, 4 * D, b.h, 4 * D, r4D, 0, Mr, D, BD_ACT_GELU);
+        ln_producer(cp, b, rD, D);
+        ln_consumer(c1, b, w.fc1_s, ln_eps);
+        if (bd_gemm_takes_ln_fold(&cp, p.c_proj) && bd_gemm_takes_ln_fold(&c1, p.c_fc1)) { fold2 = true; gp = cp; g1 = c1; }
     }
-    BD_TRY(bd_layernorm(x, D, w.ln2_w, w.ln2_b, ln_eps, b.xn, rD, nullptr, 0, Mr, D, 0, 0, 0, p.c_fc1, stream));
-    {
-        bd_gemm_args g = gemm_args(b.xn, D, rD, w.fc1, D, 4 * D, b.h, 4 * D, r4D, handoff_kind(p.c_fc1, p.c_fc2), Mr, D, BD_ACT_GELU);
-        BD_TRY(bd_gemm(&g, p.c_fc1, stream));
-    }
+    BD_TRY(bd_gemm(&gp, p.c_proj, stream));
+    if (!fold2) BD_TRY(bd_layernorm(x, D, w.ln2_w, w.ln2_b, ln_eps, b.xn, rD, nullptr, 0, Mr, D, 0, 0, 0, p.c_fc1, stream));
+    BD_TRY(bd_gemm(&g1, p.c_fc1, stream));
     {
         bd_gemm_args g = gemm_args(b.h, 4 * D, r4D, w.fc2, 4 * D, D, x, D, 0, 1, Mr, 4 * D, BD_ACT_NONE);
         g.resid = x; g.ldr = D;
+        if (emit_next) ln_producer(g, b, rD, D);
         BD_TRY(bd_gemm(&g, p.c_fc2, stream));
     }
     return BD_OK;
+}
+
+// does the NEXT block's LayerNorm 1 fold behind this block's fc2 (M rows of the stream on both sides)?
+inline bool next_ln1_folds(const bd_block_weights& w, const BlockPlan& p, const bd_block_weights* next, int wprec, const BlockBufs& b, int M, int D,
+                           int heads, float ln_eps, float rms_eps) {
+    if (!next || p.c_fc2 != BD_PREC_F16C8 || D != 768) return false;
+    bd_gemm_args g = gemm_args(b.h, 4 * D, (int64_t)M * 4 * D, w.fc2, 4 * D, D, b.x, D, 0, 1, M, 4 * D, BD_ACT_NONE);
+    g.resid = b.x; g.ldr = D;
+    ln_producer(g, b, (int64_t)M * D, D);
+    if (!bd_gemm_takes_ln_fold(&g, p.c_fc2)) return false;
+    const BlockPlan pn = plan_block(*next, wprec);
+    return ln1_foldable(*next, pn, b, M, D, heads, ln_eps, rms_eps);
 }
 
 // One pre-LN transformer block: x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x))).
@@ -175,17 +222,22 @@ int proj_mlp_stage(const bd_block_weights& w, const BlockPlan& p, const BlockBuf
 // n_prefix > 0 (DINOv2: cls + registers lead every image's tokens) and prefix_queries == false: the block's prefix rows are never read
 // again (last encoder block), so their attention is skipped (bd_attention_prefix) -- proj and the MLP then run on stale attention
 // rows there, whose results nobody consumes (row-wise operators: nothing leaks into the patch rows).
+// ln1_folded (in): this block's LayerNorm 1 is folded (the previous block's fc2 emitted for it); returns through *next_folded whether the
+// next block's is (this block's fc2 then emitted).
 int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, int seq, int D, int heads, float ln_eps, float rms_eps,
-              int wprec, void* stream, int n_prefix = 0, bool prefix_queries = true) {
+              int wprec, void* stream, int n_prefix = 0, bool prefix_queries = true, bool ln1_folded = false,
+              const bd_block_weights* next = nullptr, bool* next_folded = nullptr) {
     const BlockPlan p = plan_block(w, wprec);
     const int hd = D / heads;
-    BD_TRY(qkv_stage(w, p, b, M, D, heads, ln_eps, rms_eps, stream));
+    BD_TRY(qkv_stage(w, p, b, M, D, heads, ln_eps, rms_eps, stream, ln1_folded));
     const float scale = 1.0f / sqrtf((float)hd);
     if (n_prefix > 0 && seq > n_prefix && !prefix_queries)
         BD_TRY(bd_attention_prefix(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)M * D, batch, seq, heads, hd, scale, n_prefix, 0, p.aprec, stream));
     else
         BD_TRY(bd_attention(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)M * D, batch, seq, heads, hd, scale, p.aprec, stream));
-    return proj_mlp_stage(w, p, b, b.x, M, D, ln_eps, stream);
+    const bool emit = next_ln1_folds(w, p, next, wprec, b, M, D, heads, ln_eps, rms_eps);
+    if (next_folded) *next_folded = emit;
+    return proj_mlp_stage(w, p, b, b.x, M, D, ln_eps, stream, emit);
 }
 
 // Last decoder block: its output is consumed for the query view only (betr.py:303), so only K/V need every token.
@@ -193,10 +245,10 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
 // compact [B*P, D] result; proj, LN2 and the MLP then run on B*P rows (1/T of the work).  Row-wise arithmetic is
 // unchanged, so the result is bit-identical to the full-width block.  xc: fp32 [B*P, D] compact residual stream.
 int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, float* xc, const int32_t* query_idx, int B, int T, int P,
-                              int D, int heads, float ln_eps, float rms_eps, int wprec, void* stream) {
+                              int D, int heads, float ln_eps, float rms_eps, int wprec, void* stream, bool ln1_folded = false) {
     const BlockPlan p = plan_block(w, wprec);
     const int hd = D / heads, M = B * T * P, Mq = B * P;
-    BD_TRY(qkv_stage(w, p, b, M, D, heads, ln_eps, rms_eps, stream));
+    BD_TRY(qkv_stage(w, p, b, M, D, heads, ln_eps, rms_eps, stream, ln1_folded));
     BD_TRY(bd_attention_q(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)Mq * D, B, T * P, heads, hd, 1.0f / sqrtf((float)hd), query_idx, P,
                           p.aprec, stream));
     BD_TRY(bd_gather_query_rows_f32(b.x, query_idx, xc, B, T, P, D, stream));
@@ -210,6 +262,7 @@ BlockBufs carve_block(Carver& c, int64_t M, int D, int np) {
     b.qkv = c.take((size_t)M * 3 * D * 2 * np);
     b.ao = c.take((size_t)M * D * 2 * np);
     b.h = c.take((size_t)M * 4 * D * 2 * np);
+    b.st = (float*)c.take((size_t)M * ((D + 95) / 96) * 2 * 4);
     return b;
 }
 
@@ -288,8 +341,13 @@ extern "C" int bd_encoder_forward(const bd_dino_weights* w, const void* images, 
         BD_TRY(bd_gemm(&g, c_pe, stream));
     }
     BD_TRY(bd_write_prefix_tokens(e.blk.x, w->prefix_tokens, n_images, tpi, w->n_prefix, D, stream));
-    for (int i = 0; i < w->depth; ++i)
-        BD_TRY(run_block(w->blocks[i], e.blk, Md, n_images, tpi, D, w->heads, w->ln_eps, 0.f, wprec, stream, w->n_prefix, i + 1 < w->depth));
+    bool folded = false;           // LayerNorm 1 of block i is folded behind block i-1's fc2 (never block 0's)
+    for (int i = 0; i < w->depth; ++i) {
+        bool next_folded = false;
+        BD_TRY(run_block(w->blocks[i], e.blk, Md, n_images, tpi, D, w->heads, w->ln_eps, 0.f, wprec, stream, w->n_prefix, i + 1 < w->depth,
+                         folded, i + 1 < w->depth ? &w->blocks[i + 1] : nullptr, &next_folded));
+        folded = next_folded;
+    }
     // final LayerNorm on the patch tokens only (vision_transformer.py:263-267); feats16 in the class the consumer's first Linear reads
     BD_TRY(bd_layernorm(e.blk.x, D, w->norm_w, w->norm_b, w->ln_eps, feats16, feats16_plane, feats32, D, Mp, D, P, tpi,
                         w->n_prefix, feats_prec, stream));
@@ -345,11 +403,16 @@ extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_fea
     }
     BD_TRY(bd_query_substitute(d.blk.x, d.rgb, w->pos_table, w->query_token, query_idx, B, T, P, D, stream));
     // K9: joint self-attention over all T*P tokens of a sample
-    for (int i = 0; i + 1 < w->depth; ++i)
-        BD_TRY(run_block(w->blocks[i], d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, wprec, stream));
+    bool folded = false;           // LayerNorm 1 of block i is folded behind block i-1's fc2 (never block 0's)
+    for (int i = 0; i + 1 < w->depth; ++i) {
+        bool next_folded = false;
+        BD_TRY(run_block(w->blocks[i], d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, wprec, stream, 0, true, folded,
+                         &w->blocks[i + 1], &next_folded));
+        folded = next_folded;
+    }
     // last block: query-view rows only past the K/V projection; d.t2 (dead since the adapter) holds the compact stream
     BD_TRY(run_last_block_query_only(w->blocks[w->depth - 1], d.blk, d.t2, query_idx, B, T, P, D, w->heads,
-                                     w->ln_eps, w->rms_eps, wprec, stream));
+                                     w->ln_eps, w->rms_eps, wprec, stream, folded));
     // K10: head on the query view's tokens (no final norm, betr.py:298-306)
     BD_TRY(bd_gather_query_tokens(d.t2, nullptr, d.qtok, (int64_t)Mq * D, B, 1, P, D, c_bp, stream));
     {

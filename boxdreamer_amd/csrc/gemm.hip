@@ -230,7 +230,9 @@ __global__ __launch_bounds__(WM * WN * 64, NSTG == 2 ? 2 : 1) void gemm_kernel_g
 // ~28 % of their time (profiles/r4_gemm_counters.md); the F16C8 kernel, whose 3-stage ring of 48-KiB stages fits, shows ~7 %.
 // DMA rows stay 128 bytes (round 3's deeper rings shortened them and lost).  The epilogue scratch (8 waves x 6 KiB) is the two operand
 // buffers the tile's last slab lived in -- rows 0-7 of a 16-row chunk in the W buffer, rows 8-15 in the A buffer (pc_epilogue: sc, sc_hi).
-template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NPW, int EP, int OUTK, bool GELU, int RING = 0>
+// LNF (round 6): the consumer side of the LayerNorm fold (include/boxdreamer_hip.h, bd_gemm_args.ln_*; gemm_f16c8.hip's header has the
+// mechanism) -- here for the one launch of the default mode this file serves: BETR's q, k columns (f16, fused q/k RMSNorm, RING 1).
+template <class T, int NS, int BK, int WM, int WN, int MI, int NI, int NPW, int EP, int OUTK, bool GELU, int RING = 0, bool LNF = false>
 __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const bd_gemm_args p) {
     bd_saturating_conversions();      // fp8 / f16 results saturate (bd_common.h: RANGE)
     typedef typename Op16<T>::vec8 frag_t;
@@ -254,7 +256,8 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
     constexpr int RA = NS * A_BYTES, RW = NS * W_BYTES;            // one slab's A / W image (all planes)
     constexpr int RING_BYTES = RING ? 3 * RA + 2 * RW : 2 * STAGE_BYTES;
     static_assert(RING == 0 || (EP != 0 && NCW * 8 * NI * 32 * 4 <= RW && NCW * 8 * NI * 32 * 4 <= RA), "split scratch: half a chunk per buffer");
-    constexpr int AUX_COLP = RING_BYTES, AUX_RMS = AUX_COLP + 4096, AUX_BYTES = EP == 0 ? 0 : 6144;
+    constexpr int AUX_COLP = RING_BYTES, AUX_RMS = AUX_COLP + 4096, AUX_ROWS = AUX_RMS + 2048, AUX_BYTES = EP == 0 ? 0 : (LNF ? 10240 : 6144);
+    static_assert(!LNF || (RING == 1 && EP != 0 && NPW * 64 >= TBM && sizeof(T) == 2), "LayerNorm fold: ring form, one producer lane per tile row");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[RING_BYTES + AUX_BYTES];
     // byte offset of slab g's A / W image inside the ring (ga = g % 3, gw = g % 2 in the asymmetric form; both = g & 1 otherwise)
     auto off_a = [](int ga) { return RING ? ga * RA : ga * STAGE_BYTES; };
@@ -336,6 +339,20 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 if (p.bias) glds16_s(off, (const unsigned char*)(p.bias + n0), lds_off + AUX_COLP + (slot & 1) * 2048);
                 if (sizeof(T) == 1 && p.wscale) glds16_s(off, (const unsigned char*)(p.wscale + n0), lds_off + AUX_COLP + (slot & 1) * 2048 + 1024);
             }
+            if constexpr (LNF) {
+                if (pw == 1) {        // the column sums s[n] travel in the (otherwise unused) scale slot
+                    const unsigned off = (unsigned)lane * 16 < (unsigned)(TBN * 4 - 16) ? (unsigned)lane * 16 : (unsigned)(TBN * 4 - 16);
+                    glds16_s(off, (const unsigned char*)(p.ln_colsum + n0), lds_off + AUX_COLP + (slot & 1) * 2048 + 1024);
+                }
+            }
+        };
+        f32x4 lnst[4] = {};                // LNF: the eight (mean, M2) pairs of this lane's row of the tile whose column vectors were issued last
+        auto load_row_stats = [&](int m0) {
+            int row = m0 + pw * 64 + lane;
+            row = row < M ? row : M - 1;
+            const f32x4* sp = (const f32x4*)(p.ln_stats_in + (int64_t)row * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lnst[q] = sp[q];
         };
 #ifdef BD_GEMM_PROBE
         unsigned probe_ts = 0;
@@ -387,14 +404,27 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
             auto fetch_a = [&]() { if (ca.t < t_end) { issue_a(ga, ca.m0, ca.kt); ga = ga == 2 ? 0 : ga + 1; advance(ca); } };
             auto fetch_w = [&]() {
                 if (cw.t < t_end) {
-                    if (cw.kt == 0) { issue_colp(cw.n0, tiles_w); ++tiles_w; }
+                    if (cw.kt == 0) {
+                        issue_colp(cw.n0, tiles_w);
+                        if constexpr (LNF) load_row_stats(cw.m0);      // plain loads, older than W(first slab): the counted vmcnt covers them
+                        ++tiles_w;
+                    }
                     issue_w(gw, cw.n0, cw.kt); gw ^= 1; advance(cw);
                 }
             };
             constexpr int YOUNG = NS * (PA / NPW);                 // pieces of one A image issued by this wave
             fetch_a(); fetch_w(); fetch_a();
-            int g = 0;
-            for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
+            int g = 0, tt = 0;
+            for (int t = t_begin + (bid >> 3); t < t_end; t += stride, ++tt) {
+                if constexpr (LNF) {
+                    // this tile's row statistics -> (rstd, -mean rstd) in the LDS side buffer (slot = tile parity; the consumers read the
+                    // other slot until barrier X above; the next tile's loads are issued by fetch_w at this tile's last slab)
+                    if (pw * 64 + lane < TBM) {
+                        const float2 rs = ln_rows_combine(lnst, p.ln_eps);
+                        *(float2*)(lds + AUX_ROWS + (tt & 1) * 2048 + (pw * 64 + lane) * 8) = rs;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
                 for (int kt = 0; kt < nk; ++kt, ++g) {
                     if (ca.g > g + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG) : "memory");     // A(g+1) may still fly
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -587,9 +617,10 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 const bool has_next = t + stride < t_end;
                 int nm0 = 0, nn0 = 0;
                 if (has_next) tile_origin(t + stride, nm0, nn0);
-                pc_epilogue<T, NS, EP, OUTK, GELU, MI>(p, acc, (float*)scratch, (float*)scratch_hi, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
+                pc_epilogue<T, NS, EP, OUTK, GELU, MI, LNF>(p, acc, (float*)scratch, (float*)scratch_hi, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
                                                   (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
-                                                  lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
+                                                  lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32),
+                                                  (const float*)(lds + (LNF ? AUX_ROWS : 0) + (ti & 1) * 2048), wm * (MI * 32));
             }
         }
         BD_PROBE_IF(g == nk, 62)
@@ -640,7 +671,11 @@ template <class T, int NS, int BK, int WM, int WN, int MI, int NI> void launch_p
 #define BD_PC_LAUNCH(EP_, OUTK_, GELU_) BD_PC_LAUNCH_R(EP_, OUTK_, GELU_, ((EP_) != 0 ? 1 : 0))
     constexpr int ALT = (NS == 2 && sizeof(T) == 2) ? OUT_F16 : (sizeof(T) == 1 ? OUT_BF16 : OUT_OPERAND);   // the one non-native 16-bit kind
     constexpr bool X2 = NS == 2 && std::is_same<T, _Float16>::value;     // split-f16 also emits split-bf16 planes (attention input)
-    if (ep == 3 && ring0_ep3) BD_PC_LAUNCH_R(3, OUT_F32, false, 0);
+    if (ln_fold_consumer(a)) {          // LayerNorm fold, consumer side: the f16 q, k launch of the default mode (bd_gemm_takes_ln_fold)
+        if constexpr (NS == 1 && std::is_same<T, _Float16>::value)
+            hipLaunchKernelGGL((gemm_kernel_pc<T, NS, BK, WM, WN, MI, NI, NPW, 2, OUT_OPERAND, false, 1, true>), g, b, 0, s, a);
+    }
+    else if (ep == 3 && ring0_ep3) BD_PC_LAUNCH_R(3, OUT_F32, false, 0);
     else if (ep == 3) BD_PC_LAUNCH(3, OUT_F32, false);
     else if (ep == 2 && outk == OUT_BF16X2) { if constexpr (X2) BD_PC_LAUNCH(2, OUT_BF16X2, false); }
     else if (ep == 2) { if (outk == OUT_OPERAND) BD_PC_LAUNCH(2, OUT_OPERAND, false); else BD_PC_LAUNCH(2, ALT, false); }
@@ -693,9 +728,22 @@ inline bool uses_pc192(const bd_gemm_args& a, int ns, int esz, int cus) {
 
 template <class T, int NS, int BK> void launch_one_tile(const bd_gemm_args& a, hipStream_t s, int kCUs);
 
+// LayerNorm fold in the classes of this file: the consumer side only, and only the f16 launch with the fused q/k RMSNorm (which pins the
+// persistent 256 x 192 kernel for every row count)
+template <class T, int NS> bool takes_ln_fold(const bd_gemm_args& a) {
+    if (ln_fold_producer(a)) return false;
+    if (!ln_fold_consumer(a)) return true;
+    if (!(NS == 1 && std::is_same<T, _Float16>::value)) return false;
+    int outk = 0;
+    bool gelu = false;
+    return ln_fold_consumer_ok(a) && a.rms_wq && rms_geometry_ok(a) && pc192_possible(a, NS, OpGeom<T>::ESZ) && a.out_f32 == OUT_OPERAND &&
+           pc_epilogue_kind<T, NS>(a, outk, gelu) == 2;
+}
+
 template <class T, int NS, int BK> int launch(const bd_gemm_args& a, hipStream_t s) {
     const int kCUs = cu_count();
     if (a.rms_wq && !(rms_geometry_ok(a) && pc192_possible(a, NS, OpGeom<T>::ESZ))) return BD_ERR_SHAPE;
+    if ((ln_fold_producer(a) || ln_fold_consumer(a)) && !takes_ln_fold<T, NS>(a)) return BD_ERR_SHAPE;
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     constexpr int ESZ_ = OpGeom<T>::ESZ;
     // 256 x 192 tiles (8 consumer waves of 64 x 96: 96 accumulator + 2 x 20 fragment registers fit the 168-VGPR budget
@@ -806,6 +854,17 @@ extern "C" int bd_gemm_fuses_qk_rmsnorm(const bd_gemm_args* args, int prec) {
         case BD_PREC_BF16X3: case BD_PREC_F16X3: return pc192_possible(*args, 2, 2) ? 1 : 0;
         case BD_PREC_FP8: return pc192_possible(*args, 1, 1) ? 1 : 0;
         case BD_PREC_F16C8: return wide_epilogue_ok(*args, 2) ? 1 : 0;
+        default: return 0;
+    }
+}
+
+extern "C" int bd_gemm_takes_ln_fold(const bd_gemm_args* args, int prec) {
+    if (!args) return 0;
+    const bd_gemm_args& a = *args;
+    if (!ln_fold_producer(a) && !ln_fold_consumer(a)) return 1;
+    switch (prec) {
+        case BD_PREC_F16: return takes_ln_fold<_Float16, 1>(a) ? 1 : 0;
+        case BD_PREC_F16C8: return bd_f16c8_takes_ln_fold(a) ? 1 : 0;
         default: return 0;
     }
 }

@@ -378,14 +378,35 @@ __device__ __forceinline__ float quad_sum(float x) {
     return x;
 }
 
+// the value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ unsigned dpp_xor1(unsigned x) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);
+}
+// all-reduce over 8 consecutive lanes (8k .. 8k+7): the quad sums, then the other quad of the half-row (DPP row_half_mirror: lane i <- 7 - i)
+__device__ __forceinline__ float oct_sum(float x) {
+    x = quad_sum(x);
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    return x;
+}
+
 // Epilogue of gemm_kernel_pc for the 64 x 96 wave tile (MI = 2, NI = 3), 16 rows per pass through this wave's 6-KiB scratch.
 //   colp: this tile's per-column vectors in LDS (bias at [0, 256), weight scale at [256, 512)), indexed by tile column
 //   rmsw: q weights at [0, 96), k weights at [256, 352)
 //   wcol: first column of the wave tile inside the workgroup tile;  (wm0, wn0): its global origin
-//   next: the wave tile origin of this workgroup's next tile (EP 3 pre-loads its residual), has_next = there is one
-template <class T, int NS, int EP, int OUTK, bool GELU, int MI = 2>
+//   next: the wave tile origin of this workgroup's next tile (EP 3 / 4 pre-load its residual), has_next = there is one
+// LayerNorm fold (ABI 8, bd_gemm_args.ln_*):
+//   EP 4 = EP 3 + the producer side: the registers that just left as an fp32 row piece (8 lanes x 12 values = the row's 96 columns) give
+//          (mean, M2) -- two 8-lane reductions -- stored by one lane at ln_stats_out[row][wave tile], and leave once more as the F16C8
+//          operand copy of the row (ln_op_out);
+//   LNF  = the consumer side: rowp = this tile's row statistics in LDS, (rstd, -mean rstd) per tile row (the producer waves combined the
+//          row's partial pairs, ln_rows_combine below), colp[256 ..] = the column sums s[n]; applied where the accumulators leave the
+//          registers: rstd * acc + (-mean rstd) * s[n] + bias[n].  wrow: first row of the wave tile inside the workgroup tile.
+template <class T, int NS, int EP, int OUTK, bool GELU, int MI = 2, bool LNF = false>
 __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)[MI][3], float* sc, float* sc_hi, const float* colp, const float* colp_next,
-                                            const float* rmsw, int wcol, int wm0, int wn0, int lane_, bool has_next, int nwm0, int nwn0) {
+                                            const float* rmsw, int wcol, int wm0, int wn0, int lane_, bool has_next, int nwm0, int nwn0,
+                                            const float* rowp = nullptr, int wrow = 0) {
+    static_assert(!LNF || (sizeof(T) == 2 && EP != 3 && EP != 4), "the LayerNorm fold's consumer side: 16-bit results of the 16-bit / F16C8 classes");
+    static_assert(EP != 4 || std::is_same<T, f16c8>::value, "the LayerNorm fold's producer side emits the F16C8 operand class");
     constexpr int COLS = 96;
     // The lane id is re-derived HERE from an opaque instruction pair, so that none of the epilogue's lane-dependent addressing can be
     // hoisted above the K loop, whose register budget (168) is full: hoisted, three of those values were spilled in the F16C8 / e4m3
@@ -402,8 +423,37 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
         bj[j] = p.bias ? colp[wcol + j * 32 + lrow] : 0.f;
         sj[j] = 1.f;
         if constexpr (sizeof(T) == 1) sj[j] = p.wscale ? colp[256 + wcol + j * 32 + lrow] : 1.f;
+        if constexpr (LNF) sj[j] = colp[256 + wcol + j * 32 + lrow];          // the column sums s[n] (their slot is the e4m3 class's scale slot)
     }
+    // LNF: (rstd, -mean rstd) of a chunk's eight register rows (the same address for the 32 lanes of a half-wave: LDS broadcasts), read as a
+    // block BEFORE the chunk's writes: interleaved, every read would wait for the writes in front of it (LDS operations return in order and
+    // the compiler cannot tell the two regions apart) -- measured ~3000 cycles per tile
+    float2 lnrs[LNF ? 8 : 1];
+    auto load_row_stats = [&](int i, int hc) {
+        if constexpr (LNF) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = hc * 8 + q;
+                lnrs[q] = *(const float2*)(rowp + 2 * (wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf));
+            }
+        }
+    };
+    load_row_stats(0, 0);
     auto to_scratch = [&](int i, int hc) {          // rows 16 hc .. 16 hc + 15 of 32-row block i: registers r with (r >> 2) in {2 hc, 2 hc + 1}
+        if constexpr (LNF) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = hc * 8 + q;
+                float* const dst = ((r >> 2) - hc * 2) == 0 ? sc : sc_hi;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    dst[((r & 3) + 4 * lhalf) * COLS + j * 32 + lrow] = fmaf(acc[i][j][r], lnrs[q].x, fmaf(lnrs[q].y, sj[j], bj[j]));
+            }
+            // the NEXT chunk's row statistics into the registers this chunk just released: they arrive under this chunk's read-back and
+            // stores (only the first chunk's reads, issued before the loop, are waited for)
+            if (i * 2 + hc + 1 < 2 * MI) load_row_stats((i * 2 + hc + 1) >> 1, (i * 2 + hc + 1) & 1);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -414,7 +464,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
                 dst[((r & 3) + 4 * lhalf) * COLS + j * 32 + lrow] = sizeof(T) == 1 ? fmaf(a, sj[j], bj[j]) : a + bj[j];
             }
     };
-    if constexpr (EP == 3) {
+    if constexpr (EP == 3 || EP == 4) {
         // fp32 rows: 8 lanes x 16 bytes = one 128-byte line per row and 32-column block; 8 rows per pass, 2 passes per chunk
         const int c4 = lane & 7, rsub = lane >> 3;
         const bool pre = has_next && p.resid != nullptr;
@@ -425,6 +475,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
                 for (int j = 0; j < 3; ++j) rsn[j] = colp_next[256 + wcol + j * 32 + lrow];
             }
         }
+        float keep_mean = 0.f, keep_m2 = 0.f;            // EP 4: the (mean, M2) pair of pass c4 of this lane's row group
 #pragma unroll
         for (int ih = 0; ih < 2 * MI; ++ih) {
             const int i = ih >> 1, hc = ih & 1;
@@ -458,7 +509,74 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
                         *(f32x4*)(op + cb * 32) = v[cb];
                     }
                 }
+                if constexpr (EP == 4) {
+                    // LayerNorm fold, producer side, on the registers that just left as fp32: the 8 lanes of a row hold its 96 values (3 x 4
+                    // each).  (mean, M2) by two 8-lane reductions on the VALU (DPP); lane c4 == pass keeps the pair, so that all eight passes
+                    // of the tile leave in ONE full-wave store at the end.  The F16C8 operand copy leaves in 16-byte (f16 plane) / 8-byte (lo8
+                    // plane) pieces: neighbouring lanes swap halves (DPP) so that the even lane of a pair owns 8 consecutive columns of block
+                    // 0 and the odd lane 8 of block 1; block 2's halves both go to the even lane.
+                    // (4- and 8-byte pieces -- f16c8_store4 -- cost 10 store instructions per pass against the 3 of the fp32 rows and made the
+                    // launch 31 us slower: the CU's vector-memory path is what the eight epilogues of a workgroup share.)
+                    const int pass = ih * 2 + t;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb) sum += (v[cb][0] + v[cb][1]) + (v[cb][2] + v[cb][3]);
+                    const float mean = oct_sum(sum) * (1.0f / 96.0f);
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float d = v[cb][e] - mean; m2 = fmaf(d, d, m2); }
+                    m2 = oct_sum(m2);
+                    if (c4 == pass) { keep_mean = mean; keep_m2 = m2; }
+                    unsigned hh[3][2], ll[3];
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb) {
+                        const float v4[4] = {v[cb][0], v[cb][1], v[cb][2], v[cb][3]};
+                        _Float16 h[4];
+                        float lo[4];
+                        f16c8_split<4>(v4, h, lo);
+                        typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+                        hh[cb][0] = __builtin_bit_cast(unsigned, (h2_){h[0], h[1]});
+                        hh[cb][1] = __builtin_bit_cast(unsigned, (h2_){h[2], h[3]});
+                        int l0 = 0;
+                        l0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], l0, false);
+                        l0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], l0, true);
+                        ll[cb] = (unsigned)l0;
+                    }
+                    const bool odd = c4 & 1;
+                    auto emit8 = [&](int row, int col, unsigned a0, unsigned a1, unsigned b0, unsigned b1, unsigned la, unsigned lb) {
+                        // 8 consecutive elements of row `row` starting at column `col` (col % 8 == 0): (a0, a1 | b0, b1) f16 pairs, (la | lb) lo8
+                        // (32-bit element offsets against wave-uniform bases: one address VGPR per store; the host checks M * ld < 2^31)
+                        if (row < M) {
+                            const unsigned e = (unsigned)row * (unsigned)p.ln_op_ld + (unsigned)col;
+                            const unsigned g8 = (e >> 3) & 3u;                                        // f16c8_lo_index, 32-bit
+                            const unsigned el = (e & ~31u) + (((g8 & 1u) << 4) | ((g8 >> 1) << 3));
+                            unsigned char* const b0p = (unsigned char*)p.ln_op_out;
+                            unsigned char* const b1p = b0p + 2 * p.ln_op_plane;
+                            *(u128*)(b0p + (size_t)(2u * e)) = (u128){a0, a1, b0, b1};
+                            *(uint2*)(b1p + (size_t)el) = make_uint2(la, lb);
+                        }
+                    };
+                    {   // blocks 0 / 1: the even lane sends its block-1 half and receives the odd lane's block-0 half, and vice versa
+                        const unsigned r0 = dpp_xor1(odd ? hh[0][0] : hh[1][0]), r1 = dpp_xor1(odd ? hh[0][1] : hh[1][1]), rl = dpp_xor1(odd ? ll[0] : ll[1]);
+                        const int col = wn0 + (odd ? 32 : 0) + (c4 >> 1) * 8;
+                        if (odd) emit8(gr, col, r0, r1, hh[1][0], hh[1][1], rl, ll[1]);
+                        else emit8(gr, col, hh[0][0], hh[0][1], r0, r1, ll[0], rl);
+                    }
+                    {   // block 2: the even lane of a pair takes both halves (the odd lane's store slots stay empty: 32 lanes x 16 / 8 bytes)
+                        const unsigned r0 = dpp_xor1(hh[2][0]), r1 = dpp_xor1(hh[2][1]), rl = dpp_xor1(ll[2]);
+                        if (!odd) emit8(gr, wn0 + 64 + (c4 >> 1) * 8, hh[2][0], hh[2][1], r0, r1, ll[2], rl);
+                    }
+                }
             }
+        }
+        if constexpr (EP == 4) {
+            // the eight passes' (mean, M2) pairs: lane (rsub, c4) holds pass c4 = (32-row block, 16-row chunk, 8-row pass) of row group rsub
+            static_assert(MI == 2, "eight passes, eight lanes per row");
+            const int c4 = lane & 7, rsub = lane >> 3;
+            const int row = wm0 + (c4 >> 2) * 32 + ((c4 >> 1) & 1) * 16 + (c4 & 1) * 8 + rsub;
+            if (row < M) *(float2*)((unsigned char*)p.ln_stats_out + (size_t)(((unsigned)row * (unsigned)(p.N / 96) + (unsigned)(wn0 / 96)) * 8u)) = make_float2(keep_mean, keep_m2);
         }
     } else if constexpr (EP == 1 && NS == 1 && sizeof(T) == 2 && OUTK == OUT_OPERAND) {
         // Plain bf16 / f16 result (optional GELU): rounded to 16 bits BEFORE the LDS round trip, two adjacent rows per dword
@@ -574,6 +692,34 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
 }
 
 
+// LayerNorm fold, consumer side: one PRODUCER-wave lane per tile row turns the row's eight (mean, M2) pairs -- one per 96 columns of the K = 768
+// row, written by the launch that produced the row (pc_epilogue EP 4) -- into (rstd, -mean rstd).  Chan's combination for equal counts, in a
+// fixed order: the result does not depend on which launch form or tile shape wrote or reads the pairs.
+__device__ __forceinline__ float2 ln_rows_combine(const f32x4 (&st)[4], float eps) {
+    const float m[8] = {st[0][0], st[0][2], st[1][0], st[1][2], st[2][0], st[2][2], st[3][0], st[3][2]};
+    const float q[8] = {st[0][1], st[0][3], st[1][1], st[1][3], st[2][1], st[2][3], st[3][1], st[3][3]};
+    float mean = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mean += m[i];
+    mean *= 0.125f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float d = m[i] - mean; m2 += q[i] + 96.0f * (d * d); }
+    const float rstd = rsqrtf(m2 * (1.0f / 768.0f) + eps);
+    return make_float2(rstd, -mean * rstd);
+}
+// host side: do these arguments ask for the fold, and are they well-formed for it (the kernel forms are checked by the launchers)
+inline bool ln_fold_producer(const bd_gemm_args& a) { return a.ln_stats_out != nullptr || a.ln_op_out != nullptr; }
+inline bool ln_fold_consumer(const bd_gemm_args& a) { return a.ln_stats_in != nullptr || a.ln_colsum != nullptr; }
+inline bool ln_fold_producer_ok(const bd_gemm_args& a) {
+    return a.ln_stats_out && a.ln_op_out && a.out_f32 == OUT_F32 && a.N == 768 && a.act == BD_ACT_NONE && !a.rms_wq && !a.addtab && a.rpg_in <= 0 &&
+           !a.wscale && a.ln_op_ld % 32 == 0 && a.ln_op_plane % 8 == 0 && (((uintptr_t)a.ln_op_out | (uintptr_t)a.ln_stats_out) & 15) == 0 &&
+           (int64_t)a.M * a.ln_op_ld < ((int64_t)1 << 30);        // (the epilogue addresses the copy with 32-bit byte offsets)
+}
+inline bool ln_fold_consumer_ok(const bd_gemm_args& a) {
+    return a.ln_stats_in && a.ln_colsum && a.K == 768 && a.N % 192 == 0 && a.out_f32 != OUT_F32 && !a.resid && !a.addtab && a.rpg_in <= 0 && !a.wscale &&
+           a.bias && (((uintptr_t)a.ln_stats_in | (uintptr_t)a.ln_colsum | (uintptr_t)a.bias) & 15) == 0;
+}
+
 // the wide (LDS-staged, 16-byte) epilogue needs 16-byte aligned rows: N % 8 == 0 and aligned leading dimensions / pointers
 inline bool wide_epilogue_ok(const bd_gemm_args& p, int ns) {
     return (p.N % 8 == 0) && (p.ldo % 8 == 0) && (((uintptr_t)p.out & 15) == 0) &&
@@ -624,3 +770,4 @@ inline int64_t pc192_main_rows(const bd_gemm_args& a, int cus) {
 
 // the F16C8 class has its own persistent kernel (gemm_f16c8.hip); every shape goes through it
 int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s);
+bool bd_f16c8_takes_ln_fold(const bd_gemm_args& a);

@@ -27,7 +27,12 @@ namespace {
 //     form (tests/test_gpu_ops.py::test_gemm_f16c8_small_form_rows_equal_the_large_form).  (A 128 x 96 form on 2 + 2 waves, two workgroups
 //     per CU -- the template takes it: <.., 2, 1, 2> -- is 17 % faster still on fc2 below 3072 rows and slower everywhere else:
 //     profiles/r5_f16c8_small_form.md.)
-template <int NSTAGE, int EP, int OUTK, bool GELU, int WM = 4, int WN = 2, int NPW = 4>
+//   * (round 6) the LayerNorm fold (include/boxdreamer_hip.h, bd_gemm_args.ln_*; epilogues in gemm_common.h).  EP 4: the fp32-residual
+//     epilogue also emits the rows' F16C8 operand copy and their per-wave-tile (mean, M2) pairs.  LNF: this launch's A operand is such
+//     a raw copy; one producer-wave lane per tile row loads the row's eight pairs with the tile's first slab (plain loads: they ride in
+//     FRONT of that slab's pieces, so the counted vmcnt covers them), combines them at the top of the tile and leaves (rstd, -mean rstd)
+//     in an LDS side buffer (double-buffered by tile parity) that the consumers' epilogue reads; the column sums travel like the bias.
+template <int NSTAGE, int EP, int OUTK, bool GELU, int WM = 4, int WN = 2, int NPW = 4, bool LNF = false>
 __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1) void gemm_kernel_pc_f16c8(const bd_gemm_args p) {
     constexpr int MI = 2, NI = 3, NCW = WM * WN;
     constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32, BK = 32;
@@ -43,7 +48,8 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
     // s_waitcnt vmcnt(PIECES) with expcnt / lgkmcnt left alone (gfx9 encoding: vmcnt [3:0] and [15:14], expcnt [6:4], lgkmcnt [11:8])
     constexpr int WAIT_ONE_SLAB = (PIECES & 15) | ((PIECES >> 4) << 14) | 0x70 | 0xF00;
     // side buffer behind the ring + scratch (gemm_kernel_pc): per-column vectors of the current / next tile, q / k RMSNorm weights
-    constexpr int AUX_COLP = 2 * STAGE + S2, AUX_RMS = AUX_COLP + 4096, AUX_BYTES = EP == 0 ? 0 : 6144;
+    constexpr int AUX_COLP = 2 * STAGE + S2, AUX_RMS = AUX_COLP + 4096, AUX_ROWS = AUX_RMS + 2048, AUX_BYTES = EP == 0 ? 0 : (LNF ? 10240 : 6144);
+    static_assert(!LNF || (EP != 0 && NPW * 64 >= TBM && NSTAGE == 3), "LayerNorm fold: one producer lane per tile row");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE + S2 + AUX_BYTES];   // stages at 0, STAGE, 2*STAGE; scratch at 2*STAGE
 
     bd_saturating_conversions();      // q8 images (K loop) and F16C8 / f16 results (epilogue) saturate instead of turning NaN / inf
@@ -113,6 +119,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
                 glds16_s(off, (const unsigned char*)p.rms_wk, lds_off + AUX_RMS + 1024);
             }
         }
+        f32x4 lnst[4] = {};                // LNF: the eight (mean, M2) pairs of this lane's row of the tile whose first slab was issued last
         auto issue_next = [&]() {
             if (it >= t_end) return;
             if constexpr (EP != 0) {
@@ -122,6 +129,17 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
                     if (pw == 0 && p.bias) {
                         const unsigned off = (unsigned)lane * 16 < (unsigned)(TBN * 4 - 16) ? (unsigned)lane * 16 : (unsigned)(TBN * 4 - 16);
                         glds16_s(off, (const unsigned char*)(p.bias + in0), lds_off + AUX_COLP + (itn & 1) * 2048);
+                    }
+                    if constexpr (LNF) {
+                        if (pw == 1 % NPW) {
+                            const unsigned off = (unsigned)lane * 16 < (unsigned)(TBN * 4 - 16) ? (unsigned)lane * 16 : (unsigned)(TBN * 4 - 16);
+                            glds16_s(off, (const unsigned char*)(p.ln_colsum + in0), lds_off + AUX_COLP + (itn & 1) * 2048 + 1024);
+                        }
+                        int row = im0 + pw * 64 + lane;
+                        row = row < M ? row : M - 1;
+                        const f32x4* sp = (const f32x4*)(p.ln_stats_in + (int64_t)row * 16);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) lnst[q] = sp[q];
                     }
                     ++itn;
                 }
@@ -146,7 +164,17 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
 #pragma unroll
         for (int i = 0; i < NSTAGE - 1; ++i) issue_next();
         int g = 0;
-        for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
+        int tt = 0;
+        for (int t = t_begin + (bid >> 3); t < t_end; t += stride, ++tt) {
+            if constexpr (LNF) {
+                // this tile's row statistics (their loads were issued with the tile's first slab, at least one slab ago; the next tile's
+                // loads are issued later in this tile's K loop).  Slot tt & 1: the consumers read slot (tt - 1) & 1 until barrier X above.
+                if (pw * 64 + lane < TBM) {
+                    const float2 rs = ln_rows_combine(lnst, p.ln_eps);
+                    *(float2*)(lds + AUX_ROWS + (tt & 1) * 2048 + (pw * 64 + lane) * 8) = rs;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             for (int kt = 0; kt < nk; ++kt) {
                 BD_PROBE_IF(g < 20, g * 3 + 2)
                 wait_landed(ig - g - 1);                  // slab g has landed (later slabs may still fly)
@@ -277,9 +305,10 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
             const bool has_next = t + stride < t_end;
             int nm0 = 0, nn0 = 0;
             if (has_next) tile_origin(t + stride, nm0, nn0);
-            pc_epilogue<f16c8, 2, EP, OUTK, GELU, 2>(p, acc, (float*)scratch, (float*)scratch + 8 * 96, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
+            pc_epilogue<f16c8, 2, EP, OUTK, GELU, 2, LNF>(p, acc, (float*)scratch, (float*)scratch + 8 * 96, (const float*)(lds + AUX_COLP + (ti & 1) * 2048),
                                                  (const float*)(lds + AUX_COLP + ((ti + 1) & 1) * 2048), (const float*)(lds + AUX_RMS), wn * (NI * 32), m0 + wm * (MI * 32), n0 + wn * (NI * 32),
-                                                 lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32));
+                                                 lane, has_next, nm0 + wm * (MI * 32), nn0 + wn * (NI * 32),
+                                                 (const float*)(lds + (LNF ? AUX_ROWS : 0) + (ti & 1) * 2048), wm * (MI * 32));
         }
         BD_PROBE_IF(g == nk, 62)
     }
@@ -296,6 +325,38 @@ int& bd_concurrent_launches() {
     return n;
 }
 
+// Epilogue specialisation of a launch (gemm_kernel_pc's header): 0 generic, 1 / 2 16-bit results (2: fused q/k RMSNorm), 3 fp32 (+ residual)
+static int f16c8_epilogue_kind(const bd_gemm_args& a, int& outk, bool& gelu) {
+    int ep = 0;
+    outk = a.out_f32;
+    gelu = a.act == BD_ACT_GELU;
+    if (!a.addtab && a.rpg_in <= 0 && !a.wscale && a.N % 192 == 0 && a.K >= 128 && !(a.bias && ((uintptr_t)a.bias & 15))) {
+        if (a.out_f32 == OUT_F32) ep = (gelu || a.rms_wq) ? 0 : 3;
+        else if (!a.resid && (outk == OUT_OPERAND || outk == OUT_F16 || outk == OUT_BF16X2)) ep = a.rms_wq ? (gelu ? 0 : 2) : 1;
+    }
+    if (ep == 1 && gelu && outk != OUT_OPERAND) ep = 0;
+    return ep;
+}
+
+// LayerNorm fold (bd_gemm_args.ln_*): which of the requested sides this class's kernel forms serve.  Producer: the fp32-residual epilogue
+// (EP 3 -> 4) of a three-stage launch.  Consumer: K = 768 (three stages), the 16-bit epilogues fc1 (+ GELU), DINOv2's QKV (split-bf16
+// planes), BETR's v columns / whole QKV (f16 plane; with the fused q/k RMSNorm).
+bool bd_f16c8_takes_ln_fold(const bd_gemm_args& a) {
+    int outk = 0;
+    bool gelu = false;
+    const int ep = f16c8_epilogue_kind(a, outk, gelu);
+    const bool s3 = (a.K / 32) % 3 == 0;
+    if (!s3 || !wide_epilogue_ok(a, 2)) return false;
+    if (ln_fold_producer(a) && !(ln_fold_producer_ok(a) && ep == 3)) return false;
+    if (ln_fold_consumer(a)) {
+        if (!ln_fold_consumer_ok(a)) return false;
+        const bool form = (ep == 1 && gelu && outk == OUT_OPERAND) || (ep == 1 && !gelu && (outk == OUT_F16 || outk == OUT_BF16X2)) ||
+                          (ep == 2 && outk == OUT_F16);
+        if (!form) return false;
+    }
+    return true;
+}
+
 // F16C8 has its own persistent kernel; every shape goes through it
 int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     if (!wide_epilogue_ok(a, 2) || 256 * a.lda * 2 >= ((int64_t)1 << 31) || 256 * a.ldw * 2 >= ((int64_t)1 << 31)) return BD_ERR_ALIGN;
@@ -303,17 +364,15 @@ int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     if (a.out_f32 == OUT_OPERAND && (a.ldo % 32)) return BD_ERR_SHAPE;
     if (a.w_qexp + BD_F16C8_D < -100 || a.w_qexp + BD_F16C8_D > 120) return BD_ERR_SHAPE;
     if (a.rms_wq && !rms_geometry_ok(a)) return BD_ERR_SHAPE;
+    const bool lnp = ln_fold_producer(a), lnc = ln_fold_consumer(a);
+    if ((lnp || lnc) && !bd_f16c8_takes_ln_fold(a)) return BD_ERR_SHAPE;
     const int slot = bd_trace_open(s, 0, a.M, a.N, a.K);
     const int cus = cu_count();
     const int tiles = ((a.M + 255) / 256) * ((a.N + 191) / 192);
     // epilogue specialisation (gemm_kernel_pc's header): native / f16 / split-bf16 16-bit results, fp32 (+ residual)
-    int ep = 0, outk = a.out_f32;
-    const bool gelu = a.act == BD_ACT_GELU;
-    if (!a.addtab && a.rpg_in <= 0 && !a.wscale && a.N % 192 == 0 && a.K >= 128 && !(a.bias && ((uintptr_t)a.bias & 15))) {
-        if (a.out_f32 == OUT_F32) ep = (gelu || a.rms_wq) ? 0 : 3;
-        else if (!a.resid && (outk == OUT_OPERAND || outk == OUT_F16 || outk == OUT_BF16X2)) ep = a.rms_wq ? (gelu ? 0 : 2) : 1;
-    }
-    if (ep == 1 && gelu && outk != OUT_OPERAND) ep = 0;
+    int outk = 0;
+    bool gelu = false;
+    const int ep = f16c8_epilogue_kind(a, outk, gelu);
     const bool s3 = (a.K / 32) % 3 == 0;
     // The SMALL form (128 x 192 tiles, one consumer wave per SIMD) where the large tiles would occupy at most half of the CUs -- one pose at
     // a time: M = 1536 is 24-96 large tiles on 256 CUs; with sub-batch lanes, of the CUs' share of one lane.  Measured per shape and row count (profiles/r5_f16c8_small_form.md): up to 128 large
@@ -328,10 +387,22 @@ int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     { if (small) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_, 2, 2, 4>), g, b, 0, s, a);     \
       else if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_>), g, b, 0, s, a);            \
       else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, EP_, OUTK_, GELU_>), g, b, 0, s, a); }
+    // (LayerNorm fold: three-stage forms only -- bd_f16c8_takes_ln_fold)
+#define BD_C8_LAUNCH_LN(EP_, OUTK_, GELU_, LNF_)                                                                        \
+    { if (small) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_, 2, 2, 4, LNF_>), g, b, 0, s, a);         \
+      else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, EP_, OUTK_, GELU_, 4, 2, 4, LNF_>), g, b, 0, s, a); }
     // fc2 (deep K, 4 column tiles) below ~4096 rows: 128 x 96 tiles on 2 + 2 waves -- four times the workgroups of the large form, still at most
     // one per CU -- is another 17 % faster than the 128 x 192 form (52 vs 63 us at 1536 rows; everywhere else it is slower:
-    // profiles/r5_f16c8_small_form.md).  One instance.
-    if (ep == 3 && small && a.K >= 2048 && a.N % 96 == 0 && 4 * tiles * bd_concurrent_launches() <= cus)
+    // profiles/r5_f16c8_small_form.md).  One instance (+ its LayerNorm-fold producer twin).
+    const bool fc2_96 = ep == 3 && small && a.K >= 2048 && a.N % 96 == 0 && 4 * tiles * bd_concurrent_launches() <= cus;
+    if (lnp && fc2_96)
+        hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 4, OUT_F32, false, 2, 1, 2>), dim3(((a.M + 127) / 128) * (a.N / 96)), dim3(256), 0, s, a);
+    else if (lnp) BD_C8_LAUNCH_LN(4, OUT_F32, false, false)
+    else if (lnc && ep == 1 && gelu) BD_C8_LAUNCH_LN(1, OUT_OPERAND, true, true)
+    else if (lnc && ep == 1 && outk == OUT_F16) BD_C8_LAUNCH_LN(1, OUT_F16, false, true)
+    else if (lnc && ep == 1) BD_C8_LAUNCH_LN(1, OUT_BF16X2, false, true)
+    else if (lnc) BD_C8_LAUNCH_LN(2, OUT_F16, false, true)
+    else if (fc2_96)
         hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 3, OUT_F32, false, 2, 1, 2>), dim3(((a.M + 127) / 128) * (a.N / 96)), dim3(256), 0, s, a);
     else if (ep == 3) BD_C8_LAUNCH(3, OUT_F32, false)
     else if (ep == 2 && outk == OUT_OPERAND) BD_C8_LAUNCH(2, OUT_OPERAND, false)
@@ -344,8 +415,8 @@ int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     else if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 0, OUT_OPERAND, false>), g, b, 0, s, a);      // generic epilogue: the big form only
     else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, 0, OUT_OPERAND, false>), g, b, 0, s, a);
 #undef BD_C8_LAUNCH
+#undef BD_C8_LAUNCH_LN
     bd_trace_close(s, slot);
     BD_CHECK_LAUNCH();
     return BD_OK;
 }
-

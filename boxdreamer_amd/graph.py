@@ -59,9 +59,9 @@ class GraphedPath:
     def set_inputs(self, images: torch.Tensor, bbox_feat: torch.Tensor, query_idx: torch.Tensor | None = None):
         self.images.copy_(images, non_blocking=True)
         self.bbox_feat.copy_(bbox_feat, non_blocking=True)
-        if query_idx is not None:
-            self.mask.zero_()
-            self.mask[torch.arange(self.mask.shape[0], device=self.mask.device), query_idx.to(self.mask.device).long()] = True
+        if query_idx is not None:      # (a device comparison: an indexed assignment of the scalar True would upload it with a synchronising copy)
+            T = self.mask.shape[1]
+            self.mask.copy_(torch.arange(T, device=self.mask.device)[None, :] == query_idx.to(self.mask.device).long()[:, None])
 
     def replay(self):
         """Replays the captured step on the current stream; returns (heat, kp_px, kp_norm, idx) static tensors."""

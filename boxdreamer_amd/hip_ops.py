@@ -109,10 +109,13 @@ _OUT_SPLIT = {4: torch.bfloat16, 5: torch.float16}
 
 
 def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, addtab=None, out=None,
-         out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0), wscale=None, out_mode=None, w_qexp=0, rms=None):
+         out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0), wscale=None, out_mode=None, w_qexp=0, rms=None,
+         ln_emit=None, ln_apply=None):
     """out[map(r)] = act(wscale * (A W^T) + bias) + addtab[r % rows(addtab)] + resid[map(r)].
     out_mode: None -> operand dtype (or fp32 with out_f32), 2 -> f16 single plane, 3 -> bf16 single plane, 4 -> split-bf16 (hi, lo)
-    planes, 5 -> split-f16 (hi, lo) planes (bd_gemm_args.out_f32, include/boxdreamer_hip.h)."""
+    planes, 5 -> split-f16 (hi, lo) planes (bd_gemm_args.out_f32, include/boxdreamer_hip.h).
+    LayerNorm fold (ABI 8): ln_emit = (stats [M, N / 96, 2] fp32, operand copy [2, M, N] F16C8 storage) -- the producer side;
+    ln_apply = (stats [M, 8, 2], column sums [N], eps) -- the consumer side."""
     lib = _lib.load()
     np_ = planes(prec)
     A2 = a16[0] if np_ == 2 else a16
@@ -146,6 +149,13 @@ def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, add
         g.rms_parts = int(rms[3]) if len(rms) > 3 else 0
     g.M, g.N, g.K, g.act = M, N, K, act
     g.rpg_in, g.rpg_out, g.row_off = rpg
+    if ln_emit is not None:
+        st, op = ln_emit
+        g.ln_stats_out, g.ln_op_out, g.ln_op_plane, g.ln_op_ld = ptr(st), ptr(op), op[0].numel(), op[0].stride(0)
+    if ln_apply is not None:
+        g.ln_stats_in, g.ln_colsum, g.ln_eps = ptr(ln_apply[0]), ptr(ln_apply[1]), float(ln_apply[2])
+    if (ln_emit is not None or ln_apply is not None) and not lib.bd_gemm_takes_ln_fold(C.byref(g), prec_id(prec)):
+        raise ValueError("bd_gemm_takes_ln_fold: this launch has no kernel form with the LayerNorm-fold epilogues")
     check(lib.bd_gemm(C.byref(g), prec_id(prec), stream()), "bd_gemm")
     return out
 

@@ -83,6 +83,14 @@ class BoxDreamer(nn.Module):
         self._calibrated_for = None
         self.hip_precision_source = ("config" if "hip_precision" in dec_cfg else
                                      ("$BOXDREAMER_HIP_PREC" if "BOXDREAMER_HIP_PREC" in os.environ else "package default"))
+        # `hip_graph: true` in config["modules"]: the plain path (no dense mode, no cached features) of an eval forward is captured as ONE
+        # HIP graph per batch shape on first use and replayed afterwards (boxdreamer_amd/graph.py: ~300 launches per step; bit-identical
+        # outputs, tests/test_gpu_facade.py).  One graph is kept: a new batch shape drops it and captures again.
+        self.hip_graph = bool(module_configs.get("hip_graph", False))
+        self._graph, self._graph_key = None, None
+        self.decoder.validate_inputs = "deferred"      # the one-hot check of camera_mask travels with the corners' D2H (no sync of its own)
+        self.host_syncs_per_forward = None             # filled by forward(): what still waits for the device, for the record
+        self._pose_pin = None
 
     def calibrate(self, data) -> dict:
         """Run the precision self-check / promotion on (the first sample of) a batch dict now (forward() does it once by itself)."""
@@ -122,8 +130,8 @@ class BoxDreamer(nn.Module):
         images = data["images"]
         B, T = images.shape[:2]
         query_idx = data["query_idx"]
-        camera_mask = torch.zeros((B, T), dtype=torch.bool, device=images.device)
-        camera_mask[torch.arange(B, device=images.device), query_idx.to(images.device).long()] = True
+        # (a comparison on the device: an indexed assignment of the Python scalar True uploads it first -- a synchronising copy)
+        camera_mask = torch.arange(T, device=images.device)[None, :] == query_idx.to(images.device).long()[:, None]
         data["camera_mask"] = camera_mask.clone()
         pose_feat = data["bbox_feat"]
 
@@ -139,61 +147,112 @@ class BoxDreamer(nn.Module):
             data["hip_precision"] = self._precision_record()
             # sub-batch lanes this batch runs as (bit-identical for every value; `hip_lanes` in the decoder / encoder cfg, default "auto")
             data["hip_precision"]["sub_batch_lanes"] = _lib.resolve_lanes(self.decoder.hip_lanes, B * T, B, self.decoder.hip_precision)
-        if "cached_rgb_feat" in data:       # "next" row f1: references encoded once per object (boxdreamer_amd/cache.py)
-            rgb_feature = merge_cached_features(self.rgb_encoder, images, data["cached_rgb_feat"],
-                                                data["cached_rgb_mask"])
+        dev = images.device
+        ar, qi = torch.arange(B, device=dev), query_idx.to(dev).long()
+        decoded = None
+        dense = self.dense_cfg is not None and _get(self.dense_cfg, "enable", False)
+        if (self.hip_graph and not dense and "cached_rgb_feat" not in data and not self.training and images.is_cuda
+                and isinstance(self.decoder, BETR) and not torch.cuda.is_current_stream_capturing()):
+            heat, kp_px, kn, _ = self._graphed(images, pose_feat, qi)
+            # (the replay's outputs are static buffers the next replay overwrites: the caller gets its own tensors)
+            query_ret, decoded = heat.clone(), (kn.clone(), kp_px.clone())
+            self.decoder.mask_error = None          # query_idx indexes one view per sample by construction
         else:
-            rgb_feature = self.rgb_encoder.predict(images)
-        if self.dense_cfg is not None and _get(self.dense_cfg, "enable", False):     # BoxDreamerModel.py:291-327
-            data, pose_feat, images, camera_mask, rgb_feature, _ = process_dense_input(
-                data, pose_feat, images, camera_mask, rgb_feature, None, self.dense_cfg)
-            if _get(self.dense_cfg, "multi_round", False):
-                query_ret = process_multi_round(data, pose_feat, images, camera_mask, rgb_feature, None, self.decoder,
-                                                self.dense_cfg, self.bbox_representation)
-                if isinstance(query_ret, dict):                                   # coarse prediction only: dict is final
-                    return query_ret
+            if "cached_rgb_feat" in data:       # "next" row f1: references encoded once per object (boxdreamer_amd/cache.py)
+                rgb_feature = merge_cached_features(self.rgb_encoder, images, data["cached_rgb_feat"],
+                                                    data["cached_rgb_mask"])
             else:
-                # .contiguous() returns a NEW tensor object when it has to copy; the operand-dtype copy of the features
-                # follows only an alias of the same storage (features.carry), otherwise BETR re-casts explicitly
-                query_ret = self.decoder(pose_feat.contiguous(), images.contiguous(), camera_mask,
-                                         features.carry(rgb_feature, rgb_feature.contiguous()), None)
-            # the dense helpers re-pack the batch dict: re-read the views / query position (BoxDreamerModel.py:150-158)
-            images = data["images"]
-            B, T = images.shape[:2]
-            camera_mask = torch.zeros((B, T), dtype=torch.bool, device=images.device)
-            camera_mask[torch.arange(B, device=images.device), data["query_idx"].to(images.device).long()] = True
-        else:
-            query_ret = self.decoder(pose_feat, images, camera_mask, rgb_feature, None)
+                rgb_feature = self.rgb_encoder.predict(images)
+            if dense:     # BoxDreamerModel.py:291-327
+                data, pose_feat, images, camera_mask, rgb_feature, _ = process_dense_input(
+                    data, pose_feat, images, camera_mask, rgb_feature, None, self.dense_cfg)
+                if _get(self.dense_cfg, "multi_round", False):
+                    query_ret = process_multi_round(data, pose_feat, images, camera_mask, rgb_feature, None, self.decoder,
+                                                    self.dense_cfg, self.bbox_representation)
+                    if isinstance(query_ret, dict):                                   # coarse prediction only: dict is final
+                        return query_ret
+                else:
+                    # .contiguous() returns a NEW tensor object when it has to copy; the operand-dtype copy of the features
+                    # follows only an alias of the same storage (features.carry), otherwise BETR re-casts explicitly
+                    query_ret = self.decoder(pose_feat.contiguous(), images.contiguous(), camera_mask,
+                                             features.carry(rgb_feature, rgb_feature.contiguous()), None)
+                # the dense helpers re-pack the batch dict: re-read the views / query position (BoxDreamerModel.py:150-158)
+                images = data["images"]
+                B, T = images.shape[:2]
+                ar, qi = torch.arange(B, device=dev), data["query_idx"].to(dev).long()
+                camera_mask = torch.arange(T, device=dev)[None, :] == qi[:, None]
+            else:
+                query_ret = self.decoder(pose_feat, images, camera_mask, rgb_feature, None)
 
-        data["pred_bbox"] = data["bbox_feat"].clone()                            # BoxDreamerModel.py:341-344
-        data["pred_bbox"][camera_mask] = query_ret.to(data["pred_bbox"].dtype)
+        # BoxDreamerModel.py:341-344 (`pred_bbox[camera_mask] = query_ret`): the same write through (sample, view) indices -- a boolean-mask
+        # assignment runs nonzero() and waits for the device
+        data["pred_bbox"] = data["bbox_feat"].clone()
+        data["pred_bbox"][ar, qi] = query_ret.to(data["pred_bbox"].dtype)
 
         pred_poses = data["poses"].clone()
+        syncs = []
         if not self.training:
-            pred_poses = self._process_evaluation(pred_poses, data, query_ret, camera_mask)
+            pred_poses = self._process_evaluation(pred_poses, data, query_ret, ar, qi, decoded, syncs)
         data["pred_poses"] = pred_poses
         data["pred_intrinsics"] = data["intrinsics"]
+        self.host_syncs_per_forward = syncs
         return data
 
-    def _process_evaluation(self, pred_poses, data, query_ret, camera_mask):
-        """prediction_utils.py:63-101 for bb8/heatmap: decode corners on the GPU, one D2H, host PnP."""
+    def _graphed(self, images, pose_feat, qi):
+        """Replay (capturing first, per batch shape) encoder -> decoder -> corner decode as one HIP graph; returns the graph's STATIC
+        output tensors (heat, corners px, corners normalised, None)."""
+        from .graph import GraphedPath
+        B, T = images.shape[:2]
+        key = (B, T, images.shape[-1], images.dtype, pose_feat.dtype, str(images.device), self.decoder._signature(),
+               self.rgb_encoder.model.state_stamp(self.rgb_encoder.prec), str(self.decoder.hip_precision))
+        if self._graph is None or self._graph_key != key:
+            self._graph = None                      # lifts the modules' freeze before anything re-allocates
+            if pose_feat.dtype != images.dtype:
+                raise ValueError("hip_graph: images and bbox_feat must share a dtype (the dataset casts both to its precision)")
+            self._graph = GraphedPath(self.rgb_encoder, self.decoder, B, T, images.shape[-1], images.dtype, images.device)
+            self._graph_key = key
+        return self._graph(images, pose_feat, qi)
+
+    def _process_evaluation(self, pred_poses, data, query_ret, ar, qi, decoded=None, syncs=None):
+        """prediction_utils.py:63-101 for bb8/heatmap: decode corners on the GPU, ONE D2H (corners + 3-D box + K + the decoder's deferred
+        mask verdict in one buffer), host PnP."""
         B = query_ret.shape[0]
-        norm_kp, kp_px, _ = recover_bb8_corners_chw(query_ret)                  # [B,8,2] each
-        bbox_3d = data["bbox_3d"][camera_mask].float()
-        K = data["non_ndc_intrinsics"][camera_mask].float()
-        # PnP stays on the host CPU (north_star; box_utils.py:139-199): ONE D2H of the corners per batch, then OpenCV's
-        # solvePnP when cv2 is importable, else this repo's restatement of its ITERATIVE algorithm -- whose parity against
-        # OpenCV is UN-PINNED in this image (DESIGN.md section 2); `pose_solver` says which one produced `pred_poses`.
-        # The HIP solver (bd_solve_pnp, row f3) is opt-in: config["modules"]["pnp_on_device"] = True.
+        syncs = [] if syncs is None else syncs
+        norm_kp, kp_px = decoded if decoded is not None else recover_bb8_corners_chw(query_ret)[:2]                  # [B,8,2] each
+        bbox_3d = data["bbox_3d"][ar, qi].float()
+        K = data["non_ndc_intrinsics"][ar, qi].float()
+        err = getattr(self.decoder, "mask_error", None)
+        flag = (err if err is not None else torch.zeros((), dtype=torch.bool, device=kp_px.device)).float().reshape(1)
+        # PnP stays on the host CPU (north_star; box_utils.py:139-199): OpenCV's solvePnP when cv2 is importable, else this repo's
+        # restatement of its ITERATIVE algorithm -- whose parity against OpenCV is UN-PINNED in this image (DESIGN.md section 2);
+        # `pose_solver` says which one produced `pred_poses`.  The HIP solver (bd_solve_pnp, row f3) is opt-in:
+        # config["modules"]["pnp_on_device"] = True (then only the mask verdict crosses to the host).
         if self.pnp_on_device:
             poses = solve_poses_device(kp_px, bbox_3d, K)
             data["pose_solver"] = "hip:bd_solve_pnp (DLT + LM, parity vs OpenCV un-pinned)"
+            bad = bool(flag.item()) if err is not None else False
+            if err is not None:
+                syncs.append("mask verdict D2H (4 bytes; pnp_on_device)")
         else:
-            poses = torch.from_numpy(solve_poses_host(kp_px.cpu().numpy(), bbox_3d.cpu().numpy(), K.cpu().numpy()))
+            host = torch.cat([kp_px.reshape(-1), bbox_3d.reshape(-1), K.reshape(-1), flag]).cpu().numpy()
+            syncs.append(f"corners + 3-D box + K + mask verdict: ONE D2H of {host.size * 4} bytes, then the host PnP of {B} poses")
+            bad = bool(host[-1] != 0.0)
+            n1, n2 = B * 16, B * 16 + B * 24
+            poses = torch.from_numpy(solve_poses_host(host[:n1].reshape(B, 8, 2), host[n1:n2].reshape(B, 8, 3), host[n2:-1].reshape(B, 3, 3)))
             data["pose_solver"] = ("host:cv2.solvePnP" if pnp._HAVE_CV2
                                    else "host:bd_solve_pnp_host (native threads, DLT + LM; parity vs OpenCV un-pinned)")
-        pred_poses[camera_mask] = poses.to(pred_poses.device).to(pred_poses.dtype)
+        if bad:
+            raise ValueError("camera_mask must mark exactly one query view per sample (reported with the corners' D2H; "
+                             "BETR.validate_inputs = True checks before the launch instead)")
+        if not poses.is_cuda and pred_poses.is_cuda:
+            # the solved poses go back through a pinned staging buffer: an asynchronous copy (from pageable memory it would wait for the
+            # stream).  The buffer is rewritten only after the NEXT forward's D2H, which waits for everything enqueued before it.
+            if self._pose_pin is None or self._pose_pin.shape[0] != B:
+                self._pose_pin = torch.empty((B, 4, 4), dtype=torch.float32, pin_memory=True)
+            self._pose_pin.copy_(poses)
+            poses = self._pose_pin.to(pred_poses.device, non_blocking=True)
+        pred_poses[ar, qi] = poses.to(pred_poses.device).to(pred_poses.dtype)
         data["regression_boxes"] = data["bbox_proj_crop"].clone()
-        data["regression_boxes"][camera_mask] = norm_kp.to(data["regression_boxes"].dtype)
+        data["regression_boxes"][ar, qi] = norm_kp.to(data["regression_boxes"].dtype)
         data["pred_corners_px"] = kp_px
         return torch.nan_to_num(pred_poses, nan=0.0, posinf=0.0, neginf=0.0)

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -217,7 +218,38 @@ def _pack_block(pk: Packed, sd: dict, p: str, prec, device, ls: bool, qk_norm: b
         bw.k_norm_w = pk.keep(sd[p + "attn.k_norm.weight"].float(), device)
         if _lib.prec_id(prec) == _lib.PREC_F16C8:   # f16 single-plane copy whose q, k rows BD_PREC_F16C8_QK16 reads (3.5 MB per block)
             bw.qkv16 = pk.linear(pack_linear_weight(sd[p + "attn.qkv.weight"], "fp16"), pack_bias(sd[p + "attn.qkv.bias"]), device)
+    if _lib.prec_id(prec) == _lib.PREC_F16C8 and ln_fold_enabled():
+        _pack_ln_fold(pk, bw, sd, p, device, qk_norm)
     return bw
+
+
+def ln_fold_enabled() -> bool:
+    """The LayerNorm fold of the F16C8 family (ABI 8) is on unless $BOXDREAMER_HIP_LNFOLD = 0 (A/B measurements; read at pack time -- the
+    library itself reads no environment)."""
+    return os.environ.get("BOXDREAMER_HIP_LNFOLD", "1") != "0"
+
+
+def fold_layernorm(weight: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """LN(x) W^T + b = rstd (x W'^T - mean s) + b'  with  W' = W . gamma (per input column),  b' = b + W beta  (fp64, then fp32)."""
+    w = weight.detach().double().reshape(weight.shape[0], -1)
+    return (w * gamma.detach().double()[None, :]).float(), (bias.detach().double() + w @ beta.detach().double()).float()
+
+
+def _pack_ln_fold(pk: "Packed", bw, sd: dict, p: str, device, qk_norm: bool) -> None:
+    """The gain-folded copies of the two Linears that follow a LayerNorm, in the F16C8 layout, + the column sums of the ROUNDED weights
+    each launch multiplies (include/boxdreamer_hip.h: bd_block_weights.qkv_f ...)."""
+    from . import hip_ops
+    for name, norm, lin, fs in (("qkv_f", "norm1", "attn.qkv", "qkv_s"), ("fc1_f", "norm2", "mlp.fc1", "fc1_s")):
+        wf, bf = fold_layernorm(sd[p + lin + ".weight"], sd[p + lin + ".bias"], sd[p + norm + ".weight"], sd[p + norm + ".bias"])
+        packed, qexp = pack_linear_weight(wf, _lib.PREC_F16C8, return_scale=True)
+        hi, lo, _ = hip_ops.f16c8_decode(packed, qexp, True)
+        setattr(bw, name, pk.linear((packed, qexp), bf, device))
+        pk.named[(p + name, _lib.PREC_F16C8)] = pk.tensors[-2]
+        setattr(bw, fs, pk.keep((hi.double() + lo.double()).sum(1).float(), device))
+        if name == "qkv_f" and qk_norm:                # the f16 copy of the folded QKV weight (BD_PREC_F16C8_QK16 reads its q, k rows)
+            w16 = pack_linear_weight(wf, "fp16")
+            bw.qkv16_f = pk.linear(w16, bf, device)
+            bw.qkv16_s = pk.keep(w16.double().sum(1).float(), device)
 
 
 def pack_dino(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int = 224) -> Packed:

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define BD_ABI_VERSION 7
+#define BD_ABI_VERSION 8
 
 #define BD_DTYPE_BF16 0
 #define BD_DTYPE_F16 1
@@ -159,8 +159,22 @@ typedef struct bd_gemm_args {
     const float* rms_wq; const float* rms_wk; float rms_eps;
     int rms_parts;                                 /* with rms_wq: 0 or 3 = output columns are [q | k | v] (v untouched); 2 = [q | k] only
                                                       (a QKV Linear split into a q,k launch and a v launch, BD_PREC_F16C8_QK16) */
+    /* LayerNorm folded into the neighbouring Linears (ABI 8; replaces the nn.LayerNorm launches between a residual Linear and the next
+     * Linear: blocks.py:35-41, 876-886, DINOv2 layers/block.py:89-114).  LN(x) W^T + b = rstd (x (g . W)^T - mean s) + (beta W^T + b),
+     * s[n] = sum_k (g . W)[n, k]: the weights are gain-folded at load time (bd_block_weights.qkv_f, fc1_f), the PRODUCER of x emits
+     * what the consumer needs, the CONSUMER applies the row statistics to its fp32 accumulators.
+     *   producer (an fp32-result Linear with a residual, BD_PREC_F16C8, N = 768): next to the fp32 rows it writes (a) their BD_PREC_F16C8
+     *     operand copy -- the raw, un-normalised row -- at ln_op_out and (b) per 96-column wave tile the pair (mean, M2 = sum (x - mean)^2)
+     *     of its 96 values at ln_stats_out[row][N / 96][2]: plain stores, one writer per element, no atomics -- deterministic;
+     *   consumer (BD_PREC_F16C8, or BD_PREC_F16 with the fused q/k RMSNorm; K = 768): combines the row's K / 96 pairs in a fixed order
+     *     (Chan), rstd = rsqrt(M2 / K + ln_eps), and forms rstd * acc + (-mean rstd) * ln_colsum[n] + bias[n] before anything else.
+     * Ask bd_gemm_takes_ln_fold first: launches that would not run on a kernel form with these epilogues return BD_ERR_SHAPE. */
+    float* ln_stats_out; void* ln_op_out; int64_t ln_op_plane; int64_t ln_op_ld;
+    const float* ln_stats_in; const float* ln_colsum; float ln_eps;
 } bd_gemm_args;
 int bd_gemm(const bd_gemm_args* args /*[host]*/, int prec, void* stream);
+/* 1 if bd_gemm(args, prec) serves the ln_* fields that are set in args (producer and / or consumer side of the LayerNorm fold), else 0. */
+int bd_gemm_takes_ln_fold(const bd_gemm_args* args /*[host]*/, int prec);
 /* 1 if bd_gemm(args, prec) with args->rms_wq set would fuse the q/k RMSNorm (tile shape and head geometry fit), else 0. */
 int bd_gemm_fuses_qk_rmsnorm(const bd_gemm_args* args /*[host]*/, int prec);
 
@@ -311,6 +325,11 @@ typedef struct bd_block_weights {
     const float* q_norm_w; const float* k_norm_w;   /* [head_dim]; NULL for DINOv2 */
     bd_linear qkv16;                                /* f16 single-plane copy of qkv (BD_PREC_F16C8_QK16 reads its q, k rows) or {NULL} */
     int promote;                                    /* BD_PROMOTE_* bits (F16C8 family only) */
+    /* LayerNorm fold (ABI 8, F16C8 family only; all {NULL} elsewhere): the Linears that follow norm1 / norm2 with the norm's gain folded
+     * into the weight columns and its shift into the bias (W' = g . W, b' = b + W beta), in the BD_PREC_F16C8 layout (qkv16_f: f16 single
+     * plane), and the column sums s[n] = sum_k W'[n, k] of the ROUNDED weights each launch multiplies (qkv16_s: of the f16 copy's q, k rows) */
+    bd_linear qkv_f, fc1_f, qkv16_f;
+    const float* qkv_s; const float* fc1_s; const float* qkv16_s;
 } bd_block_weights;
 
 typedef struct bd_dino_weights {

@@ -193,9 +193,17 @@ def test_hip_graph_replay_matches_eager(hip):
         rkp, _, ridx = hip_ops.decode_topk(ref)
         assert torch.equal(heat, ref) and torch.equal(kp, rkp) and torch.equal(idx, ridx)
     # building a graph must not switch the decoder's one-hot mask check off for later eager use ...
-    assert model.decoder.validate_inputs is True
+    # (the facade's decoder leaves its verdict on the device -- "deferred": it travels with the corners' D2H, model.py; a stand-alone BETR checks
+    # before the launch)
+    assert model.decoder.validate_inputs == "deferred"
+    model.decoder(bf, img, torch.zeros(B, T, dtype=torch.bool, device="cuda"), model.rgb_encoder.predict(img), None)
+    assert bool(model.decoder.mask_error)
+    model.decoder(bf, img, mask.cuda(), model.rgb_encoder.predict(img), None)
+    assert not bool(model.decoder.mask_error)
+    model.decoder.validate_inputs = True
     with pytest.raises(ValueError, match="exactly one query view"):
         model.decoder(bf, img, torch.zeros(B, T, dtype=torch.bool, device="cuda"), model.rgb_encoder.predict(img), None)
+    model.decoder.validate_inputs = "deferred"
     # ... a live graph freezes the modules it captured raw pointers into (a larger eager batch would re-allocate the workspace) ...
     big = synth.make_batch(seed=3, B=B + 2, T=T)
     with pytest.raises(RuntimeError, match="GraphedPath"):
@@ -209,6 +217,46 @@ def test_hip_graph_replay_matches_eager(hip):
     del g
     gc.collect()
     assert model.rgb_encoder.predict(big["images"].cuda()).shape[0] == B + 2
+
+
+@pytest.mark.parametrize("prec", ["f16c8_qk16", "bf16"])
+def test_facade_hip_graph_and_sync_budget(hip, prec):
+    """what a maintainer gets from the 3-line patch.  `hip_graph: true` replays the step from one captured graph behind
+    BoxDreamer.forward -- every output bit-identical to the eager forward, over changing query positions and a changing batch shape -- and
+    an eval forward waits for the device exactly once (the corners' D2H, which also carries the one-hot verdict of camera_mask)."""
+    def build(graph):
+        cfg = _config(prec)
+        cfg["modules"]["hip_graph"] = graph
+        m = BoxDreamer(cfg)
+        m.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
+        return m.cuda().eval()
+    eager, graphed = build(False), build(True)
+    for seed, B, T, qi in ((8, 2, 3, [2, 0]), (9, 2, 3, [1, 1]), (10, 3, 2, [0, 1, 1])):
+        batch = synth.make_batch(seed=seed, B=B, T=T)
+        batch["query_idx"] = torch.tensor(qi)
+        dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        a, b = eager(dict(dev)), graphed(dict(dev))
+        for k in ("pred_bbox", "pred_poses", "regression_boxes", "pred_corners_px", "camera_mask"):
+            assert torch.equal(a[k], b[k]), (prec, seed, k)
+        assert len(eager.host_syncs_per_forward) == 1 and len(graphed.host_syncs_per_forward) == 1
+        assert "ONE D2H" in graphed.host_syncs_per_forward[0]
+    assert graphed._graph is not None and graphed._graph_key[0] == 3           # the last shape's capture replaced the first
+    # a boolean-mask assignment or an .item() anywhere in the forward would show up here: torch's own count of synchronising calls
+    import warnings
+    for m in (eager, graphed):
+        try:
+            torch.cuda.set_sync_debug_mode("warn")
+        except Exception:                       # noqa: BLE001 -- a build without the debug hook: the list above is the record
+            break
+        try:
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                m(dict(dev))
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        n = sum("synchroniz" in str(x.message).lower() for x in w)
+        print(f"[facade syncs] {prec} {'graphed' if m is graphed else 'eager'}: torch counted {n} synchronising call(s) in one eval forward")
+        assert n <= 1, [str(x.message) for x in w]
 
 
 def test_two_batches_in_flight_match_one_at_a_time(hip):
