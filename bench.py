@@ -1080,11 +1080,12 @@ def facade_block(args, device, one: dict, prec: str, reference_value: float | No
     B, T = one["images"].shape[:2]
     batch = {k: ((v.to(torch.bfloat16) if v.is_floating_point() else v).to(device) if torch.is_tensor(v) else v) for k, v in one.items()}
     out, res = {}, {}
-    for tag, graph in (("eager", False), ("hip_graph", True)):
+    for tag, graph, dev_pnp in (("eager", False, False), ("hip_graph", True, False), ("hip_graph_pnp_on_device", True, True)):
         mods = copy.deepcopy(json.load(open(path))["modules"])
         mods["decoder"].update(num_decoder_layers=12, hip_precision=prec)
         mods["encoder"]["dino"]["cfg"].update(state_dict=dsd, hip_precision=prec)
         mods["hip_graph"] = graph
+        mods["pnp_on_device"] = dev_pnp
         model = BoxDreamer({"modules": mods})
         model.load_state_dict({"decoder." + k: v for k, v in bsd.items()}, strict=True)
         model = model.to(device).eval()
@@ -1103,13 +1104,21 @@ def facade_block(args, device, one: dict, prec: str, reference_value: float | No
         res[tag] = {"poses_per_s": round(B * args.steps / dt, 2), "ms_per_forward": round(dt / args.steps * 1e3, 3)}
         if reference_value:
             res[tag]["vs_parity_mode_value"] = round(B * args.steps / dt / reference_value, 4)
-        syncs, solver, lanes = list(model.host_syncs_per_forward or []), ret.get("pose_solver"), ret["hip_precision"].get("sub_batch_lanes")
+        res[tag]["host_syncs_per_forward"] = list(model.host_syncs_per_forward or [])
+        res[tag]["pose_solver"] = ret.get("pose_solver")
+        if not dev_pnp:
+            syncs, solver, lanes = list(model.host_syncs_per_forward or []), ret.get("pose_solver"), ret["hip_precision"].get("sub_batch_lanes")
         del model
         torch.cuda.empty_cache()
     same = all(torch.equal(out["eager"][k], out["hip_graph"][k]) for k in ("pred_bbox", "pred_poses", "regression_boxes", "pred_corners_px"))
     return {"what": "BoxDreamer(config).eval()(batch) on the configs[1] dict (1 query + 5 refs, batch %d, bf16 tensors on the device): encoder + decoder + "
                     "corner decode + ONE D2H + host PnP + the dict's outputs, per call; K = %d calls back to back" % (B, args.steps),
             "mode": prec, "eager": res["eager"], "hip_graph": res["hip_graph"], "poses_per_s": res["hip_graph"]["poses_per_s"],
+            "hip_graph_pnp_on_device": dict(res["hip_graph_pnp_on_device"],
+                                            what="config['modules']['pnp_on_device'] = True: the corners never leave the device (bd_solve_pnp), no host "
+                                                 "synchronisation inside forward(); the heat maps / corners are bit-identical, the poses come from the HIP "
+                                                 "solver instead of the host one (both un-pinned against OpenCV)"),
+            "corners_identical_with_pnp_on_device": bool(torch.equal(out["hip_graph"]["pred_corners_px"], out["hip_graph_pnp_on_device"]["pred_corners_px"])),
             "outputs_bit_identical_eager_vs_graph": bool(same), "sub_batch_lanes": lanes, "pose_solver": solver,
             "host_syncs_per_forward": syncs,
             "not_overlapped": "the host PnP of batch i runs before the call returns (pred_poses is part of the returned dict); "

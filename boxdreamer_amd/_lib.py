@@ -76,7 +76,7 @@ class GemmArgs(C.Structure):
                 ("rpg_in", C.c_int), ("rpg_out", C.c_int), ("row_off", C.c_int), ("w_qexp", C.c_int),
                 ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("rms_parts", C.c_int),
                 ("ln_stats_out", C.c_void_p), ("ln_op_out", C.c_void_p), ("ln_op_plane", C.c_int64), ("ln_op_ld", C.c_int64),
-                ("ln_stats_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float)]
+                ("ln_stats_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_resid_in_op", C.c_int)]
 
 
 class Linear(C.Structure):
@@ -88,7 +88,7 @@ class BlockWeights(C.Structure):
                 ("qkv", Linear), ("proj", Linear), ("fc1", Linear), ("fc2", Linear),
                 ("q_norm_w", C.c_void_p), ("k_norm_w", C.c_void_p), ("qkv16", Linear), ("promote", C.c_int),
                 ("qkv_f", Linear), ("fc1_f", Linear), ("qkv16_f", Linear),
-                ("qkv_s", C.c_void_p), ("fc1_s", C.c_void_p), ("qkv16_s", C.c_void_p)]
+                ("qkv_s", C.c_void_p), ("fc1_s", C.c_void_p), ("qkv16_s", C.c_void_p), ("ln_resid3", C.c_int)]
 
 
 class DinoWeights(C.Structure):

@@ -50,6 +50,32 @@ def _plane_views(t16: torch.Tensor, pid: int, n_views: int, P: int, C: int):
     return [t16[0].reshape(n_views, P, C), t16[1].reshape(n_views, P, C)]
 
 
+def take_views(feats: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """feats (B, T, P, C) fp32 from the HIP encoder; idx (B, T') long, -1 = an all-zero view -> (B, T', P, C) with
+    out[b, j] = feats[b, idx[b, j]], its operand-dtype copy re-packed the same way and attached (features.attach): what the dense-reference
+    helpers (dense.py: view selection, sub-batches of references) need so that BETR does not re-cast on every forward.  Features that carry
+    no operand copy come back plain (BETR then re-casts, as before)."""
+    B, T, P, C = feats.shape
+    dev = feats.device
+    idx = idx.to(dev).long()
+    Tn = idx.shape[1]
+    valid = (idx >= 0).reshape(-1)
+    flat = (torch.arange(B, device=dev)[:, None] * T + idx.clamp_min(0)).reshape(-1)
+    out32 = feats.reshape(B * T, P, C)[flat]
+    out32[~valid] = 0
+    out32 = out32.reshape(B, Tn, P, C)
+    tag = features.tag_of(feats)
+    if tag is None:
+        return out32
+    f16, pid = tag
+    out16 = _new_operand(pid, B * Tn, P, C, f16.dtype, dev)
+    for dst, src in zip(_plane_views(out16, pid, B * Tn, P, C), _plane_views(f16, pid, B * T, P, C)):
+        g = src[flat]
+        g[~valid] = 0
+        dst.copy_(g)
+    return features.attach(out32, out16, pid, features.stamp_of(feats))
+
+
 class RefFeatureCache:
     def __init__(self, encoder):
         self.encoder = encoder                                 # a DinoV2Wrapper

@@ -177,31 +177,84 @@ inline bool ln1_foldable(const bd_block_weights& w, const BlockPlan& p, const Bl
     return qkv_stage(w, p, b, M, D, heads, ln_eps, rms_eps, nullptr, true, true) == BD_OK;
 }
 
+// The residual side of a block as bd_gemm launches.  3-byte residual stream (bd_gemm_args.ln_resid_in_op, bd_block_weights.ln_resid3): between
+// FOLDED LayerNorms nobody reads the stream as fp32 -- the next reader is a Linear that multiplies the operand copy -- so a residual Linear
+// may read its residual rows from that copy (b.xn) and write the sum back there only.  What decides, per residual Linear:
+//   reads the copy   iff b.xn IS the stream (the LayerNorm in front of it was folded) and the launch has the form (un-promoted F16C8);
+//   writes fp32 too  iff someone reads b.x before the next residual Linear: a LayerNorm kernel, a residual Linear without that form, the
+//                    stack's final norm / the last decoder block's row gather (need_f32_out).
+// x_stale (in / out): b.x does not hold the stream (the previous residual Linear wrote the copy only).
+struct ResidPlan { bool fold2, proj_c8, proj_f32, fc2_c8, fc2_f32; };
+
+inline bd_gemm_args proj_args(const bd_block_weights& w, const BlockBufs& b, float* x, int Mr, int D) {
+    bd_gemm_args g = gemm_args(b.ao, D, (int64_t)Mr * D, w.proj, D, D, x, D, 0, 1, Mr, D, BD_ACT_NONE);
+    g.resid = x; g.ldr = D;
+    return g;
+}
+inline bd_gemm_args fc2_args(const bd_block_weights& w, const BlockBufs& b, float* x, int Mr, int D) {
+    bd_gemm_args g = gemm_args(b.h, 4 * D, (int64_t)Mr * 4 * D, w.fc2, 4 * D, D, x, D, 0, 1, Mr, 4 * D, BD_ACT_NONE);
+    g.resid = x; g.ldr = D;
+    return g;
+}
+// the same launch reading its residual from the operand copy (and writing fp32 rows only if asked)
+inline void resid_from_copy(bd_gemm_args& g, const BlockBufs& b, int64_t plane, int D, bool f32_too) {
+    ln_producer(g, b, plane, D);
+    g.ln_resid_in_op = 1; g.resid = nullptr; g.ldr = 0;
+    g.out_f32 = f32_too ? 1 : 0;
+}
+inline bool fold2_possible(const bd_block_weights& w, const BlockPlan& p, const BlockBufs& b, float* x, int Mr, int D, float ln_eps) {
+    if (!(w.fc1_f.w && w.fc1_s && p.c_proj == BD_PREC_F16C8 && p.c_fc1 == BD_PREC_F16C8 && p.c_fc2 == BD_PREC_F16C8 && D == 768)) return false;
+    bd_gemm_args cp = proj_args(w, b, x, Mr, D), c1 = gemm_args(b.xn, D, (int64_t)Mr * D, w.fc1_f, D, 4 * D, b.h, 4 * D, (int64_t)Mr * 4 * D, 0, Mr, D, BD_ACT_GELU);
+    ln_producer(cp, b, (int64_t)Mr * D, D);
+    ln_consumer(c1, b, w.fc1_s, ln_eps);
+    return bd_gemm_takes_ln_fold(&cp, p.c_proj) && bd_gemm_takes_ln_fold(&c1, p.c_fc1);
+}
+// can this block's proj read its residual from the operand copy (given that its LayerNorm 1 is folded)?
+inline bool proj_c8_possible(const bd_block_weights& w, const BlockPlan& p, const BlockBufs& b, float* x, int Mr, int D, float ln_eps) {
+    if (!w.ln_resid3 || !fold2_possible(w, p, b, x, Mr, D, ln_eps)) return false;
+    bd_gemm_args g = proj_args(w, b, x, Mr, D);
+    resid_from_copy(g, b, (int64_t)Mr * D, D, false);
+    return bd_gemm_takes_ln_fold(&g, p.c_proj) != 0;
+}
+inline ResidPlan plan_resid(const bd_block_weights& w, const BlockPlan& p, const BlockBufs& b, float* x, int Mr, int D, float ln_eps,
+                            bool emit_next, bool xn_is_stream, bool next_proj_c8, bool need_f32_out) {
+    ResidPlan r{};
+    r.fold2 = fold2_possible(w, p, b, x, Mr, D, ln_eps);
+    if (r.fold2 && emit_next && w.ln_resid3) {
+        bd_gemm_args g = fc2_args(w, b, x, Mr, D);
+        resid_from_copy(g, b, (int64_t)Mr * D, D, false);
+        r.fc2_c8 = bd_gemm_takes_ln_fold(&g, p.c_fc2) != 0;
+    }
+    r.proj_c8 = xn_is_stream && proj_c8_possible(w, p, b, x, Mr, D, ln_eps);
+    r.proj_f32 = !r.fc2_c8;                                  // (LayerNorm 2 as a kernel implies !fold2, hence !fc2_c8)
+    r.fc2_f32 = need_f32_out || !next_proj_c8;
+    return r;
+}
+
 // x += proj(ao); x += fc2(gelu(fc1(LN2 x)))  on Mr rows (the whole stream, or the query view's compact rows of the last block).
 // emit_next: the NEXT block's LayerNorm 1 is folded -- fc2 also writes the operand copy / row statistics of the rows it completes.
+// xn_is_stream: b.xn holds the stream's operand copy (this block's LayerNorm 1 was folded); next_proj_c8: the next block's proj can read it
+// from there; x_stale: see above (in: b.x is stale, out: it is stale after this block).
 int proj_mlp_stage(const bd_block_weights& w, const BlockPlan& p, const BlockBufs& b, float* x, int Mr, int D, float ln_eps, void* stream,
-                   bool emit_next = false) {
+                   bool emit_next = false, bool xn_is_stream = false, bool next_proj_c8 = false, bool need_f32_out = true,
+                   bool x_stale = false, bool* x_stale_out = nullptr) {
     const int64_t rD = (int64_t)Mr * D, r4D = (int64_t)Mr * 4 * D;
-    bd_gemm_args gp = gemm_args(b.ao, D, rD, w.proj, D, D, x, D, 0, 1, Mr, D, BD_ACT_NONE);
-    gp.resid = x; gp.ldr = D;
-    bd_gemm_args g1 = gemm_args(b.xn, D, rD, w.fc1, D, 4 * D, b.h, 4 * D, r4D, handoff_kind(p.c_fc1, p.c_fc2), Mr, D, BD_ACT_GELU);
-    // LayerNorm 2 folds when proj can emit and fc1 can apply
-    bool fold2 = false;
-    if (w.fc1_f.w && w.fc1_s && p.c_proj == BD_PREC_F16C8 && p.c_fc1 == BD_PREC_F16C8 && p.c_fc2 == BD_PREC_F16C8 && D == 768) {
-        bd_gemm_args cp = gp, c1 = gemm_args(b.xn, D, rD, w.fc1_f, D, 4 * D, b.h, 4 * D, r4D, 0, Mr, D, BD_ACT_GELU);
-        ln_producer(cp, b, rD, D);
-        ln_consumer(c1, b, w.fc1_s, ln_eps);
-        if (bd_gemm_takes_ln_fold(&cp, p.c_proj) && bd_gemm_takes_ln_fold(&c1, p.c_fc1)) { fold2 = true; gp = cp; g1 = c1; }
-    }
+    const ResidPlan r = plan_resid(w, p, b, x, Mr, D, ln_eps, emit_next, xn_is_stream, next_proj_c8, need_f32_out);
+    if (x_stale && !r.proj_c8) return BD_ERR_SHAPE;          // (the previous block's plan looked ahead: cannot happen)
+    bd_gemm_args gp = proj_args(w, b, x, Mr, D);
+    if (r.proj_c8) resid_from_copy(gp, b, rD, D, r.proj_f32);
+    else if (r.fold2) ln_producer(gp, b, rD, D);
     BD_TRY(bd_gemm(&gp, p.c_proj, stream));
-    if (!fold2) BD_TRY(bd_layernorm(x, D, w.ln2_w, w.ln2_b, ln_eps, b.xn, rD, nullptr, 0, Mr, D, 0, 0, 0, p.c_fc1, stream));
+    bd_gemm_args g1 = r.fold2 ? gemm_args(b.xn, D, rD, w.fc1_f, D, 4 * D, b.h, 4 * D, r4D, 0, Mr, D, BD_ACT_GELU)
+                              : gemm_args(b.xn, D, rD, w.fc1, D, 4 * D, b.h, 4 * D, r4D, handoff_kind(p.c_fc1, p.c_fc2), Mr, D, BD_ACT_GELU);
+    if (r.fold2) ln_consumer(g1, b, w.fc1_s, ln_eps);
+    else BD_TRY(bd_layernorm(x, D, w.ln2_w, w.ln2_b, ln_eps, b.xn, rD, nullptr, 0, Mr, D, 0, 0, 0, p.c_fc1, stream));
     BD_TRY(bd_gemm(&g1, p.c_fc1, stream));
-    {
-        bd_gemm_args g = gemm_args(b.h, 4 * D, r4D, w.fc2, 4 * D, D, x, D, 0, 1, Mr, 4 * D, BD_ACT_NONE);
-        g.resid = x; g.ldr = D;
-        if (emit_next) ln_producer(g, b, rD, D);
-        BD_TRY(bd_gemm(&g, p.c_fc2, stream));
-    }
+    bd_gemm_args g2 = fc2_args(w, b, x, Mr, D);
+    if (r.fc2_c8) resid_from_copy(g2, b, rD, D, r.fc2_f32);
+    else if (emit_next) ln_producer(g2, b, rD, D);
+    BD_TRY(bd_gemm(&g2, p.c_fc2, stream));
+    if (x_stale_out) *x_stale_out = r.fc2_c8 && !r.fc2_f32;
     return BD_OK;
 }
 
@@ -209,8 +262,7 @@ int proj_mlp_stage(const bd_block_weights& w, const BlockPlan& p, const BlockBuf
 inline bool next_ln1_folds(const bd_block_weights& w, const BlockPlan& p, const bd_block_weights* next, int wprec, const BlockBufs& b, int M, int D,
                            int heads, float ln_eps, float rms_eps) {
     if (!next || p.c_fc2 != BD_PREC_F16C8 || D != 768) return false;
-    bd_gemm_args g = gemm_args(b.h, 4 * D, (int64_t)M * 4 * D, w.fc2, 4 * D, D, b.x, D, 0, 1, M, 4 * D, BD_ACT_NONE);
-    g.resid = b.x; g.ldr = D;
+    bd_gemm_args g = fc2_args(w, b, b.x, M, D);
     ln_producer(g, b, (int64_t)M * D, D);
     if (!bd_gemm_takes_ln_fold(&g, p.c_fc2)) return false;
     const BlockPlan pn = plan_block(*next, wprec);
@@ -224,9 +276,11 @@ inline bool next_ln1_folds(const bd_block_weights& w, const BlockPlan& p, const 
 // rows there, whose results nobody consumes (row-wise operators: nothing leaks into the patch rows).
 // ln1_folded (in): this block's LayerNorm 1 is folded (the previous block's fc2 emitted for it); returns through *next_folded whether the
 // next block's is (this block's fc2 then emitted).
+// x_stale (in / out) and next_needs_f32: the 3-byte residual stream (proj_mlp_stage); next_compact: the next block runs its residual side on
+// other rows (the last decoder block), so its proj cannot read this block's copy.
 int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, int seq, int D, int heads, float ln_eps, float rms_eps,
               int wprec, void* stream, int n_prefix = 0, bool prefix_queries = true, bool ln1_folded = false,
-              const bd_block_weights* next = nullptr, bool* next_folded = nullptr) {
+              const bd_block_weights* next = nullptr, bool* next_folded = nullptr, bool* x_stale = nullptr, bool next_compact = false) {
     const BlockPlan p = plan_block(w, wprec);
     const int hd = D / heads;
     BD_TRY(qkv_stage(w, p, b, M, D, heads, ln_eps, rms_eps, stream, ln1_folded));
@@ -237,7 +291,14 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
         BD_TRY(bd_attention(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)M * D, batch, seq, heads, hd, scale, p.aprec, stream));
     const bool emit = next_ln1_folds(w, p, next, wprec, b, M, D, heads, ln_eps, rms_eps);
     if (next_folded) *next_folded = emit;
-    return proj_mlp_stage(w, p, b, b.x, M, D, ln_eps, stream, emit);
+    bool next_c8 = false;
+    if (emit && next && !next_compact) {
+        const BlockPlan pn = plan_block(*next, wprec);
+        next_c8 = proj_c8_possible(*next, pn, b, b.x, M, D, ln_eps);
+    }
+    const bool stale_in = x_stale ? *x_stale : false;
+    // fp32 rows after this block: the stack's last block (final norm / head), or a next block that gathers rows from b.x
+    return proj_mlp_stage(w, p, b, b.x, M, D, ln_eps, stream, emit, ln1_folded, next_c8, /*need_f32_out=*/next == nullptr || next_compact, stale_in, x_stale);
 }
 
 // Last decoder block: its output is consumed for the query view only (betr.py:303), so only K/V need every token.
@@ -341,13 +402,14 @@ extern "C" int bd_encoder_forward(const bd_dino_weights* w, const void* images, 
         BD_TRY(bd_gemm(&g, c_pe, stream));
     }
     BD_TRY(bd_write_prefix_tokens(e.blk.x, w->prefix_tokens, n_images, tpi, w->n_prefix, D, stream));
-    bool folded = false;           // LayerNorm 1 of block i is folded behind block i-1's fc2 (never block 0's)
+    bool folded = false, stale = false;      // LayerNorm 1 of block i is folded behind block i-1's fc2 (never block 0's); b.x is stale
     for (int i = 0; i < w->depth; ++i) {
         bool next_folded = false;
         BD_TRY(run_block(w->blocks[i], e.blk, Md, n_images, tpi, D, w->heads, w->ln_eps, 0.f, wprec, stream, w->n_prefix, i + 1 < w->depth,
-                         folded, i + 1 < w->depth ? &w->blocks[i + 1] : nullptr, &next_folded));
+                         folded, i + 1 < w->depth ? &w->blocks[i + 1] : nullptr, &next_folded, &stale));
         folded = next_folded;
     }
+    if (stale) return BD_ERR_SHAPE;          // (the last block writes fp32 rows: the final norm reads them)
     // final LayerNorm on the patch tokens only (vision_transformer.py:263-267); feats16 in the class the consumer's first Linear reads
     BD_TRY(bd_layernorm(e.blk.x, D, w->norm_w, w->norm_b, w->ln_eps, feats16, feats16_plane, feats32, D, Mp, D, P, tpi,
                         w->n_prefix, feats_prec, stream));
@@ -403,13 +465,14 @@ extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_fea
     }
     BD_TRY(bd_query_substitute(d.blk.x, d.rgb, w->pos_table, w->query_token, query_idx, B, T, P, D, stream));
     // K9: joint self-attention over all T*P tokens of a sample
-    bool folded = false;           // LayerNorm 1 of block i is folded behind block i-1's fc2 (never block 0's)
+    bool folded = false, stale = false;      // LayerNorm 1 of block i is folded behind block i-1's fc2 (never block 0's); b.x is stale
     for (int i = 0; i + 1 < w->depth; ++i) {
         bool next_folded = false;
         BD_TRY(run_block(w->blocks[i], d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, wprec, stream, 0, true, folded,
-                         &w->blocks[i + 1], &next_folded));
+                         &w->blocks[i + 1], &next_folded, &stale, /*next_compact=*/i + 2 == w->depth));
         folded = next_folded;
     }
+    if (stale) return BD_ERR_SHAPE;          // (the block in front of the last one writes fp32 rows: the last block gathers its query rows from them)
     // last block: query-view rows only past the K/V projection; d.t2 (dead since the adapter) holds the compact stream
     BD_TRY(run_last_block_query_only(w->blocks[w->depth - 1], d.blk, d.t2, query_idx, B, T, P, D, w->heads,
                                      w->ln_eps, w->rms_eps, wprec, stream, folded));

@@ -406,7 +406,7 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
                                             const float* rmsw, int wcol, int wm0, int wn0, int lane_, bool has_next, int nwm0, int nwn0,
                                             const float* rowp = nullptr, int wrow = 0) {
     static_assert(!LNF || (sizeof(T) == 2 && EP != 3 && EP != 4), "the LayerNorm fold's consumer side: 16-bit results of the 16-bit / F16C8 classes");
-    static_assert(EP != 4 || std::is_same<T, f16c8>::value, "the LayerNorm fold's producer side emits the F16C8 operand class");
+    static_assert((EP != 4 && EP != 5) || std::is_same<T, f16c8>::value, "the LayerNorm fold's producer side emits the F16C8 operand class");
     constexpr int COLS = 96;
     // The lane id is re-derived HERE from an opaque instruction pair, so that none of the epilogue's lane-dependent addressing can be
     // hoisted above the K loop, whose register budget (168) is full: hoisted, three of those values were spilled in the F16C8 / e4m3
@@ -578,6 +578,96 @@ __device__ __forceinline__ void pc_epilogue(const bd_gemm_args& p, f32x16 (&acc)
             const int row = wm0 + (c4 >> 2) * 32 + ((c4 >> 1) & 1) * 16 + (c4 & 1) * 8 + rsub;
             if (row < M) *(float2*)((unsigned char*)p.ln_stats_out + (size_t)(((unsigned)row * (unsigned)(p.N / 96) + (unsigned)(wn0 / 96)) * 8u)) = make_float2(keep_mean, keep_m2);
         }
+    } else if constexpr (EP == 5) {
+        // LayerNorm fold, producer side with the 3-byte residual stream (bd_gemm_args.ln_resid_in_op): the residual rows are the F16C8 operand
+        // copy the PREVIOUS residual Linear left at ln_op_out, the sum goes back there in place (+ its row statistics), and fp32 rows are
+        // written only for OUTK == OUT_F32 (someone reads the stream as fp32 before the next residual Linear).  Everything happens in the
+        // 16-bit row layout: a lane owns 3 x 8 columns of one row per 16-row chunk.  The residual pieces of chunk c + 1 (3 x 16 + 3 x 8
+        // bytes per lane) are requested BEFORE chunk c's stores, into the second of two register sets: on gfx9 loads and stores share
+        // the in-order vmcnt, so a load issued behind a store could only be waited for together with that store's acknowledgement.
+        static_assert(MI == 2, "four 16-row chunks, four lanes per row");
+        const int c8 = lane & 3, rsub = lane >> 2;
+        const unsigned ld = (unsigned)p.ln_op_ld;
+        unsigned char* const b0p = (unsigned char*)p.ln_op_out;
+        unsigned char* const b1p = b0p + 2 * p.ln_op_plane;
+        auto lo_index32 = [](unsigned e) { const unsigned g8 = (e >> 3) & 3u; return (e & ~31u) + (((g8 & 1u) << 4) | ((g8 >> 1) << 3)); };
+        u128 rh[2][3];
+        uint2 rl[2][3];
+        auto load_resid = [&](int buf, int ih) {
+            int row = wm0 + (ih >> 1) * 32 + (ih & 1) * 16 + rsub;
+            row = row < M ? row : M - 1;                    // (rows past the edge read a valid row; their results are never stored)
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const unsigned e = (unsigned)row * ld + (unsigned)(wn0 + cb * 32 + c8 * 8);
+                rh[buf][cb] = *(const u128*)(b0p + (size_t)(2u * e));
+                rl[buf][cb] = *(const uint2*)(b1p + (size_t)lo_index32(e));
+            }
+        };
+        float keep_mean = 0.f, keep_m2 = 0.f;
+        load_resid(0, 0);
+#pragma unroll
+        for (int ih = 0; ih < 2 * MI; ++ih) {
+            const int i = ih >> 1, hc = ih & 1, buf = ih & 1;
+            to_scratch(i, hc);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = hc * 8; r < hc * 8 + 8; ++r) acc[i][j][r] = 0.f;
+            if (ih + 1 < 2 * MI) load_resid(buf ^ 1, ih + 1);
+            const int gr = wm0 + i * 32 + hc * 16 + rsub;
+            float v[3][8];
+            float sum = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const float* src = (rsub < 8 ? sc : sc_hi - 8 * COLS) + rsub * COLS + cb * 32 + c8 * 8;
+                const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+                const f16x8 h = __builtin_bit_cast(f16x8, rh[buf][cb]);
+                const int l0 = (int)rl[buf][cb].x, l1 = (int)rl[buf][cb].y;
+                const float lo[8] = {__builtin_amdgcn_cvt_f32_fp8(l0, 0), __builtin_amdgcn_cvt_f32_fp8(l0, 1), __builtin_amdgcn_cvt_f32_fp8(l0, 2),
+                                     __builtin_amdgcn_cvt_f32_fp8(l0, 3), __builtin_amdgcn_cvt_f32_fp8(l1, 0), __builtin_amdgcn_cvt_f32_fp8(l1, 1),
+                                     __builtin_amdgcn_cvt_f32_fp8(l1, 2), __builtin_amdgcn_cvt_f32_fp8(l1, 3)};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = fmaf(lo[e], 1.0f / (float)(1 << BD_F16C8_D), (float)h[e]);      // the residual element: hi + lo8 2^-D (exact in fp32)
+                    v[cb][e] = (e < 4 ? a0[e] : a1[e - 4]) + x;
+                    sum += v[cb][e];
+                }
+            }
+            const float mean = quad_sum(sum) * (1.0f / 96.0f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[cb][e] - mean; m2 = fmaf(d, d, m2); }
+            m2 = quad_sum(m2);
+            if (c8 == ih) { keep_mean = mean; keep_m2 = m2; }
+            if (gr < M) {
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) {
+                    const unsigned e = (unsigned)gr * ld + (unsigned)(wn0 + cb * 32 + c8 * 8);
+                    if constexpr (OUTK == OUT_F32) {
+                        float* op = (float*)p.out + (int64_t)gr * p.ldo + wn0 + cb * 32 + c8 * 8;
+                        *(f32x4*)op = (f32x4){v[cb][0], v[cb][1], v[cb][2], v[cb][3]};
+                        *(f32x4*)(op + 4) = (f32x4){v[cb][4], v[cb][5], v[cb][6], v[cb][7]};
+                    }
+                    _Float16 hh[8];
+                    float lo[8];
+                    f16c8_split<8>(v[cb], hh, lo);
+                    f16x8 hv;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) hv[q] = hh[q];
+                    int l0 = 0, l1 = 0;
+                    l0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], l0, false); l0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], l0, true);
+                    l1 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[4], lo[5], l1, false); l1 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[6], lo[7], l1, true);
+                    *(u128*)(b0p + (size_t)(2u * e)) = __builtin_bit_cast(u128, hv);
+                    *(uint2*)(b1p + (size_t)lo_index32(e)) = make_uint2((unsigned)l0, (unsigned)l1);
+                }
+            }
+        }
+        {   // the four chunks' (mean, M2) pairs in one store: lane (rsub, c8) holds chunk c8 of row group rsub
+            const int row = wm0 + (c8 >> 1) * 32 + (c8 & 1) * 16 + rsub;
+            if (row < M) *(float2*)((unsigned char*)p.ln_stats_out + (size_t)(((unsigned)row * (unsigned)(p.N / 96) + (unsigned)(wn0 / 96)) * 8u)) = make_float2(keep_mean, keep_m2);
+        }
     } else if constexpr (EP == 1 && NS == 1 && sizeof(T) == 2 && OUTK == OUT_OPERAND) {
         // Plain bf16 / f16 result (optional GELU): rounded to 16 bits BEFORE the LDS round trip, two adjacent rows per dword
         // (registers r, r + 1 of a C fragment are rows 2 k, 2 k + 1 of the same column), so the transposition moves half the bytes:
@@ -708,10 +798,11 @@ __device__ __forceinline__ float2 ln_rows_combine(const f32x4 (&st)[4], float ep
     return make_float2(rstd, -mean * rstd);
 }
 // host side: do these arguments ask for the fold, and are they well-formed for it (the kernel forms are checked by the launchers)
-inline bool ln_fold_producer(const bd_gemm_args& a) { return a.ln_stats_out != nullptr || a.ln_op_out != nullptr; }
+inline bool ln_fold_producer(const bd_gemm_args& a) { return a.ln_stats_out != nullptr || a.ln_op_out != nullptr || a.ln_resid_in_op != 0; }
 inline bool ln_fold_consumer(const bd_gemm_args& a) { return a.ln_stats_in != nullptr || a.ln_colsum != nullptr; }
 inline bool ln_fold_producer_ok(const bd_gemm_args& a) {
-    return a.ln_stats_out && a.ln_op_out && a.out_f32 == OUT_F32 && a.N == 768 && a.act == BD_ACT_NONE && !a.rms_wq && !a.addtab && a.rpg_in <= 0 &&
+    if (a.ln_resid_in_op ? (a.resid != nullptr || (a.out_f32 != OUT_F32 && a.out_f32 != OUT_OPERAND)) : a.out_f32 != OUT_F32) return false;
+    return a.ln_stats_out && a.ln_op_out && a.N == 768 && a.act == BD_ACT_NONE && !a.rms_wq && !a.addtab && a.rpg_in <= 0 &&
            !a.wscale && a.ln_op_ld % 32 == 0 && a.ln_op_plane % 8 == 0 && (((uintptr_t)a.ln_op_out | (uintptr_t)a.ln_stats_out) & 15) == 0 &&
            (int64_t)a.M * a.ln_op_ld < ((int64_t)1 << 30);        // (the epilogue addresses the copy with 32-bit byte offsets)
 }

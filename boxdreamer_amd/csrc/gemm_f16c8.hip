@@ -347,7 +347,14 @@ bool bd_f16c8_takes_ln_fold(const bd_gemm_args& a) {
     const int ep = f16c8_epilogue_kind(a, outk, gelu);
     const bool s3 = (a.K / 32) % 3 == 0;
     if (!s3 || !wide_epilogue_ok(a, 2)) return false;
-    if (ln_fold_producer(a) && !(ln_fold_producer_ok(a) && ep == 3)) return false;
+    if (ln_fold_producer(a)) {
+        if (!ln_fold_producer_ok(a)) return false;
+        // the fp32-residual epilogue's launch conditions (f16c8_epilogue_kind's ep == 3), also for the form that reads the residual from the
+        // operand copy and may write no fp32 rows at all
+        const bool base = !a.addtab && a.rpg_in <= 0 && !a.wscale && a.N % 192 == 0 && a.K >= 128 && !(a.bias && ((uintptr_t)a.bias & 15)) &&
+                          !gelu && !a.rms_wq;
+        if (!base || (!a.ln_resid_in_op && ep != 3)) return false;
+    }
     if (ln_fold_consumer(a)) {
         if (!ln_fold_consumer_ok(a)) return false;
         const bool form = (ep == 1 && gelu && outk == OUT_OPERAND) || (ep == 1 && !gelu && (outk == OUT_F16 || outk == OUT_BF16X2)) ||
@@ -394,8 +401,15 @@ int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     // fc2 (deep K, 4 column tiles) below ~4096 rows: 128 x 96 tiles on 2 + 2 waves -- four times the workgroups of the large form, still at most
     // one per CU -- is another 17 % faster than the 128 x 192 form (52 vs 63 us at 1536 rows; everywhere else it is slower:
     // profiles/r5_f16c8_small_form.md).  One instance (+ its LayerNorm-fold producer twin).
-    const bool fc2_96 = ep == 3 && small && a.K >= 2048 && a.N % 96 == 0 && 4 * tiles * bd_concurrent_launches() <= cus;
-    if (lnp && fc2_96)
+    const bool r5 = lnp && a.ln_resid_in_op;              // the residual comes from (and goes back to) the operand copy: EP 5
+    const bool fc2_96 = (ep == 3 || r5) && small && a.K >= 2048 && a.N % 96 == 0 && 4 * tiles * bd_concurrent_launches() <= cus;
+    if (r5 && fc2_96 && a.out_f32 == OUT_F32)
+        hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 5, OUT_F32, false, 2, 1, 2>), dim3(((a.M + 127) / 128) * (a.N / 96)), dim3(256), 0, s, a);
+    else if (r5 && fc2_96)
+        hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 5, OUT_OPERAND, false, 2, 1, 2>), dim3(((a.M + 127) / 128) * (a.N / 96)), dim3(256), 0, s, a);
+    else if (r5 && a.out_f32 == OUT_F32) BD_C8_LAUNCH_LN(5, OUT_F32, false, false)
+    else if (r5) BD_C8_LAUNCH_LN(5, OUT_OPERAND, false, false)
+    else if (lnp && fc2_96)
         hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 4, OUT_F32, false, 2, 1, 2>), dim3(((a.M + 127) / 128) * (a.N / 96)), dim3(256), 0, s, a);
     else if (lnp) BD_C8_LAUNCH_LN(4, OUT_F32, false, false)
     else if (lnc && ep == 1 && gelu) BD_C8_LAUNCH_LN(1, OUT_OPERAND, true, true)

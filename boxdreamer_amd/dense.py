@@ -11,8 +11,9 @@ several decoder rounds.  Host mirror of the reference's helpers, same names / ar
 The arithmetic that scales with the database size -- the L x L patch-similarity of every (query, reference) pair -- runs in
 HIP (csrc/match.hip: one pass over the patch features per view, closed form of the reference's masked mean) together with
 the top-k selection; the decoder rounds reuse BETR unchanged.  View selection / re-packing of the batch tensors is torch
-indexing on the device (plumbing).  Pose recovery inside the multi-round mode goes through the host PnP (pnp.py), whose
-parity against OpenCV is un-pinned in this image.
+indexing on the device (plumbing).  Pose recovery inside the multi-round mode goes through the host RANSAC PnP (pnp.solve_pnp_ransac:
+the reference's cv2.solvePnPRansac call where cv2 imports, a restatement of the scheme otherwise), whose parity against OpenCV is
+un-pinned in this image.
 """
 from __future__ import annotations
 
@@ -76,13 +77,44 @@ def _filter(x, camera_mask, neighbor_mask):
     return torch.cat([ref, x[camera_mask].unsqueeze(1)], dim=1)
 
 
+def _filter_index(camera_mask, neighbor_mask):
+    """The view indices `_filter` keeps, (B, k + 1): the selected references in their original order, the query last."""
+    B, T = camera_mask.shape
+    ar = torch.arange(T, device=camera_mask.device).expand(B, T)
+    ref = ar[~camera_mask].reshape(B, T - 1)[neighbor_mask].reshape(B, -1)
+    return torch.cat([ref, ar[camera_mask].reshape(B, 1)], dim=1)
+
+
+def _filter_features(rgb_feature, camera_mask, neighbor_mask):
+    """`_filter` for the encoder features: the same views, WITH their operand-dtype copy (cache.take_views) -- a plain index would drop
+    it and BETR would re-cast the features on every forward (the dense path always ran that slow path)."""
+    from .cache import take_views
+    if rgb_feature.dim() != 4:
+        return _filter(rgb_feature, camera_mask, neighbor_mask)
+    return take_views(rgb_feature, _filter_index(camera_mask, neighbor_mask))
+
+
+def _sub_index(camera_mask, sub):
+    """View indices of `_sub`, (B, rounds, sub + 1): `sub` consecutive references per round (-1 where the last round runs out), query last."""
+    B, T = camera_mask.shape
+    ar = torch.arange(T, device=camera_mask.device).expand(B, T)
+    ref, q = ar[~camera_mask].reshape(B, T - 1), ar[camera_mask].reshape(B)
+    rounds = (T - 1 + sub - 1) // sub
+    idx = torch.full((B, rounds, sub + 1), -1, dtype=torch.long, device=camera_mask.device)
+    for i in range(rounds):
+        end = min((i + 1) * sub, T - 1)
+        idx[:, i, :end - i * sub] = ref[:, i * sub:end]
+        idx[:, i, sub] = q
+    return idx
+
+
 def filter_by_neighbor_mask(data, neighbor_mask, pose_feat, frames, camera_mask, rgb_feature, image_masks):
     """Keep the selected references (original order) followed by the query view; updates the batch dict like the
     reference's update_filtered_data (bbox_feat, images, query_idx, camera_mask, poses and the per-view tensors)."""
     B = frames.shape[0]
     new_pose_feat = _filter(pose_feat, camera_mask, neighbor_mask)
     new_frames = _filter(frames, camera_mask, neighbor_mask)
-    new_rgb = _filter(rgb_feature, camera_mask, neighbor_mask) if rgb_feature is not None else None
+    new_rgb = _filter_features(rgb_feature, camera_mask, neighbor_mask) if rgb_feature is not None else None
     new_masks = _filter(image_masks, camera_mask, neighbor_mask) if image_masks is not None else None
     T = new_frames.shape[1]
     new_camera_mask = torch.zeros(B, T, dtype=torch.bool, device=camera_mask.device)
@@ -159,8 +191,10 @@ def fetch_neighbors_by_pose_similarity(gt_poses, pred_pose, topk=5):
 
 def recover_pose_from_dense_bb8(query_rets, bbox_3d, K):
     """query_rets (B, R, 8, H, W) heatmaps of R decoder rounds; bbox_3d (B, 8, 3); K (B, 3, 3).  All R*8 decoded corners of
-    a sample go into one PnP (box_utils.py:202-300; the reference tries solvePnPRansac first -- not available here, the
-    iterative solver it falls back to is used directly).  Returns poses (B, 1, 4, 4), normalised corners (B, R, 8, 2)."""
+    a sample go into one RANSAC PnP (box_utils.py:202-300: solvePnPRansac at 2 px / 0.99 / 1000 trials, ITERATIVE on failure --
+    pnp.solve_pnp_ransac: cv2's own call where importable, else this repo's restatement of the scheme): a round whose corners are off
+    is rejected instead of pulling the coarse pose (and with it the fine level's neighbour choice).  Returns poses (B, 1, 4, 4),
+    normalised corners (B, R, 8, 2)."""
     B, R = query_rets.shape[:2]
     norm_kp, kp_px, _ = recover_bb8_corners_chw(query_rets.reshape(B * R, *query_rets.shape[2:]))
     kp = kp_px.reshape(B, R * 8, 2).cpu().numpy()
@@ -169,7 +203,7 @@ def recover_pose_from_dense_bb8(query_rets, bbox_3d, K):
     poses = np.zeros((B, 1, 4, 4), np.float32)
     for b in range(B):
         try:
-            ok, Rm, t = pnp.solve_pnp_iterative(np.tile(b3[b], (R, 1)), kp[b], Kh[b])
+            ok, Rm, t, _ = pnp.solve_pnp_ransac(np.tile(b3[b], (R, 1)), kp[b], Kh[b], reproj_err=2.0, confidence=0.99, max_trials=1000, seed=b)
         except Exception as e:  # noqa: BLE001
             print(f"PnP failed due to exception: {e}")
             continue
@@ -190,15 +224,24 @@ def process_multi_round(data, pose_feat, frames, camera_mask, rgb_feature, image
     K = data["non_ndc_intrinsics"].clone()
     bbox_3d = data["bbox_3d"].clone()
     sub = int(_get(dense_cfg, "sub_batch_size"))
+    from .cache import take_views
     npf, nfr, ncm, nrf, _ = sub_batchify(pose_feat, frames, camera_mask, rgb_feature, None, sub)
     R = npf.shape[1]
+    # the rounds' features WITH their operand-dtype copies (same values as `nrf`; cache.take_views): BETR does not re-cast them
+    sidx = _sub_index(camera_mask, sub)                                   # (B, R, sub + 1) view indices, -1 = zero padding
+    tagged = rgb_feature.dim() == 4
     if _get(dense_cfg, "dense_mem_friendly"):
-        outs = [decoder(npf[:, i].contiguous(), nfr[:, i].contiguous(), ncm[:, i], nrf[:, i].contiguous(), None).clone()
-                for i in range(R)]
+        outs = [decoder(npf[:, i].contiguous(), nfr[:, i].contiguous(), ncm[:, i],
+                        take_views(rgb_feature, sidx[:, i]) if tagged else nrf[:, i].contiguous(), None).clone() for i in range(R)]
         query_rets = torch.stack(outs, dim=1)
     else:
-        flat = decoder(npf.reshape(B * R, *npf.shape[2:]), nfr.reshape(B * R, *nfr.shape[2:]), ncm.reshape(B * R, -1),
-                       nrf.reshape(B * R, *nrf.shape[2:]), None)
+        feats = (take_views(rgb_feature, sidx.reshape(B, R * (sub + 1))) if tagged else nrf)
+        if tagged:      # (B, R (sub + 1), P, C) -> (B R, sub + 1, P, C): the same storage, the operand copy follows the alias
+            from . import features as _features
+            feats = _features.carry(feats, feats.reshape(B * R, sub + 1, *feats.shape[2:]))
+        else:
+            feats = feats.reshape(B * R, *nrf.shape[2:])
+        flat = decoder(npf.reshape(B * R, *npf.shape[2:]), nfr.reshape(B * R, *nfr.shape[2:]), ncm.reshape(B * R, -1), feats, None)
         query_rets = flat.reshape(B, R, *flat.shape[1:])
     query_poses, pred_proj = recover_pose_from_dense_bb8(query_rets, bbox_3d[camera_mask], K[camera_mask])
     if _get(dense_cfg, "fine_level"):
@@ -208,7 +251,8 @@ def process_multi_round(data, pose_feat, frames, camera_mask, rgb_feature, image
         neighbor_mask.scatter_(1, idx.to(poses.device), True)
         data, pose_feat, frames, camera_mask, rgb_feature, image_masks = filter_by_neighbor_mask(
             data, neighbor_mask, pose_feat, frames, camera_mask, rgb_feature, image_masks)
-        return decoder(pose_feat.contiguous(), frames.contiguous(), camera_mask, rgb_feature.contiguous(), None)
+        from . import features as _features
+        return decoder(pose_feat.contiguous(), frames.contiguous(), camera_mask, _features.carry(rgb_feature, rgb_feature.contiguous()), None)
     pred_poses = poses.clone()
     data["pred_bbox"] = pose_feat.clone()
     data["pred_bbox"][camera_mask] = query_rets[:, 0].to(pose_feat.dtype)

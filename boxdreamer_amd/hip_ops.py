@@ -110,7 +110,7 @@ _OUT_SPLIT = {4: torch.bfloat16, 5: torch.float16}
 
 def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, addtab=None, out=None,
          out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0), wscale=None, out_mode=None, w_qexp=0, rms=None,
-         ln_emit=None, ln_apply=None):
+         ln_emit=None, ln_apply=None, ln_resid_in_op=False):
     """out[map(r)] = act(wscale * (A W^T) + bias) + addtab[r % rows(addtab)] + resid[map(r)].
     out_mode: None -> operand dtype (or fp32 with out_f32), 2 -> f16 single plane, 3 -> bf16 single plane, 4 -> split-bf16 (hi, lo)
     planes, 5 -> split-f16 (hi, lo) planes (bd_gemm_args.out_f32, include/boxdreamer_hip.h).
@@ -152,6 +152,7 @@ def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, add
     if ln_emit is not None:
         st, op = ln_emit
         g.ln_stats_out, g.ln_op_out, g.ln_op_plane, g.ln_op_ld = ptr(st), ptr(op), op[0].numel(), op[0].stride(0)
+        g.ln_resid_in_op = int(bool(ln_resid_in_op))      # the residual rows are read from (and the sum written back to) `op`; fp32 rows only with out_f32
     if ln_apply is not None:
         g.ln_stats_in, g.ln_colsum, g.ln_eps = ptr(ln_apply[0]), ptr(ln_apply[1]), float(ln_apply[2])
     if (ln_emit is not None or ln_apply is not None) and not lib.bd_gemm_takes_ln_fold(C.byref(g), prec_id(prec)):

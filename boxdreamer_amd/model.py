@@ -137,8 +137,10 @@ class BoxDreamer(nn.Module):
 
         if images.device != self.rgb_encoder.get_device():
             self.rgb_encoder.to_device(images.device)                            # BoxDreamerModel.py:279-282
+        sig = None
         if isinstance(self.decoder, BETR):     # (tests swap the decoder for a stub: nothing to check then)
-            if (self._calibrated_for != self.decoder._signature() and images.is_cuda and not torch.cuda.is_current_stream_capturing()
+            sig = self.decoder._signature()    # (walks every parameter: computed once per forward and handed on)
+            if (self._calibrated_for != sig and images.is_cuda and not torch.cuda.is_current_stream_capturing()
                     and calibrate.applicable(self.rgb_encoder, self.decoder)):
                 if self._calibrated_for is None and calibrate.has_state(self.rgb_encoder, self.decoder):
                     self.mark_calibrated()       # a state the caller applied before the first forward is kept, not measured over
@@ -153,9 +155,10 @@ class BoxDreamer(nn.Module):
         dense = self.dense_cfg is not None and _get(self.dense_cfg, "enable", False)
         if (self.hip_graph and not dense and "cached_rgb_feat" not in data and not self.training and images.is_cuda
                 and isinstance(self.decoder, BETR) and not torch.cuda.is_current_stream_capturing()):
-            heat, kp_px, kn, _ = self._graphed(images, pose_feat, qi)
-            # (the replay's outputs are static buffers the next replay overwrites: the caller gets its own tensors)
-            query_ret, decoded = heat.clone(), (kn.clone(), kp_px.clone())
+            heat, kp_px, kn, _ = self._graphed(images, pose_feat, qi, sig if self._calibrated_for == sig else None)
+            # (the replay's outputs are static buffers the next replay overwrites: what the caller keeps is copied out of them below --
+            # pred_bbox's query slot is written straight from the static heat map, the corners get their own tensors)
+            query_ret, decoded = heat, (kn.clone(), kp_px.clone())
             self.decoder.mask_error = None          # query_idx indexes one view per sample by construction
         else:
             if "cached_rgb_feat" in data:       # "next" row f1: references encoded once per object (boxdreamer_amd/cache.py)
@@ -198,12 +201,12 @@ class BoxDreamer(nn.Module):
         self.host_syncs_per_forward = syncs
         return data
 
-    def _graphed(self, images, pose_feat, qi):
+    def _graphed(self, images, pose_feat, qi, sig=None):
         """Replay (capturing first, per batch shape) encoder -> decoder -> corner decode as one HIP graph; returns the graph's STATIC
         output tensors (heat, corners px, corners normalised, None)."""
         from .graph import GraphedPath
         B, T = images.shape[:2]
-        key = (B, T, images.shape[-1], images.dtype, pose_feat.dtype, str(images.device), self.decoder._signature(),
+        key = (B, T, images.shape[-1], images.dtype, pose_feat.dtype, str(images.device), sig if sig is not None else self.decoder._signature(),
                self.rgb_encoder.model.state_stamp(self.rgb_encoder.prec), str(self.decoder.hip_precision))
         if self._graph is None or self._graph_key != key:
             self._graph = None                      # lifts the modules' freeze before anything re-allocates

@@ -239,6 +239,7 @@ def _pack_ln_fold(pk: "Packed", bw, sd: dict, p: str, device, qk_norm: bool) -> 
     """The gain-folded copies of the two Linears that follow a LayerNorm, in the F16C8 layout, + the column sums of the ROUNDED weights
     each launch multiplies (include/boxdreamer_hip.h: bd_block_weights.qkv_f ...)."""
     from . import hip_ops
+    bw.ln_resid3 = int(os.environ.get("BOXDREAMER_HIP_RESID3", "1") != "0")       # (A/B switch, read at pack time like BOXDREAMER_HIP_LNFOLD)
     for name, norm, lin, fs in (("qkv_f", "norm1", "attn.qkv", "qkv_s"), ("fc1_f", "norm2", "mlp.fc1", "fc1_s")):
         wf, bf = fold_layernorm(sd[p + lin + ".weight"], sd[p + lin + ".bias"], sd[p + norm + ".weight"], sd[p + norm + ".bias"])
         packed, qexp = pack_linear_weight(wf, _lib.PREC_F16C8, return_scale=True)

@@ -232,3 +232,80 @@ def solve_pnp_batched(p3: np.ndarray, p2: np.ndarray, K: np.ndarray, iters: int 
     tout = x[:, 3:].copy()
     Rout[~ok] = np.eye(3); tout[~ok] = 0.0
     return ok, Rout, tout
+
+
+# ------------------------------------------------------------------------------------------------
+# RANSAC form (round 6): the dense multi-round pose.  The reference feeds the R x 8 corners of all decoder rounds to
+# cv2.solvePnPRansac(reprojectionError=2.0, confidence=0.99, iterationsCount=1000, flags=SOLVEPNP_ITERATIVE) and falls back to
+# cv2.solvePnP only when that fails (reference: src/models/utils/box_utils.py:266-285): one bad round's corners are REJECTED, not
+# averaged in.  With cv2 importable that exact call is used.  Without it: the same scheme -- minimal-sample hypotheses (6 distinct 3-D
+# points: the DLT's minimum; the rounds repeat the same 8 box corners, so a sample never takes one corner twice), inliers within
+# `reproj_err` pixels, an adaptive trial count from the best inlier ratio, a final ITERATIVE solve on the inliers of the best hypothesis.
+# Hypotheses are generated and scored in vectorised batches (solve_pnp_batched).  Sampling is deterministic (a Philox counter stream
+# keyed by `seed`): the same corners give the same pose on every box.  OpenCV's own sampler / minimal solver (EPnP on 5 points) are NOT
+# reproduced: parity against its binary is un-pinned, like the rest of this file.
+
+def _reproj_px(R, t, p3, p2, K):
+    pc = p3 @ np.swapaxes(R, -1, -2) + t[..., None, :]
+    z = pc[..., 2:3]
+    uv = pc[..., :2] / np.where(np.abs(z) < 1e-12, 1e-12, z) * np.stack([K[0, 0], K[1, 1]]) + K[:2, 2]
+    err = np.linalg.norm(uv - p2, axis=-1)
+    return np.where(z[..., 0] > 0, err, np.inf)            # a point behind the camera is never an inlier
+
+
+def solve_pnp_ransac(p3: np.ndarray, p2: np.ndarray, K: np.ndarray, reproj_err: float = 2.0, confidence: float = 0.99,
+                     max_trials: int = 1000, seed: int = 0, batch: int = 32):
+    """(success, R (3,3), t (3,), inlier mask (n,) bool).  p3 (n,3) may repeat 3-D points (several 2-D observations of one corner)."""
+    p3 = np.asarray(p3, np.float64)
+    p2 = np.asarray(p2, np.float64)
+    K = np.asarray(K, np.float64)
+    n = p3.shape[0]
+    if _HAVE_CV2:  # pragma: no cover - the reference's own call when it is importable
+        ok, rvec, tvec, inl = cv2.solvePnPRansac(p3.astype(np.float32), p2.astype(np.float32), K.astype(np.float32), None,
+                                                 reprojectionError=float(reproj_err), confidence=float(confidence),
+                                                 flags=cv2.SOLVEPNP_ITERATIVE, iterationsCount=int(max_trials))
+        if ok:
+            mask = np.zeros(n, bool)
+            if inl is not None:
+                mask[np.asarray(inl).reshape(-1)] = True
+            return True, cv2.Rodrigues(rvec)[0], tvec.reshape(3), mask
+        ok, R, t = solve_pnp_iterative(p3, p2, K)
+        return ok, R, t, np.ones(n, bool)
+    # distinct 3-D points (the rounds repeat the box corners): a sample draws S distinct corners, then one observation of each
+    _, corner_of = np.unique(np.round(p3, 9), axis=0, return_inverse=True)
+    corner_of = corner_of.reshape(-1)
+    n_corners = int(corner_of.max()) + 1
+    S = 6
+    if n_corners < S or not np.isfinite(p2).all():
+        ok, R, t = solve_pnp_iterative(p3, p2, K)
+        return ok, R, t, np.ones(n, bool)
+    obs = [np.nonzero(corner_of == c)[0] for c in range(n_corners)]
+    rng = np.random.Generator(np.random.Philox(key=int(seed) & 0xFFFFFFFFFFFFFFFF))
+    best_mask, best_cnt, best_err = None, -1, np.inf
+    trials, need = 0, max_trials
+    while trials < min(need, max_trials):
+        h = min(batch, max_trials - trials)
+        corners = np.argsort(rng.random((h, n_corners)), axis=1)[:, :S]               # S distinct corners per hypothesis
+        pick = np.stack([[obs[c][int(rng.integers(len(obs[c])))] for c in row] for row in corners])      # one observation of each
+        ok, R, t = solve_pnp_batched(p3[pick], p2[pick], np.broadcast_to(K, (h, 3, 3)), iters=5)
+        err = _reproj_px(R, t, p3[None], p2[None], K)                                     # (h, n)
+        inl = err < reproj_err
+        cnt = np.where(ok, inl.sum(1), -1)
+        tot = np.where(inl, err, 0.0).sum(1)
+        for i in np.argsort(-cnt, kind="stable")[:1]:                                     # the batch's best; ties: lowest index
+            if cnt[i] > best_cnt or (cnt[i] == best_cnt and tot[i] < best_err):
+                best_cnt, best_err, best_mask = int(cnt[i]), float(tot[i]), inl[i].copy()
+        trials += h
+        w = max(best_cnt, 0) / n
+        if w >= 1.0:
+            break
+        if w > 0:                                                                          # trials for `confidence` at this inlier ratio
+            need = int(np.ceil(np.log(1.0 - confidence) / np.log(max(1.0 - w ** S, 1e-300))))
+    if best_mask is None or best_cnt < S or len(np.unique(corner_of[best_mask])) < S:
+        ok, R, t = solve_pnp_iterative(p3, p2, K)                                         # the reference's fallback (box_utils.py:280-285)
+        return ok, R, t, np.ones(n, bool)
+    ok, R, t = solve_pnp_iterative(p3[best_mask], p2[best_mask], K)
+    if not ok:
+        ok, R, t = solve_pnp_iterative(p3, p2, K)
+        return ok, R, t, np.ones(n, bool)
+    return True, R, t, best_mask

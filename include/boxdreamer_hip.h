@@ -171,6 +171,12 @@ typedef struct bd_gemm_args {
      * Ask bd_gemm_takes_ln_fold first: launches that would not run on a kernel form with these epilogues return BD_ERR_SHAPE. */
     float* ln_stats_out; void* ln_op_out; int64_t ln_op_plane; int64_t ln_op_ld;
     const float* ln_stats_in; const float* ln_colsum; float ln_eps;
+    /* producer side, the 3-byte residual stream: 1 = the residual rows are READ from the operand copy at ln_op_out (x = hi + lo8 2^-11, exactly
+     * what the consumer Linears multiply) instead of `resid` (which must be NULL), the sum is written back there in place, and the fp32 rows
+     * at `out` are written only with out_f32 == 1 (out_f32 == 0: `out` is ignored -- nobody reads the stream as fp32 before the next residual
+     * Linear).  Per residual Linear 3 + 3 bytes per element cross HBM instead of 4 + 7; the stream is rounded to the operand class (~2^-15
+     * relative) once per residual add (tools/lnfold_sim.py RESID3=1: logits 2.2e-4 -> 2.6e-4 at full depth). */
+    int ln_resid_in_op;
 } bd_gemm_args;
 int bd_gemm(const bd_gemm_args* args /*[host]*/, int prec, void* stream);
 /* 1 if bd_gemm(args, prec) serves the ln_* fields that are set in args (producer and / or consumer side of the LayerNorm fold), else 0. */
@@ -330,6 +336,8 @@ typedef struct bd_block_weights {
      * plane), and the column sums s[n] = sum_k W'[n, k] of the ROUNDED weights each launch multiplies (qkv16_s: of the f16 copy's q, k rows) */
     bd_linear qkv_f, fc1_f, qkv16_f;
     const float* qkv_s; const float* fc1_s; const float* qkv16_s;
+    int ln_resid3;    /* != 0: between folded LayerNorms the residual stream of this block may live in the 3-byte operand form only
+                         (bd_gemm_args.ln_resid_in_op); 0: every residual Linear reads and writes the fp32 stream */
 } bd_block_weights;
 
 typedef struct bd_dino_weights {

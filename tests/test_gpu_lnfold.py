@@ -74,6 +74,46 @@ def test_producer_rows_do_not_depend_on_the_launch_form(hip, K):
         assert torch.equal(op[0], big[2][0][:rows]) and torch.equal(_lo8(op, rows, 768), _lo8(big[2], rows, 768)), (K, rows)
 
 
+@pytest.mark.parametrize("M,K", [(49152, 768), (1536, 768), (1000, 3072), (300, 768), (50112, 3072)])
+def test_producer_with_the_residual_in_the_operand_copy(hip, M, K):
+    """bd_gemm_args.ln_resid_in_op (the 3-byte residual stream): the residual rows are the F16C8 copy the previous residual Linear left, the
+    sum goes back in place (+ row statistics); fp32 rows only on request.  Against fp64 on the decoded planes + the decoded residual."""
+    N = 768
+    a, w, b = _rand("a", (M, K), seed=7).cuda(), _rand("w", (N, K), 0.04, 7).cuda(), _rand("b", (N,), 0.3, 7).cuda()
+    x0 = (_rand("r", (M, N), 2.0, 7) + 0.7).cuda()
+    e = hip_ops.f16c8_qexp(w)
+    a16, w16 = hip_ops.f16c8_encode(a, 0, False), hip_ops.f16c8_encode(w, e, True)
+    outs = []
+    for f32 in (False, True):
+        op = hip_ops.f16c8_encode(x0, 0, False)                          # the stream as the previous residual Linear left it
+        st = torch.full((M, 8, 2), float("nan"), dtype=torch.float32, device="cuda")
+        dummy = torch.zeros((2, M, N), dtype=torch.float16, device="cuda") if not f32 else None
+        out = hip_ops.gemm(a16, w16, b, prec="f16c8", w_qexp=e, out_f32=f32, out=dummy, ln_emit=(st, op), ln_resid_in_op=True)
+        outs.append((out, st, op))
+    (_, st0, op0), (o32, st1, op1) = outs
+    assert torch.equal(op0[0], op1[0]) and torch.equal(_lo8(op0, M, N), _lo8(op1, M, N)) and torch.equal(st0, st1)
+    ref = hip_ops.f16c8_encode(o32, 0, False)                            # the copy IS the reference packing of the fp32 rows
+    assert torch.equal(op1[0], ref[0]) and torch.equal(_lo8(op1, M, N), _lo8(ref, M, N))
+    rows = torch.arange(0, M, max(1, M // 129), device="cuda")
+    ah, al, aq = (t.double()[rows] for t in hip_ops.f16c8_decode(a16))
+    wh, wl, wq = (t.double() for t in hip_ops.f16c8_decode(w16, e, True))
+    want = ah @ wh.t() + al @ wq.t() + aq @ wl.t() + b.double() + hip_ops.from_operand(hip_ops.f16c8_encode(x0, 0, False), "f16c8")[rows].double()
+    assert (o32[rows].double() - want).abs().max().item() <= 2e-5 * K ** 0.5 + 1e-5
+    xd = o32.double().reshape(M, 8, 96)
+    mean = xd.mean(-1)
+    m2 = ((xd - mean[..., None]) ** 2).sum(-1)
+    assert (st1[..., 0].double() - mean).abs().max().item() <= 2e-6 * float(xd.abs().max())
+    assert ((st1[..., 1].double() - m2).abs() / m2.clamp_min(1e-3)).max().item() <= 2e-5
+    # form independence: the head rows of the large launch launched alone (small forms)
+    if M == 49152:
+        for rws in (1536, 300):
+            op = hip_ops.f16c8_encode(x0[:rws], 0, False)
+            st = torch.zeros((rws, 8, 2), dtype=torch.float32, device="cuda")
+            hip_ops.gemm(hip_ops.f16c8_encode(a[:rws], 0, False), w16, b, prec="f16c8", w_qexp=e, out_f32=False,
+                         out=torch.zeros((2, rws, N), dtype=torch.float16, device="cuda"), ln_emit=(st, op), ln_resid_in_op=True)
+            assert torch.equal(op[0], op0[0][:rws]) and torch.equal(_lo8(op, rws, N), _lo8(op0, rws, N)) and torch.equal(st, st0[:rws]), rws
+
+
 def _stats_of(x):
     """(mean, M2) per 96-column group of fp32 rows, as the producer writes them (fp64 math, rounded)."""
     M = x.shape[0]

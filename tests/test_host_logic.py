@@ -572,3 +572,45 @@ def test_pnp_is_the_minimiser_of_the_pixel_reprojection_error():
     other = least_squares(normalised_residuals, np.concatenate([rv, t]), method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15)
     ok, Rs, ts = pnp.solve_pnp_iterative(box, p2, K)
     assert np.abs(ts - other.x[3:]).max() > 1e-5
+
+
+def test_dense_pose_rejects_a_bad_round_like_solvepnpransac():
+    """VERDICT r5 missing #3: the dense multi-round pose feeds the R x 8 corners of all decoder rounds to cv2.solvePnPRansac (2 px, 0.99,
+    1000 trials) and only falls back to ITERATIVE (/root/reference/src/models/utils/box_utils.py:266-285).  pnp.solve_pnp_ransac: with ONE
+    of R rounds replaced by random corners the pose must stay within the clean rounds' own spread (the plain least-squares solve is pulled
+    degrees away); on clean rounds every point is an inlier and the result IS the ITERATIVE solve of all points; sampling is deterministic."""
+    rng = np.random.default_rng(3)
+
+    def ang(A, B):
+        return np.degrees(np.arccos(np.clip((np.trace(A @ B.T) - 1) / 2, -1, 1)))
+    worst_ransac, worst_ls = 0.0, 0.0
+    for trial in range(6):
+        b3 = rng.uniform(-0.5, 0.5, (8, 3))
+        K = np.array([[270.0, 0, 112], [0, 265.0, 110], [0, 0, 1]])
+        Rt = pnp.rodrigues(rng.normal(size=3) * 0.7)
+        tt = np.array([0.05, -0.03, 1.4]) + rng.normal(size=3) * 0.05
+        pc = b3 @ Rt.T + tt
+        uv = pc[:, :2] / pc[:, 2:3] * [270.0, 265.0] + [112, 110]
+        R_rounds = 3 + trial % 3
+        p3 = np.tile(b3, (R_rounds, 1))
+        p2 = np.tile(uv, (R_rounds, 1)) + rng.normal(size=(R_rounds * 8, 2)) * 0.4
+        ok0, R0, t0 = pnp.solve_pnp_iterative(p3, p2, K)
+        ok3, R3, t3, m3 = pnp.solve_pnp_ransac(p3, p2, K, seed=trial)
+        assert ok0 and ok3 and m3.all() and np.array_equal(R3, R0) and np.array_equal(t3, t0)         # clean: every point an inlier
+        # the clean rounds' own spread: each round solved alone
+        spread = max(ang(pnp.solve_pnp_iterative(b3, p2[r * 8:(r + 1) * 8], K)[1], R0) for r in range(R_rounds))
+        bad = trial % R_rounds
+        p2b = p2.copy()
+        p2b[bad * 8:(bad + 1) * 8] = rng.uniform(30, 194, (8, 2))
+        ok1, R1, t1 = pnp.solve_pnp_iterative(p3, p2b, K)
+        ok2, R2, t2, m = pnp.solve_pnp_ransac(p3, p2b, K, seed=trial)
+        again = pnp.solve_pnp_ransac(p3, p2b, K, seed=trial)
+        assert ok2 and np.array_equal(again[1], R2) and np.array_equal(again[3], m)                   # deterministic
+        per_round = m.reshape(R_rounds, 8).sum(1)
+        assert per_round[bad] <= 1 and (np.delete(per_round, bad) >= 7).all(), per_round             # the bad round is rejected
+        assert ang(R2, R0) <= max(spread, 0.05) and np.linalg.norm(t2 - t0) <= 0.02, (trial, ang(R2, R0), spread)
+        worst_ransac, worst_ls = max(worst_ransac, ang(R2, R0)), max(worst_ls, ang(R1, R0))
+    assert worst_ls > 10 * worst_ransac               # what the un-guarded least squares of round 5 did with the same corners
+    # fewer than six distinct 3-D points: the ITERATIVE solve of everything (the reference's fallback)
+    ok, R, t, m = pnp.solve_pnp_ransac(b3[:5], uv[:5], K)
+    assert m.all()
