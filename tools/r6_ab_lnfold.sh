@@ -2,7 +2,7 @@
 # same-box A/B of the LayerNorm fold (default mode): BOXDREAMER_HIP_LNFOLD=0 keeps every bd_layernorm launch
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-COMMON="--prec f16c8_qk16 --no-fp8 --no-latency --no-cpu-baseline --no-inline-counters --no-h2d --no-pnp --no-rccl-probe --steps 20 --warmup 5"
+COMMON="--prec f16c8_qk16 --no-strict --sustained 0 --no-facade --no-trained-like --no-fp8 --no-latency --no-cpu-baseline --no-inline-counters --no-h2d --no-pnp --no-rccl-probe --steps 20 --warmup 5"
 for rep in 1 2; do
   for f in 0 1; do
     env ${AB_VAR:-BOXDREAMER_HIP_LNFOLD}=$f timeout 600 python bench.py $COMMON > gpurun_out/r6_ab_lnfold_${f}_${rep}.json 2> gpurun_out/r6_ab_lnfold_${f}_${rep}.err
