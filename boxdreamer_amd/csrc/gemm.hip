@@ -346,13 +346,17 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 }
             }
         };
-        f32x4 lnst[4] = {};                // LNF: the eight (mean, M2) pairs of this lane's row of the tile whose column vectors were issued last
-        auto load_row_stats = [&](int m0) {
-            int row = m0 + pw * 64 + lane;
-            row = row < M ? row : M - 1;
-            const f32x4* sp = (const f32x4*)(p.ln_stats_in + (int64_t)row * 16);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) lnst[q] = sp[q];
+        int lnt = 0;                       // LNF: tiles whose row statistics this wave has combined (parity = their LDS slot)
+        auto load_row_stats = [&](int m0) {      // (gemm_f16c8.hip has the why: combined at once, not kept in registers until the tile starts)
+            if (pw * 64 + lane < TBM) {
+                int row = m0 + pw * 64 + lane;
+                row = row < M ? row : M - 1;
+                const f32x4* sp = (const f32x4*)(p.ln_stats_in + (int64_t)row * 16);
+                const f32x4 lnst[4] = {sp[0], sp[1], sp[2], sp[3]};
+                *(float2*)(lds + AUX_ROWS + (lnt & 1) * 2048 + (pw * 64 + lane) * 8) = ln_rows_combine(lnst, p.ln_eps);
+            }
+            ++lnt;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
 #ifdef BD_GEMM_PROBE
         unsigned probe_ts = 0;
@@ -406,7 +410,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
                 if (cw.t < t_end) {
                     if (cw.kt == 0) {
                         issue_colp(cw.n0, tiles_w);
-                        if constexpr (LNF) load_row_stats(cw.m0);      // plain loads, older than W(first slab): the counted vmcnt covers them
+                        if constexpr (LNF) load_row_stats(cw.m0);      // one slab ahead of the consumers: the wait for these loads is off their path
                         ++tiles_w;
                     }
                     issue_w(gw, cw.n0, cw.kt); gw ^= 1; advance(cw);
@@ -414,17 +418,8 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, 1) void gemm_kernel_pc(const 
             };
             constexpr int YOUNG = NS * (PA / NPW);                 // pieces of one A image issued by this wave
             fetch_a(); fetch_w(); fetch_a();
-            int g = 0, tt = 0;
-            for (int t = t_begin + (bid >> 3); t < t_end; t += stride, ++tt) {
-                if constexpr (LNF) {
-                    // this tile's row statistics -> (rstd, -mean rstd) in the LDS side buffer (slot = tile parity; the consumers read the
-                    // other slot until barrier X above; the next tile's loads are issued by fetch_w at this tile's last slab)
-                    if (pw * 64 + lane < TBM) {
-                        const float2 rs = ln_rows_combine(lnst, p.ln_eps);
-                        *(float2*)(lds + AUX_ROWS + (tt & 1) * 2048 + (pw * 64 + lane) * 8) = rs;
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
+            int g = 0;
+            for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
                 for (int kt = 0; kt < nk; ++kt, ++g) {
                     if (ca.g > g + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG) : "memory");     // A(g+1) may still fly
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

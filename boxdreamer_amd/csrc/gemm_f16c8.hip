@@ -29,9 +29,9 @@ namespace {
 //     profiles/r5_f16c8_small_form.md.)
 //   * (round 6) the LayerNorm fold (include/boxdreamer_hip.h, bd_gemm_args.ln_*; epilogues in gemm_common.h).  EP 4: the fp32-residual
 //     epilogue also emits the rows' F16C8 operand copy and their per-wave-tile (mean, M2) pairs.  LNF: this launch's A operand is such
-//     a raw copy; one producer-wave lane per tile row loads the row's eight pairs with the tile's first slab (plain loads: they ride in
-//     FRONT of that slab's pieces, so the counted vmcnt covers them), combines them at the top of the tile and leaves (rstd, -mean rstd)
-//     in an LDS side buffer (double-buffered by tile parity) that the consumers' epilogue reads; the column sums travel like the bias.
+//     a raw copy; one producer-wave lane per tile row loads the row's eight pairs in front of the tile's first slab (two slabs ahead of the
+//     consumers), combines them at once and leaves (rstd, -mean rstd) in an LDS side buffer (double-buffered by tile parity) that the
+//     consumers' epilogue reads; the column sums travel like the bias.
 template <int NSTAGE, int EP, int OUTK, bool GELU, int WM = 4, int WN = 2, int NPW = 4, bool LNF = false>
 __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1) void gemm_kernel_pc_f16c8(const bd_gemm_args p) {
     constexpr int MI = 2, NI = 3, NCW = WM * WN;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
                 glds16_s(off, (const unsigned char*)p.rms_wk, lds_off + AUX_RMS + 1024);
             }
         }
-        f32x4 lnst[4] = {};                // LNF: the eight (mean, M2) pairs of this lane's row of the tile whose first slab was issued last
+        int lnt = 0;                       // LNF: tiles whose row statistics this wave has combined (parity = their LDS slot)
         auto issue_next = [&]() {
             if (it >= t_end) return;
             if constexpr (EP != 0) {
@@ -135,11 +135,21 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
                             const unsigned off = (unsigned)lane * 16 < (unsigned)(TBN * 4 - 16) ? (unsigned)lane * 16 : (unsigned)(TBN * 4 - 16);
                             glds16_s(off, (const unsigned char*)(p.ln_colsum + in0), lds_off + AUX_COLP + (itn & 1) * 2048 + 1024);
                         }
-                        int row = im0 + pw * 64 + lane;
-                        row = row < M ? row : M - 1;
-                        const f32x4* sp = (const f32x4*)(p.ln_stats_in + (int64_t)row * 16);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) lnst[q] = sp[q];
+                        // The tile's row statistics -> (rstd, -mean rstd) in the LDS side buffer, HERE, two slabs ahead of the consumers:
+                        // this wave waits for its four loads right away (and, vmcnt being in order, for the slab it issued last), which the
+                        // ring's slack absorbs.  Keeping the loaded registers until the tile starts instead made hipcc guard them with an
+                        // s_waitcnt vmcnt(2) in front of every re-load -- a drain of the whole DMA queue once per tile (~1600 cycles per tile,
+                        // 11 us on fc1: the probe is in profiles/r6_layernorm_fold.md).  Slot parity = tile parity: the consumers read the
+                        // other slot until this tile's first barrier.
+                        if (pw * 64 + lane < TBM) {
+                            int row = im0 + pw * 64 + lane;
+                            row = row < M ? row : M - 1;
+                            const f32x4* sp = (const f32x4*)(p.ln_stats_in + (int64_t)row * 16);
+                            const f32x4 lnst[4] = {sp[0], sp[1], sp[2], sp[3]};
+                            *(float2*)(lds + AUX_ROWS + (lnt & 1) * 2048 + (pw * 64 + lane) * 8) = ln_rows_combine(lnst, p.ln_eps);
+                        }
+                        ++lnt;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
                     ++itn;
                 }
@@ -164,17 +174,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
 #pragma unroll
         for (int i = 0; i < NSTAGE - 1; ++i) issue_next();
         int g = 0;
-        int tt = 0;
-        for (int t = t_begin + (bid >> 3); t < t_end; t += stride, ++tt) {
-            if constexpr (LNF) {
-                // this tile's row statistics (their loads were issued with the tile's first slab, at least one slab ago; the next tile's
-                // loads are issued later in this tile's K loop).  Slot tt & 1: the consumers read slot (tt - 1) & 1 until barrier X above.
-                if (pw * 64 + lane < TBM) {
-                    const float2 rs = ln_rows_combine(lnst, p.ln_eps);
-                    *(float2*)(lds + AUX_ROWS + (tt & 1) * 2048 + (pw * 64 + lane) * 8) = rs;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
+        for (int t = t_begin + (bid >> 3); t < t_end; t += stride) {
             for (int kt = 0; kt < nk; ++kt) {
                 BD_PROBE_IF(g < 20, g * 3 + 2)
                 wait_landed(ig - g - 1);                  // slab g has landed (later slabs may still fly)
