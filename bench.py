@@ -969,6 +969,9 @@ def apply_counters(rf: dict, c: dict) -> None:
                          "unit": "fraction of SIMD cycles with the MFMA pipe busy (counted, rocprofv3 PMC)"},
               mfma_busy_gemm=pk.get("gemm", {}).get("mfma_busy"), mfma_busy_whole_step=c["mfma_busy_whole_step"],
               counters_measured_in_this_run=True, counter_pass_seconds=c.get("pass_seconds"),
+              counters_run_configuration="a rocprofv3 child process of this run: the same step UN-GRAPHED as ONE lane (per-kernel counters need "
+                                         "one launch at a time); `value` / `achieved` are the graphed step with sub-batch lanes -- the counter "
+                                         "figures describe the kernels, not that schedule",
               gemm_ms_per_step_under_the_counters=pk.get("gemm", {}).get("ms_per_step"),
               delivered_clock_ghz_gemm=pk.get("gemm", {}).get("delivered_clock_ghz"))
 

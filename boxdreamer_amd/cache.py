@@ -50,6 +50,10 @@ def _plane_views(t16: torch.Tensor, pid: int, n_views: int, P: int, C: int):
     return [t16[0].reshape(n_views, P, C), t16[1].reshape(n_views, P, C)]
 
 
+def _init_last_stale():
+    merge_cached_features.last_stale = False
+
+
 def take_views(feats: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """feats (B, T, P, C) fp32 from the HIP encoder; idx (B, T') long, -1 = an all-zero view -> (B, T', P, C) with
     out[b, j] = feats[b, idx[b, j]], its operand-dtype copy re-packed the same way and attached (features.attach): what the dense-reference
@@ -109,11 +113,17 @@ class RefFeatureCache:
 
 
 def merge_cached_features(encoder, images: torch.Tensor, cached: torch.Tensor, valid: torch.Tensor) -> torch.Tensor:
-    """Encode only the views with valid == False and write them into (a copy of) the cached layout."""
+    """Encode only the views with valid == False and write them into (a copy of) the cached layout.  `merge_cached_features.last_stale`
+    says whether THIS call fell back to encoding every view (the facade records it per forward in data["hip_precision"]["cache_stale"]:
+    the warning fires once per process, the fallback every time)."""
     B, T = images.shape[:2]
     f16, pid = RefFeatureCache._feats16_view(cached)
     stamp, now = features.stamp_of(cached), encoder.model.state_stamp(encoder.prec)
-    if stamp is not None and stamp != now:
+    # (a missing stamp -- an older producer, or a tag lost through .to() / .clone() -- counts as stale whenever the encoder's state carries
+    # a promotion: such features cannot be told apart from ones computed under another state)
+    promoted_now = any(encoder.model.promote) or bool(encoder.model.promote_misc)
+    merge_cached_features.last_stale = bool((stamp is not None and stamp != now) or (stamp is None and promoted_now))
+    if merge_cached_features.last_stale:
         global _WARNED_STALE
         if not _WARNED_STALE:
             _WARNED_STALE = True
@@ -135,3 +145,6 @@ def merge_cached_features(encoder, images: torch.Tensor, cached: torch.Tensor, v
     for dst, src in zip(_plane_views(out16, pid, B * T, P, C), _plane_views(n16, pid, n_miss, P, C)):
         dst.reshape(B, T, P, C)[miss] = src
     return features.attach(out32, out16, pid, now)
+
+
+_init_last_stale()

@@ -82,10 +82,20 @@ def sync_state_across_ranks(encoder, decoder, src: int = 0) -> bool:
     mine = get_state(encoder, decoder)
     box = [mine if dist.get_rank() == src else None]
     dist.broadcast_object_list(box, src=src)
+    if isinstance(box[0], dict) and "error" in box[0]:
+        raise RuntimeError(f"rank {src} could not calibrate: {box[0]['error']}")
     if box[0] == mine:
         return False
     set_state(encoder, decoder, box[0])
     return True
+
+
+def broadcast_failure(reason: str, src: int = 0) -> None:
+    """What rank `src` sends INSTEAD of its state when its calibration raised: the other ranks, which all reach the same broadcast (model.py
+    calls it from ONE place in forward()), raise too instead of waiting for a state that never comes."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_rank() == src:
+        dist.broadcast_object_list([{"error": str(reason)}], src=src)
 
 
 def _state_of(units, promoted, n_enc, n_dec) -> dict:

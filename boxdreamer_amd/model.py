@@ -81,6 +81,8 @@ class BoxDreamer(nn.Module):
         # both weight sets): the first process measures and writes it, later ones load it instead of re-measuring
         self.hip_promotion_file = module_configs.get("hip_promotion_file", None)
         self._calibrated_for = None
+        self._ranks_synced_for = None
+        self._pending_save = False
         self.hip_precision_source = ("config" if "hip_precision" in dec_cfg else
                                      ("$BOXDREAMER_HIP_PREC" if "BOXDREAMER_HIP_PREC" in os.environ else "package default"))
         # `hip_graph: true` in config["modules"]: the plain path (no dense mode, no cached features) of an eval forward is captured as ONE
@@ -104,15 +106,45 @@ class BoxDreamer(nn.Module):
             self._calibrated_for = self.decoder._signature()
             return self.decoder.hip_calibration
         rep = calibrate.calibrate(self.rgb_encoder, self.decoder, images, data["bbox_feat"], mask, promote=self.hip_calibrate)
-        # one process per GPU: every rank measured its own first batch; rank 0's promotion set is the one all ranks run (same bits for
-        # the same sample on every rank)
-        if calibrate.sync_state_across_ranks(self.rgb_encoder, self.decoder):
-            rep = dict(rep, state=calibrate.get_state(self.rgb_encoder, self.decoder), synced_from_rank=0)
-            self.decoder.hip_calibration = rep
         self._calibrated_for = self.decoder._signature()
-        if self.hip_promotion_file and self.hip_calibrate and rep.get("applicable"):
+        # (no collective in here: an explicit model.calibrate(data) on ONE rank must not wait for the others.  forward() adopts rank 0's
+        # state in one place that every rank reaches, _sync_ranks_once, and rank 0 writes the promotion file there)
+        self._pending_save = bool(self.hip_promotion_file and self.hip_calibrate and rep.get("applicable"))
+        if self._pending_save and not self._multi_rank():
             calibrate.save_state(self.hip_promotion_file, self.rgb_encoder, self.decoder, rep)
+            self._pending_save = False
         return rep
+
+    @staticmethod
+    def _multi_rank() -> bool:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _sync_ranks_once(self, failure: str | None = None) -> None:
+        """One process per GPU: every rank measured (or loaded, or was handed) a promotion state on its own; rank 0's is the one all
+        ranks run (same bits for the same sample on every rank).  Called from ONE place in forward(), after the calibrate / mark_calibrated
+        branches, once per decoder signature: every rank reaches it whichever branch it took; a rank-0 failure is broadcast instead of a
+        state, so the others raise instead of hanging.  Only rank 0 writes the promotion file."""
+        import torch.distributed as dist
+        sig = self.decoder._signature()
+        if self._ranks_synced_for == sig or not self._multi_rank():
+            self._ranks_synced_for = sig
+            return
+        if failure is not None:
+            calibrate.broadcast_failure(failure)
+            return
+        if calibrate.sync_state_across_ranks(self.rgb_encoder, self.decoder):
+            rep = dict(self.decoder.hip_calibration or {}, state=calibrate.get_state(self.rgb_encoder, self.decoder), synced_from_rank=0)
+            # this rank's own measurement no longer describes the state it runs: say so instead of reporting its numbers
+            for k in ("promoted", "delta_final", "ok"):
+                rep[k] = None if k != "promoted" else []
+            rep["measured_here"] = False
+            self.decoder.hip_calibration = rep
+            self._calibrated_for = self.decoder._signature()
+        if getattr(self, "_pending_save", False) and dist.get_rank() == 0:
+            calibrate.save_state(self.hip_promotion_file, self.rgb_encoder, self.decoder, self.decoder.hip_calibration or {})
+        self._pending_save = False
+        self._ranks_synced_for = sig
 
     def mark_calibrated(self) -> None:
         """Keep the promotion state that is in place (applied through `calibrate.set_state` / `calibrate.load_state`): the first forward
@@ -145,7 +177,13 @@ class BoxDreamer(nn.Module):
                 if self._calibrated_for is None and calibrate.has_state(self.rgb_encoder, self.decoder):
                     self.mark_calibrated()       # a state the caller applied before the first forward is kept, not measured over
                 else:
-                    self.calibrate(data)
+                    try:
+                        self.calibrate(data)
+                    except Exception as e:       # noqa: BLE001 -- tell the other ranks before re-raising (they wait in _sync_ranks_once)
+                        self._sync_ranks_once(failure=f"{type(e).__name__}: {e}")
+                        raise
+            if images.is_cuda and not torch.cuda.is_current_stream_capturing():
+                self._sync_ranks_once()
             data["hip_precision"] = self._precision_record()
             # sub-batch lanes this batch runs as (bit-identical for every value; `hip_lanes` in the decoder / encoder cfg, default "auto")
             data["hip_precision"]["sub_batch_lanes"] = _lib.resolve_lanes(self.decoder.hip_lanes, B * T, B, self.decoder.hip_precision)
@@ -164,6 +202,8 @@ class BoxDreamer(nn.Module):
             if "cached_rgb_feat" in data:       # "next" row f1: references encoded once per object (boxdreamer_amd/cache.py)
                 rgb_feature = merge_cached_features(self.rgb_encoder, images, data["cached_rgb_feat"],
                                                     data["cached_rgb_mask"])
+                if "hip_precision" in data:       # the stale-cache fallback re-encodes every view on EVERY forward: say so every time
+                    data["hip_precision"]["cache_stale"] = bool(merge_cached_features.last_stale)
             else:
                 rgb_feature = self.rgb_encoder.predict(images)
             if dense:     # BoxDreamerModel.py:291-327

@@ -14,7 +14,10 @@
  *   - library-owned state, all of it: (1) per device, the side streams and fork / join events of the sub-batch lanes
  *     (bd_*_forward_lanes, created on first use or by bd_lanes_prepare, never destroyed; see "Sub-batch lanes" for what that
  *     means for concurrent callers), (2) the optional launch trace at the end of this file (off by default), (3) an immutable
- *     per-device cache of the compute-unit count;
+ *     per-device cache of the compute-unit count, (4) a THREAD-LOCAL hint "this thread's bd_gemm launches run side by side with
+ *     n - 1 others of the same shape" (1 outside the laned entry points, which set it for the duration of their enqueue and reset it
+ *     before they return): it only biases the choice between kernel FORMS of a launch (large / small tiles) towards the CUs' share
+ *     of one lane -- a row's bits never depend on the form, so the hint cannot change a result, only a duration;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) -- the laned entry points also
  *     on their side streams, forked from and joined back into `stream` inside the call;
  *   - return 0 on success, a negative BD_ERR_* for bad arguments, a positive hipError_t if a launch failed; no exceptions,

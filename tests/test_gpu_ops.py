@@ -771,3 +771,33 @@ def test_gpu_pnp_matches_host_form(hip, npts):
         assert got[i, 3, 3] == 1.0
     got = solve_poses_device(f32(exact), f32(p3), f32(K)).cpu().numpy()
     assert np.abs(got[:, :3, :3] - Rt).max() < 1e-4 and np.abs(got[:, :3, 3] - tt).max() < 1e-4
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "bf16x3"])
+@pytest.mark.parametrize("batch,seq,heads,hd", [(2, 261, 12, 64), (3, 70, 2, 64), (2, 13, 2, 64), (2, 70, 8, 96), (1, 300, 8, 96)])
+def test_attention_ragged_tail_never_reads_past_the_sample(hip, prec, batch, seq, heads, hd):
+    """the K / V tiles of a ragged last key tile are fetched through a buffer descriptor whose range ends with the sample; the
+    rows past `seq` must come back as ZERO (hardware bounds check), never as whatever lies behind the sample -- P = 0 times NaN / Inf is NaN.
+    The qkv planes are carved out of an arena whose guard rows behind every plane are NaN (and, between samples, the next sample's rows are
+    real data): outputs must be finite and equal, bit for bit, to the run on an arena whose guard rows are zero."""
+    from boxdreamer_amd import _lib
+    lib = _lib.load()
+    np_ = 2 if prec == "bf16x3" else 1
+    rows, cols, guard = batch * seq, 3 * heads * hd, 96
+    qkv = _rand("attq_guard", (rows, cols), 1.0)
+    t = hip_ops.to_operand(qkv.cuda(), prec)
+    planes = [t[0], t[1]] if np_ == 2 else [t]
+
+    def run(fill):
+        arena = torch.full((np_, rows + guard, cols), fill, dtype=planes[0].dtype, device="cuda")
+        for i, pl in enumerate(planes):
+            arena[i, :rows] = pl
+        out = torch.full((np_, rows + guard, heads * hd), 0.0, dtype=planes[0].dtype, device="cuda")
+        _lib.check(lib.bd_attention(arena.data_ptr(), (rows + guard) * cols if np_ == 2 else 0, out.data_ptr(),
+                                    (rows + guard) * heads * hd if np_ == 2 else 0, batch, seq, heads, hd, hd ** -0.5, _lib.prec_id(prec),
+                                    _lib.stream()), "bd_attention")
+        torch.cuda.synchronize()
+        return out[:, :rows].clone()
+    clean, poisoned = run(0.0), run(float("nan"))
+    assert torch.isfinite(poisoned.float()).all(), "a key / value row past the sample leaked into the result"
+    assert torch.equal(clean.view(torch.int16), poisoned.view(torch.int16))
