@@ -121,7 +121,7 @@ def merge_cached_features(encoder, images: torch.Tensor, cached: torch.Tensor, v
     stamp, now = features.stamp_of(cached), encoder.model.state_stamp(encoder.prec)
     # (a missing stamp -- an older producer, or a tag lost through .to() / .clone() -- counts as stale whenever the encoder's state carries
     # a promotion: such features cannot be told apart from ones computed under another state)
-    promoted_now = any(encoder.model.promote) or bool(encoder.model.promote_misc)
+    promoted_now = any(getattr(encoder.model, "promote", ())) or bool(getattr(encoder.model, "promote_misc", 0))
     merge_cached_features.last_stale = bool((stamp is not None and stamp != now) or (stamp is None and promoted_now))
     if merge_cached_features.last_stale:
         global _WARNED_STALE
