@@ -76,7 +76,8 @@ class GemmArgs(C.Structure):
                 ("rpg_in", C.c_int), ("rpg_out", C.c_int), ("row_off", C.c_int), ("w_qexp", C.c_int),
                 ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("rms_parts", C.c_int),
                 ("ln_stats_out", C.c_void_p), ("ln_op_out", C.c_void_p), ("ln_op_plane", C.c_int64), ("ln_op_ld", C.c_int64),
-                ("ln_stats_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_resid_in_op", C.c_int)]
+                ("ln_stats_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_resid_in_op", C.c_int),
+                ("sk_ws", C.c_void_p), ("sk_split", C.c_int)]
 
 
 class Linear(C.Structure):
@@ -120,7 +121,8 @@ EXPORTS = [
     "bd_gather_query_tokens", "bd_unpatchify_sigmoid", "bd_decode_topk",
     "bd_encoder_workspace_bytes", "bd_encoder_forward", "bd_decoder_workspace_bytes", "bd_decoder_forward",
     "bd_trace_begin", "bd_trace_end", "bd_render_corner_heatmaps", "bd_attention_q", "bd_gather_query_rows_f32",
-    "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm", "bd_gemm_takes_ln_fold", "bd_solve_pnp_host", "bd_attention_prefix",
+    "bd_dino_match_scores", "bd_topk_mask", "bd_solve_pnp", "bd_gemm_fuses_qk_rmsnorm", "bd_gemm_takes_ln_fold", "bd_gemm_splitk_flag_bytes",
+    "bd_gemm_splitk_workspace_bytes", "bd_solve_pnp_host", "bd_attention_prefix",
     "bd_lanes_prepare", "bd_encoder_workspace_bytes_lanes", "bd_encoder_forward_lanes", "bd_decoder_workspace_bytes_lanes",
     "bd_decoder_forward_lanes",
 ]
@@ -150,6 +152,10 @@ def load() -> C.CDLL:
     lib.bd_gemm.argtypes = [C.POINTER(GemmArgs), i, vp]
     lib.bd_gemm_fuses_qk_rmsnorm.argtypes = [C.POINTER(GemmArgs), i]
     lib.bd_gemm_takes_ln_fold.argtypes = [C.POINTER(GemmArgs), i]
+    lib.bd_gemm_splitk_flag_bytes.argtypes = [i, i]
+    lib.bd_gemm_splitk_flag_bytes.restype = sz
+    lib.bd_gemm_splitk_workspace_bytes.argtypes = [i, i]
+    lib.bd_gemm_splitk_workspace_bytes.restype = sz
     lib.bd_layernorm.argtypes = [vp, i64, vp, vp, f, vp, i64, vp, i64, i, i, i, i, i, i, vp]
     lib.bd_qk_rmsnorm.argtypes = [vp, i64, vp, vp, f, i, i, i, i, vp]
     lib.bd_attention.argtypes = [vp, i64, vp, i64, i, i, i, i, f, i, vp]
@@ -183,7 +189,7 @@ def load() -> C.CDLL:
     lib.bd_solve_pnp_host.argtypes = [vp, vp, vp, i, i, i, vp, i]
     lib.bd_trace_begin.argtypes = [i]
     lib.bd_trace_end.argtypes = [C.POINTER(TraceRecord), i]
-    if lib.bd_abi_version() != 8:
+    if lib.bd_abi_version() != 9:
         raise HipLibraryError("libboxdreamer_hip.so ABI version mismatch")
     _lib = lib
     return lib

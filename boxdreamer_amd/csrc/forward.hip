@@ -29,6 +29,8 @@ struct BlockBufs {
     void* ao;        // 16-bit attention out [M, D]
     void* h;         // 16-bit MLP hidden    [M, 4D]
     float* st;       // LayerNorm fold: (mean, M2) per row and 96-column group [M, D / 96, 2] fp32 (F16C8 family)
+    void* sk;        // split-K scratch of the residual Linears (bd_gemm_args.sk_ws; small M only, else NULL); flags zeroed per forward
+    size_t sk_flag_bytes;
 };
 
 inline bd_gemm_args gemm_args(const void* A, int64_t lda, int64_t a_plane, const bd_linear& lin, int64_t ldw, int N,
@@ -186,14 +188,19 @@ inline bool ln1_foldable(const bd_block_weights& w, const BlockPlan& p, const Bl
 // x_stale (in / out): b.x does not hold the stream (the previous residual Linear wrote the copy only).
 struct ResidPlan { bool fold2, proj_c8, proj_f32, fc2_c8, fc2_f32; };
 
+// split-K scratch: lent to a residual Linear on at most as many rows as the region was carved for (the stream's M; the last decoder
+// block's compact rows are fewer)
+inline void lend_sk(bd_gemm_args& g, const BlockBufs& b) { if (b.sk && g.M <= BD_SPLITK_MAX_ROWS) g.sk_ws = b.sk; }
 inline bd_gemm_args proj_args(const bd_block_weights& w, const BlockBufs& b, float* x, int Mr, int D) {
     bd_gemm_args g = gemm_args(b.ao, D, (int64_t)Mr * D, w.proj, D, D, x, D, 0, 1, Mr, D, BD_ACT_NONE);
     g.resid = x; g.ldr = D;
+    lend_sk(g, b);
     return g;
 }
 inline bd_gemm_args fc2_args(const bd_block_weights& w, const BlockBufs& b, float* x, int Mr, int D) {
     bd_gemm_args g = gemm_args(b.h, 4 * D, (int64_t)Mr * 4 * D, w.fc2, 4 * D, D, x, D, 0, 1, Mr, 4 * D, BD_ACT_NONE);
     g.resid = x; g.ldr = D;
+    lend_sk(g, b);
     return g;
 }
 // the same launch reading its residual from the operand copy (and writing fp32 rows only if asked)
@@ -324,6 +331,10 @@ BlockBufs carve_block(Carver& c, int64_t M, int D, int np) {
     b.ao = c.take((size_t)M * D * 2 * np);
     b.h = c.take((size_t)M * 4 * D * 2 * np);
     b.st = (float*)c.take((size_t)M * ((D + 95) / 96) * 2 * 4);
+    // split-K scratch for the stream's residual Linears when the whole stream is a few tiles (one or two poses at a time)
+    const size_t skb = (np == 2 && M <= BD_SPLITK_MAX_ROWS) ? bd_gemm_splitk_workspace_bytes((int)M, D) : 0;
+    b.sk = skb ? c.take(skb) : nullptr;
+    b.sk_flag_bytes = skb ? bd_gemm_splitk_flag_bytes((int)M, D) : 0;
     return b;
 }
 
@@ -388,6 +399,7 @@ extern "C" int bd_encoder_forward(const bd_dino_weights* w, const void* images, 
     if (workspace_bytes < e.bytes) return BD_ERR_WORKSPACE;
     const int P = w->grid * w->grid, D = w->dim, tpi = P + w->n_prefix;
     const int Mp = n_images * P, Md = n_images * tpi;
+    if (e.blk.sk && hipMemsetAsync(e.blk.sk, 0, e.blk.sk_flag_bytes, (hipStream_t)stream) != hipSuccess) return BD_ERR_WORKSPACE;
 
     // K1+K2: normalise + im2col, then the patch-embed GEMM scattering rows b*P+p -> b*tpi+n_prefix+p and
     // adding the (pre-resampled) positional table  (vision_transformer.py:213-232, patch_embed.py:65-75)
@@ -437,6 +449,7 @@ extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_fea
     const int P = w->grid * w->grid, D = w->dim, F = w->patch * w->patch * w->box_dim;
     const int Mb = B * T * P, Mq = B * P;
     const int64_t pD = (int64_t)Mb * D;
+    if (d.blk.sk && hipMemsetAsync(d.blk.sk, 0, d.blk.sk_flag_bytes, (hipStream_t)stream) != hipSuccess) return BD_ERR_WORKSPACE;
 
     // operand classes of the Linears outside the blocks (F16C8 family: per-Linear promotion, include/boxdreamer_hip.h)
     const int pm0 = (prec == BD_PREC_F16C8 || prec == BD_PREC_FP8) ? w->promote_misc : 0;

@@ -32,7 +32,13 @@ namespace {
 //     a raw copy; one producer-wave lane per tile row loads the row's eight pairs in front of the tile's first slab (two slabs ahead of the
 //     consumers), combines them at once and leaves (rstd, -mean rstd) in an LDS side buffer (double-buffered by tile parity) that the
 //     consumers' epilogue reads; the column sums travel like the bias.
-template <int NSTAGE, int EP, int OUTK, bool GELU, int WM = 4, int WN = 2, int NPW = 4, bool LNF = false>
+//   * (round 6) split-K for launches of a few tiles (one pose at a time: fc2 / proj on 1536 rows are 96 tiles of 128 x 96 on 256 CUs), SK:
+//     every tile is computed by S = p.sk_split workgroups (one tile per workgroup, all S on one XCD), workgroup ks taking the slabs
+//     [ks nk / S, (ks + 1) nk / S).  The first S - 1 ("secondaries") start from zero and leave their raw accumulators in p.sk_ws, release a
+//     per-(tile, ks, wave) flag and exit; the LAST one (highest blockIdx of the tile: dispatched after its secondaries, so its wait cannot
+//     starve them) starts from the residual as usual, waits for each flag in turn, adds the partials in the fixed order ks = 0 .. S - 2
+//     and runs the epilogue.  Deterministic (fixed association), NOT bit-identical to the unsplit forms: include/boxdreamer_hip.h, sk_ws.
+template <int NSTAGE, int EP, int OUTK, bool GELU, int WM = 4, int WN = 2, int NPW = 4, bool LNF = false, bool SK = false>
 __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1) void gemm_kernel_pc_f16c8(const bd_gemm_args p) {
     constexpr int MI = 2, NI = 3, NCW = WM * WN;
     constexpr int TBM = WM * MI * 32, TBN = WN * NI * 32, BK = 32;
@@ -50,15 +56,22 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
     // side buffer behind the ring + scratch (gemm_kernel_pc): per-column vectors of the current / next tile, q / k RMSNorm weights
     constexpr int AUX_COLP = 2 * STAGE + S2, AUX_RMS = AUX_COLP + 4096, AUX_ROWS = AUX_RMS + 2048, AUX_BYTES = EP == 0 ? 0 : (LNF ? 10240 : 6144);
     static_assert(!LNF || (EP != 0 && NPW * 64 >= TBM && NSTAGE == 3), "LayerNorm fold: one producer lane per tile row");
+    static_assert(!SK || ((EP == 3 || EP == 4 || EP == 5) && !LNF && NSTAGE == 3), "split-K: the fp32-residual epilogues, one tile per workgroup");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE + S2 + AUX_BYTES];   // stages at 0, STAGE, 2*STAGE; scratch at 2*STAGE
 
     bd_saturating_conversions();      // q8 images (K loop) and F16C8 / f16 results (epilogue) saturate instead of turning NaN / inf
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = p.M, N = p.N;
-    const int nk = p.K / BK;
+    // split-K: S workgroups per tile, consecutive on one XCD (real id = xcd + 8 (S q + ks) for the virtual workgroup xcd + 8 q)
+    const int S = SK ? p.sk_split : 1;
+    const int ks = SK ? ((int)blockIdx.x >> 3) % S : 0;
+    const int nk_all = p.K / BK;
+    const int k_lo = SK ? ks * nk_all / S : 0;
+    const int nk = SK ? (ks + 1) * nk_all / S - k_lo : nk_all;
     const int tilesM = (M + TBM - 1) / TBM, tilesN = (N + TBN - 1) / TBN, nt = tilesM * tilesN;
-    const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7;
+    const int nwg = SK ? (int)gridDim.x / S : (int)gridDim.x;
+    const int bid = SK ? ((int)blockIdx.x & 7) + 8 * (((int)blockIdx.x >> 3) / S) : (int)blockIdx.x, xcd = bid & 7;
     const int tq = nt >> 3, tr = nt & 7;
     const int t_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
     const int t_end = t_begin + tq + (xcd < tr ? 1 : 0);
@@ -96,10 +109,10 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
             const unsigned la0 = (unsigned)(rows_a - 1) * lda0 + 48, lw0 = (unsigned)(rows_w - 1) * ldw0 + 48;
             const unsigned la1 = (unsigned)(rows_a - 1) * lda1 + 16, lw1 = (unsigned)(rows_w - 1) * ldw1 + 48;
             const unsigned st = lds_off + stage * STAGE + pw * 1024;
-            const unsigned char* ba0 = pA0 + (int64_t)m0 * lda0 + (int64_t)kt * 64;
-            const unsigned char* bw0 = pW0 + (int64_t)n0 * ldw0 + (int64_t)kt * 64;
-            const unsigned char* ba1 = pA1 + (int64_t)m0 * lda1 + (int64_t)kt * 32;
-            const unsigned char* bw1 = pW1 + (int64_t)n0 * ldw1 + (int64_t)kt * 64;
+            const unsigned char* ba0 = pA0 + (int64_t)m0 * lda0 + (int64_t)(k_lo + kt) * 64;
+            const unsigned char* bw0 = pW0 + (int64_t)n0 * ldw0 + (int64_t)(k_lo + kt) * 64;
+            const unsigned char* ba1 = pA1 + (int64_t)m0 * lda1 + (int64_t)(k_lo + kt) * 32;
+            const unsigned char* bw1 = pW1 + (int64_t)n0 * ldw1 + (int64_t)(k_lo + kt) * 64;
 #pragma unroll
             for (int i = 0; i < IA0; ++i) glds16_s(oA0[i] < la0 ? oA0[i] : la0, ba0, st + i * (NPW * 1024));
 #pragma unroll
@@ -204,10 +217,20 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
     BD_PROBE(58) BD_PROBE_RT(56)
     int ti = 0;
     f32x16 acc[MI][NI];
+    const bool secondary = SK && ks != S - 1;
     if constexpr (EP != 0) {      // first tile; later tiles are initialised inside the previous tile's epilogue
         int m0, n0;
         tile_origin(t_begin + (bid >> 3), m0, n0);
-        acc_init<MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+        if (secondary) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        } else {
+            acc_init<MI, NI>(p, acc, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
+        }
     }
     for (int t = t_begin + (bid >> 3); t < t_end; t += stride, ++ti) {
         int m0, n0;
@@ -298,6 +321,58 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
         BD_PROBE_IF(g == nk, 60)
         pc_barrier();                                     // X
         BD_PROBE_IF(g == nk, 61)
+        if constexpr (SK) {
+            // flags [tile][3][NCW] ints in the first BD_SPLITK_FLAG_BYTES of sk_ws (zero between launches), then the partials
+            // [tile][3][NCW][MI NI 4][64 lanes] x 16 B
+            int* const flags = (int*)p.sk_ws;
+            f32x4* const parts = (f32x4*)((unsigned char*)p.sk_ws + BD_SPLITK_FLAG_BYTES);
+            // Coherence without cache-wide fences: partials and flags move with agent-scope (sc1) loads / stores, which are coherent at the
+            // device's coherence point on their own; the secondary waits for its stores' acknowledgements (vmcnt) before it raises the flag,
+            // the last workgroup issues its partial loads only after it has seen the flag.  (A release / acquire fence pair here is
+            // buffer_wbl2 sc1 + buffer_inv sc1: the invalidate drops the XCD's L2 lines under every workgroup still in its K loop --
+            // measured: fc2 at 1536 rows 44 us with S = 2 and SLOWER with S = 3, profiles/r6_split_k.md.)
+            if (secondary) {
+                const int idx = (t * 3 + ks) * NCW + wid;
+                f32x4* dst = parts + (size_t)idx * (MI * NI * 4 * 64) + lane;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + ((i * NI + j) * 4 + q) * 64), "v"(v) : "memory");
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(flags + idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            for (int sk = 0; sk < S - 1; ++sk) {
+                const int idx = (t * 3 + sk) * NCW + wid;
+                while (__hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_store(flags + idx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const f32x4* src = parts + (size_t)idx * (MI * NI * 4 * 64) + lane;
+                // the wave tile's 24 x 16 bytes per lane in ONE round trip: the loads go to the coherence point (sc1), ~2 us each way
+                // (one wait per four loads -- six dependent round trips -- cost ~9 us per secondary)
+                f32x4 v[MI * NI * 4];
+#pragma unroll
+                for (int u = 0; u < MI * NI * 4; ++u)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u]) : "v"(src + u * 64) : "memory");
+                static_assert(MI * NI == 6, "24 register quads named below");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                             "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]),
+                             "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]), "+v"(v[20]), "+v"(v[21]), "+v"(v[22]), "+v"(v[23]) : : "memory");
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[(i * NI + j) * 4 + q][e];
+            }
+        }
         unsigned char* scratch = lds + 2 * STAGE + wid * (SR * NI * 32 * 4);
         if constexpr (EP == 0) {
             gemm_epilogue_lds<f16c8, 2, MI, NI, SR, true>(p, acc, scratch, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lane);
@@ -364,6 +439,38 @@ bool bd_f16c8_takes_ln_fold(const bd_gemm_args& a) {
     return true;
 }
 
+// Split-K factor of a launch (1 = none).  Only with a scratch region from the caller, only the fp32-residual epilogue kinds on the 128 x 96
+// form (one tile per workgroup), only where S workgroups per tile still fit the chip's 2 x CUs slots of that form at once.  args.sk_split
+// forces a factor (tests, tuning); otherwise the largest of 2 .. 4 that fits, with at least 6 slabs per workgroup.
+static int f16c8_split_k(const bd_gemm_args& a, int ep, bool r5, bool lnp, bool s3, int cus) {
+    (void)lnp;                             // (a producer launch that is not r5 has ep == 3: bd_f16c8_takes_ln_fold)
+    if (!a.sk_ws || ((uintptr_t)a.sk_ws & 255) || !s3 || a.N % 96 != 0 || !bd_gemm_splitk_flag_bytes(a.M, a.N) || !(ep == 3 || r5)) return 1;
+    const int t96 = ((a.M + 127) / 128) * (a.N / 96), nk = a.K / 32;
+    // one workgroup per CU: two of this form on a CU put both their consumer-wave pairs on the same two SIMDs (measured: fc2 at 1536 rows
+    // 34 us with S = 2 = 192 workgroups, 43 us with S = 3 = 288; profiles/r6_split_k.md)
+    const int slots = cus / (bd_concurrent_launches() > 0 ? bd_concurrent_launches() : 1);
+    int sk = a.sk_split;
+    if (sk <= 0) {
+        sk = 1;
+        for (int c = 4; c >= 2; --c)
+            if (t96 * c <= slots && nk / c >= 6) { sk = c; break; }
+    }
+    if (sk < 2 || sk > 4 || nk / sk < 1) return 1;
+    return sk;
+}
+
+extern "C" size_t bd_gemm_splitk_flag_bytes(int M, int N) {
+    if (M <= 0 || N <= 0 || N % 96 != 0 || M > BD_SPLITK_MAX_ROWS) return 0;
+    const size_t t96 = (size_t)((M + 127) / 128) * (size_t)(N / 96);
+    return t96 * 3 * 2 * 4 <= BD_SPLITK_FLAG_BYTES ? BD_SPLITK_FLAG_BYTES : 0;      // [tile][3 secondaries][2 consumer waves] ints
+}
+extern "C" size_t bd_gemm_splitk_workspace_bytes(int M, int N) {
+    const size_t fb = bd_gemm_splitk_flag_bytes(M, N);
+    if (!fb) return 0;
+    const size_t t96 = (size_t)((M + 127) / 128) * (size_t)(N / 96);
+    return fb + t96 * 3 * 2 * (size_t)(64 * 96 * 4);               // + [tile][3][2][64 x 96 fp32 accumulators of a wave tile]
+}
+
 // F16C8 has its own persistent kernel; every shape goes through it
 int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     if (!wide_epilogue_ok(a, 2) || 256 * a.lda * 2 >= ((int64_t)1 << 31) || 256 * a.ldw * 2 >= ((int64_t)1 << 31)) return BD_ERR_ALIGN;
@@ -403,6 +510,23 @@ int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     // profiles/r5_f16c8_small_form.md).  One instance (+ its LayerNorm-fold producer twin).
     const bool r5 = lnp && a.ln_resid_in_op;              // the residual comes from (and goes back to) the operand copy: EP 5
     const bool fc2_96 = (ep == 3 || r5) && small && a.K >= 2048 && a.N % 96 == 0 && 4 * tiles * bd_concurrent_launches() <= cus;
+    // Split-K (the caller lent a scratch region: bd_gemm_args.sk_ws): the fp32-residual Linears of a launch whose 128 x 96 tiles would still
+    // leave most of the chip idle -- one pose at a time, fc2 / proj on 1536 rows: 96 tiles on 256 CUs (two workgroups of this form fit a CU);
+    // the last decoder block's query rows: 16 tiles.  S workgroups per tile, see the kernel's header.
+    const int sk = f16c8_split_k(a, ep, r5, lnp, s3, cus);
+    if (sk > 1) {
+        bd_gemm_args b2 = a;
+        b2.sk_split = sk;
+        const int t96 = ((a.M + 127) / 128) * (a.N / 96);
+        const dim3 gs(((t96 + 7) / 8) * 8 * sk), bs(256);
+        if (r5 && a.out_f32 == OUT_F32) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 5, OUT_F32, false, 2, 1, 2, false, true>), gs, bs, 0, s, b2);
+        else if (r5) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 5, OUT_OPERAND, false, 2, 1, 2, false, true>), gs, bs, 0, s, b2);
+        else if (lnp) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 4, OUT_F32, false, 2, 1, 2, false, true>), gs, bs, 0, s, b2);
+        else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 3, OUT_F32, false, 2, 1, 2, false, true>), gs, bs, 0, s, b2);
+        bd_trace_close(s, slot);
+        BD_CHECK_LAUNCH();
+        return BD_OK;
+    }
     if (r5 && fc2_96 && a.out_f32 == OUT_F32)
         hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 5, OUT_F32, false, 2, 1, 2>), dim3(((a.M + 127) / 128) * (a.N / 96)), dim3(256), 0, s, a);
     else if (r5 && fc2_96)

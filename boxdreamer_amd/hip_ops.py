@@ -110,12 +110,14 @@ _OUT_SPLIT = {4: torch.bfloat16, 5: torch.float16}
 
 def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, addtab=None, out=None,
          out_f32=False, n=None, out_rows=None, rpg=(0, 0, 0), wscale=None, out_mode=None, w_qexp=0, rms=None,
-         ln_emit=None, ln_apply=None, ln_resid_in_op=False):
+         ln_emit=None, ln_apply=None, ln_resid_in_op=False, split_k=None):
     """out[map(r)] = act(wscale * (A W^T) + bias) + addtab[r % rows(addtab)] + resid[map(r)].
     out_mode: None -> operand dtype (or fp32 with out_f32), 2 -> f16 single plane, 3 -> bf16 single plane, 4 -> split-bf16 (hi, lo)
     planes, 5 -> split-f16 (hi, lo) planes (bd_gemm_args.out_f32, include/boxdreamer_hip.h).
     LayerNorm fold (ABI 8): ln_emit = (stats [M, N / 96, 2] fp32, operand copy [2, M, N] F16C8 storage) -- the producer side;
-    ln_apply = (stats [M, 8, 2], column sums [N], eps) -- the consumer side."""
+    ln_apply = (stats [M, 8, 2], column sums [N], eps) -- the consumer side.
+    split_k = (scratch uint8 tensor of splitk_workspace_bytes(M, N) whose first 16 KiB are zero, factor 0 = library's choice | 2 .. 4):
+    bd_gemm_args.sk_ws / sk_split (ABI 9)."""
     lib = _lib.load()
     np_ = planes(prec)
     A2 = a16[0] if np_ == 2 else a16
@@ -155,10 +157,18 @@ def gemm(a16, w16, bias=None, *, prec="bf16", act=_lib.ACT_NONE, resid=None, add
         g.ln_resid_in_op = int(bool(ln_resid_in_op))      # the residual rows are read from (and the sum written back to) `op`; fp32 rows only with out_f32
     if ln_apply is not None:
         g.ln_stats_in, g.ln_colsum, g.ln_eps = ptr(ln_apply[0]), ptr(ln_apply[1]), float(ln_apply[2])
+    if split_k is not None:
+        g.sk_ws, g.sk_split = ptr(split_k[0]), int(split_k[1])
     if (ln_emit is not None or ln_apply is not None) and not lib.bd_gemm_takes_ln_fold(C.byref(g), prec_id(prec)):
         raise ValueError("bd_gemm_takes_ln_fold: this launch has no kernel form with the LayerNorm-fold epilogues")
     check(lib.bd_gemm(C.byref(g), prec_id(prec), stream()), "bd_gemm")
     return out
+
+
+def splitk_workspace(M, N, device="cuda"):
+    """Zeroed scratch region for gemm(..., split_k=(ws, factor)); None when (M, N) has no split-K form."""
+    nbytes = _lib.load().bd_gemm_splitk_workspace_bytes(int(M), int(N))
+    return torch.zeros(nbytes, dtype=torch.uint8, device=device) if nbytes else None
 
 
 def layernorm(x, gamma, beta, eps, *, prec="bf16", want16=True, want32=False, rows=None, rpg=(0, 0, 0)):

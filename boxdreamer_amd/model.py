@@ -193,7 +193,7 @@ class BoxDreamer(nn.Module):
         dense = self.dense_cfg is not None and _get(self.dense_cfg, "enable", False)
         if (self.hip_graph and not dense and "cached_rgb_feat" not in data and not self.training and images.is_cuda
                 and isinstance(self.decoder, BETR) and not torch.cuda.is_current_stream_capturing()):
-            heat, kp_px, kn, _ = self._graphed(images, pose_feat, qi, sig if self._calibrated_for == sig else None)
+            heat, kp_px, kn, _ = self._graphed(images, pose_feat, qi, sig)
             # (the replay's outputs are static buffers the next replay overwrites: what the caller keeps is copied out of them below --
             # pred_bbox's query slot is written straight from the static heat map, the corners get their own tensors)
             query_ret, decoded = heat, (kn.clone(), kp_px.clone())

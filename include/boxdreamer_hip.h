@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define BD_ABI_VERSION 8
+#define BD_ABI_VERSION 9
 
 #define BD_DTYPE_BF16 0
 #define BD_DTYPE_F16 1
@@ -180,7 +180,20 @@ typedef struct bd_gemm_args {
      * Linear).  Per residual Linear 3 + 3 bytes per element cross HBM instead of 4 + 7; the stream is rounded to the operand class (~2^-15
      * relative) once per residual add (tools/lnfold_sim.py RESID3=1: logits 2.2e-4 -> 2.6e-4 at full depth). */
     int ln_resid_in_op;
+    /* Split-K for launches of a few tiles (ABI 9; BD_PREC_F16C8, the fp32-residual Linears proj / fc2 -- with or without the ln_* producer
+     * fields -- at M <= BD_SPLITK_MAX_ROWS: one pose at a time, the reference demo's per-frame call src/demo/demo.py:1501-1514).
+     * sk_ws != NULL lends the launch a scratch region of bd_gemm_splitk_workspace_bytes(M, N) bytes, 256-byte aligned, whose first
+     * BD_SPLITK_FLAG_BYTES bytes are ZERO when the launch starts (every launch leaves them zero again, so launches on fewer rows may reuse
+     * a region sized for more; the region must not be shared by launches that may run concurrently).  The library then MAY compute every 128 x 96 output tile with S = 2 .. 4 workgroups over
+     * disjoint K ranges, summed in a fixed order: deterministic, but NOT bit-identical to the unsplit result (fp32 association differs,
+     * ~1e-7 relative) -- the row-result-independent-of-the-launch-form property of the other forms does not hold across this switch,
+     * which is why it is opt-in per launch.  sk_split: 0 = the library chooses (1 = no split where it does not pay), 2 .. 4 = forced. */
+    void* sk_ws; int sk_split;
 } bd_gemm_args;
+#define BD_SPLITK_MAX_ROWS 4096
+#define BD_SPLITK_FLAG_BYTES 16384
+size_t bd_gemm_splitk_flag_bytes(int M, int N);            /* BD_SPLITK_FLAG_BYTES, or 0 when M, N have no split-K form */
+size_t bd_gemm_splitk_workspace_bytes(int M, int N);      /* 0 when M, N have no split-K form (N % 96 != 0, M > BD_SPLITK_MAX_ROWS) */
 int bd_gemm(const bd_gemm_args* args /*[host]*/, int prec, void* stream);
 /* 1 if bd_gemm(args, prec) serves the ln_* fields that are set in args (producer and / or consumer side of the LayerNorm fold), else 0. */
 int bd_gemm_takes_ln_fold(const bd_gemm_args* args /*[host]*/, int prec);

@@ -268,3 +268,75 @@ def test_predicate_refuses_what_no_kernel_form_serves(hip):
         w = torch.zeros((2, 768, 768), dtype=torch.float16, device="cuda")
         a = torch.zeros((2, 512, 768), dtype=torch.float16, device="cuda")
         hip_ops.gemm(a, w, x[:768], prec="f16x3", ln_apply=(x, x[:768], 1e-6))
+
+
+# ---- split-K of the residual Linears for launches of a few tiles (ABI 9, bd_gemm_args.sk_ws / sk_split): one pose at a time
+
+def _splitk_case(M, K, kind, split, seed=11):
+    """kind: "resid" (fp32 residual, EP 3), "emit" (+ LayerNorm-fold producer, EP 4), "c8" / "c8f32" (residual in the operand copy, EP 5)."""
+    N = 768
+    a, w, b = _rand("a", (M, K), seed=seed).cuda(), _rand("w", (N, K), 0.04, seed).cuda(), _rand("b", (N,), 0.3, seed).cuda()
+    x0 = (_rand("r", (M, N), 2.0, seed) + 0.7).cuda()
+    e = hip_ops.f16c8_qexp(w)
+    a16, w16 = hip_ops.f16c8_encode(a, 0, False), hip_ops.f16c8_encode(w, e, True)
+    kw = dict(prec="f16c8", w_qexp=e)
+    st = op = None
+    if kind in ("resid", "emit"):
+        kw.update(out_f32=True, resid=x0.clone())
+    if kind != "resid":
+        st = torch.full((M, 8, 2), float("nan"), dtype=torch.float32, device="cuda")
+        op = hip_ops.f16c8_encode(x0, 0, False) if kind.startswith("c8") else torch.zeros((2, M, N), dtype=torch.float16, device="cuda")
+        kw["ln_emit"] = (st, op)
+    if kind.startswith("c8"):
+        kw.update(ln_resid_in_op=True, out_f32=kind == "c8f32")
+        if kind == "c8":
+            kw["out"] = torch.zeros((2, M, N), dtype=torch.float16, device="cuda")
+    ws = None
+    if split is not None:
+        ws = hip_ops.splitk_workspace(M, N)
+        kw["split_k"] = (ws, split)
+    out = hip_ops.gemm(a16, w16, b, **kw)
+    torch.cuda.synchronize()
+    return out, st, op, ws
+
+
+@pytest.mark.parametrize("M,K", [(1536, 3072), (1536, 768), (256, 3072), (256, 768), (300, 768), (1566, 3072), (3072, 768)])
+@pytest.mark.parametrize("kind", ["resid", "emit", "c8", "c8f32"])
+def test_split_k_matches_the_unsplit_launch(hip, M, K, kind):
+    """S workgroups per 128 x 96 tile over disjoint K ranges, summed in a fixed order: equal to the unsplit launch up to fp32 association
+    (not bit-identical by contract), deterministic, and the flag region is left zero."""
+    base, st0, op0, _ = _splitk_case(M, K, kind, None)
+    for split in (2, 3, 4):
+        out, st, op, ws = _splitk_case(M, K, kind, split)
+        assert int(ws[:16384].view(torch.int32).abs().max()) == 0, "flags must be left zero"
+        if kind != "c8":
+            scale = float(base.abs().max())
+            assert (out - base).abs().max().item() <= 4e-6 * scale, (split, (out - base).abs().max().item())
+            assert not torch.equal(out, torch.zeros_like(out))
+        if kind != "resid":
+            x0 = hip_ops.from_operand(op0, "f16c8").double()
+            x1 = hip_ops.from_operand(op, "f16c8").double()
+            assert (x1 - x0).abs().max().item() <= 2.0 ** -14 * float(x0.abs().max()), split       # one operand-class rounding step at most
+            assert (st[..., 0] - st0[..., 0]).abs().max().item() <= 1e-4 and ((st[..., 1] - st0[..., 1]).abs() / st0[..., 1].clamp_min(1e-3)).max().item() <= 1e-3
+        again, st2, op2, _ = _splitk_case(M, K, kind, split)
+        if kind != "c8":
+            assert torch.equal(out, again), "split-K must be deterministic"
+        if kind != "resid":
+            assert torch.equal(op[0], op2[0]) and torch.equal(_lo8(op, M, 768), _lo8(op2, M, 768)) and torch.equal(st, st2)
+
+
+def test_split_k_library_choice_and_reused_scratch(hip):
+    """sk_split = 0: the library chooses the factor; one scratch region serves launches of different row counts back to back (the whole-path use:
+    the stream's proj / fc2, then the last decoder block's compact rows)."""
+    ws = hip_ops.splitk_workspace(1536, 768)
+    for M, K in ((1536, 3072), (256, 3072), (1536, 768), (256, 768), (1536, 3072)):
+        N = 768
+        a, w, b = _rand("a", (M, K), seed=13).cuda(), _rand("w", (N, K), 0.04, 13).cuda(), _rand("b", (N,), 0.3, 13).cuda()
+        x0 = (_rand("r", (M, N), 2.0, 13) + 0.7).cuda()
+        e = hip_ops.f16c8_qexp(w)
+        a16, w16 = hip_ops.f16c8_encode(a, 0, False), hip_ops.f16c8_encode(w, e, True)
+        base = hip_ops.gemm(a16, w16, b, prec="f16c8", w_qexp=e, out_f32=True, resid=x0.clone())
+        out = hip_ops.gemm(a16, w16, b, prec="f16c8", w_qexp=e, out_f32=True, resid=x0.clone(), split_k=(ws, 0))
+        assert (out - base).abs().max().item() <= 4e-6 * float(base.abs().max()), (M, K)
+        assert int(ws[:16384].view(torch.int32).abs().max()) == 0
+    assert hip_ops.splitk_workspace(8192, 768) is None and hip_ops.splitk_workspace(1536, 1000) is None

@@ -216,7 +216,7 @@ def test_c_abi_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.bd_abi_version() == 8 and lib.bd_target_arch() == b"gfx950"
+    assert lib.bd_abi_version() == 9 and lib.bd_target_arch() == b"gfx950"
     # argument validation happens before any launch: NULL / bad shapes are rejected on a GPU-less box
     g = _lib.GemmArgs()
     assert lib.bd_gemm(ctypes.byref(g), 0, None) == -5
@@ -398,7 +398,7 @@ def test_precision_ids():
         with pytest.raises(ValueError):
             _lib.prec_id(gone)
     hdr = open(os.path.join(ROOT, "include", "boxdreamer_hip.h")).read()
-    for name, val in (("BD_PREC_BF16X3_ATTN_X3", 6), ("BD_PREC_F16C8", 8), ("BD_PREC_F16C8_QK16", 13), ("BD_ABI_VERSION", 8),
+    for name, val in (("BD_PREC_BF16X3_ATTN_X3", 6), ("BD_PREC_F16C8", 8), ("BD_PREC_F16C8_QK16", 13), ("BD_ABI_VERSION", 9),
                       ("BD_PROMOTE_QKV", _lib.PROMOTE_QKV), ("BD_PROMOTE_PROJ", _lib.PROMOTE_PROJ), ("BD_PROMOTE_FC1", _lib.PROMOTE_FC1),
                       ("BD_PROMOTE_FC2", _lib.PROMOTE_FC2), ("BD_PROMOTE_ATTN", _lib.PROMOTE_ATTN),
                       ("BD_PROMOTE_ADAPTER_FC1", _lib.PROMOTE_ADAPTER_FC1), ("BD_PROMOTE_ADAPTER_FC2", _lib.PROMOTE_ADAPTER_FC2),
