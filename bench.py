@@ -138,13 +138,12 @@ def cpu_baseline(T: int, budget_s: float = 24.0) -> dict:
                       f"{torch.get_num_threads()} threads"}
 
 
-def parity_probe(prec, T: int, device, models=None, weights: str = "plain") -> dict:
+def parity_probe(prec, T: int, device, models=None, weights: str = "plain", B: int = 2) -> dict:
     """Max-abs error of the heatmap logits vs the CPU oracle on full-depth poses (outside the timed region): B = 2 samples
     with different inputs, the same weights as the timed step."""
     from boxdreamer_amd import hip_ops, synth
     from oracle import boxdreamer_oracle as orc
     enc, dec = models if models is not None else build_models(prec, device, weights)
-    B = 2
     data = synth.make_batch(seed=11, B=B, T=T)
     mask = torch.zeros(B, T, dtype=torch.bool); mask[:, T - 1] = True
     img, bf = data["images"].to(device), data["bbox_feat"].to(device)
@@ -775,6 +774,8 @@ class ModeRun:
                 return torch.cat(parts, 0).to(kp.device)
             self.gather = host_staged_gather
         self.enc, self.dec = build_models(prec, device, weights)
+        if getattr(args, "latency_forms", False):      # opt-in latency forms (split-K residual Linears for calls of one or two poses; ABI 9)
+            self.enc.model.latency, self.dec.hip_latency = True, True
         # sub-batch lanes of one batch (two BATCHES in flight already fill each other's idle CUs: each then runs as one lane)
         def lane_arg(v):
             return v if v == "auto" else int(v)
@@ -1370,6 +1371,9 @@ def main():
     ap.add_argument("--no-strict", action="store_true", help="skip the second (strict-mode) timing")
     ap.add_argument("--no-trained-like", action="store_true", help="skip the strict-mode leg on the trained-like outlier weights")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-pose (B = 1) latency leg of the default single-GPU run")
+    ap.add_argument("--latency-forms", action="store_true",
+                    help="opt into the latency forms (`hip_latency: true`: split-K residual Linears for calls of one or two poses; deterministic, within "
+                         "tolerance, not bit-identical to the same sample inside a larger batch) -- for --batch 1 / 2 runs")
     ap.add_argument("--no-fp8", action="store_true", help="skip the configs[4] leg (fp8 Linears, batch 64) of the default single-GPU run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -1674,6 +1678,18 @@ def run(args):
             lat[m] = {"ms_per_pose": round(lres["ms_per_step"], 3), "poses_per_s": round(lres["value"], 1), "hip_graph": lres["run"].graphed is not None}
             lres["run"].close()
             del lres
+            if m in ("f16c8_qk16", "f16c8"):
+                # the same call with the OPT-IN latency forms (`hip_latency: true`, ABI 9: split-K residual Linears): the figure of record for
+                # one pose at a time; the row above is the throughput forms (bit-identical to the same sample inside any batch)
+                torch.cuda.empty_cache()
+                argsL = argparse.Namespace(**{**vars(args1), "latency_forms": True})
+                lres = measure_mode(m, argsL, device, world, rank, dist, img1, bb1, mask1)
+                par = parity_probe(m, T, device, (lres["run"].enc, lres["run"].dec), B=1) if not args.no_parity else None
+                lat[m] = {"ms_per_pose": round(lres["ms_per_step"], 3), "poses_per_s": round(lres["value"], 1), "hip_graph": lres["run"].graphed is not None,
+                          "forms": "latency forms (hip_latency: true)", "throughput_forms_ms_per_pose": lat[m]["ms_per_pose"],
+                          "parity": par}
+                lres["run"].close()
+                del lres
         line["one_pose_latency"] = {"workload": "B = 1: 1 query + 5 references, 224x224, one forward at a time (HIP graph), inputs resident in HBM",
                                     "modes": lat}
         line["config"].update(one_pose_ms=lat[prec]["ms_per_pose"])

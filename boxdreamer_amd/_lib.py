@@ -99,7 +99,7 @@ class DinoWeights(C.Structure):
                 ("patch_embed", Linear),
                 ("pos_patch", C.c_void_p), ("prefix_tokens", C.c_void_p),
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
-                ("blocks", C.POINTER(BlockWeights)), ("promote_misc", C.c_int), ("feats_prec", C.c_int)]
+                ("blocks", C.POINTER(BlockWeights)), ("promote_misc", C.c_int), ("feats_prec", C.c_int), ("latency_mode", C.c_int)]
 
 
 class BetrWeights(C.Structure):
@@ -108,7 +108,7 @@ class BetrWeights(C.Structure):
                 ("ln_eps", C.c_float), ("adapter_ln_eps", C.c_float), ("rms_eps", C.c_float),
                 ("adapter_fc1", Linear), ("adapter_fc2", Linear), ("bbox_emb", Linear), ("bbox_proj", Linear),
                 ("pos_table", C.c_void_p), ("query_token", C.c_void_p),
-                ("blocks", C.POINTER(BlockWeights)), ("promote_misc", C.c_int)]
+                ("blocks", C.POINTER(BlockWeights)), ("promote_misc", C.c_int), ("latency_mode", C.c_int)]
 
 
 class TraceRecord(C.Structure):

@@ -85,6 +85,9 @@ class BETR(nn.Module):
         # per-Linear promotion (F16C8 family -> split-f16, e4m3 -> bf16) (include/boxdreamer_hip.h: BD_PROMOTE_*): one mask per block and
         # one for the Linears outside the blocks; all zero until boxdreamer_amd/calibrate.py (or the caller) sets them
         self.hip_lanes = kwargs.get("hip_lanes", "auto")   # sub-batch lanes of one forward ("auto" | 1..4; bit-identical results)
+        # OPT-IN latency forms for calls of one or two poses (bd_betr_weights.latency_mode: split-K residual Linears; deterministic, within
+        # the mode's tolerance, NOT bit-identical to the same sample inside a larger batch) -- the reference demo's per-frame call
+        self.hip_latency = bool(kwargs.get("hip_latency", False))
         self.hip_promote = [0] * num_decoder_layers
         self.hip_promote_misc = 0
         if self.hip_precision == "fp8_mixed":
@@ -190,6 +193,9 @@ class BETR(nn.Module):
         prec = self.hip_precision
         pid = _lib.prec_id(prec)
         w = self._weights(dev, prec).struct
+        if w.latency_mode != int(self.hip_latency):
+            self._check_not_frozen("switching hip_latency (the workspace layout changes)")
+            w.latency_mode = int(self.hip_latency)
         P, D = w.grid * w.grid, w.dim
         if masks.dtype != torch.bool or masks.shape != (B, T):
             raise ValueError("masks must be a (B, T) bool tensor")

@@ -323,7 +323,7 @@ int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, flo
     return proj_mlp_stage(w, p, b, xc, Mq, D, ln_eps, stream);
 }
 
-BlockBufs carve_block(Carver& c, int64_t M, int D, int np) {
+BlockBufs carve_block(Carver& c, int64_t M, int D, int np, bool latency) {
     BlockBufs b;
     b.x = (float*)c.take((size_t)M * D * 4);
     b.xn = c.take((size_t)M * D * 2 * np);
@@ -331,8 +331,9 @@ BlockBufs carve_block(Carver& c, int64_t M, int D, int np) {
     b.ao = c.take((size_t)M * D * 2 * np);
     b.h = c.take((size_t)M * 4 * D * 2 * np);
     b.st = (float*)c.take((size_t)M * ((D + 95) / 96) * 2 * 4);
-    // split-K scratch for the stream's residual Linears when the whole stream is a few tiles (one or two poses at a time)
-    const size_t skb = (np == 2 && M <= BD_SPLITK_MAX_ROWS) ? bd_gemm_splitk_workspace_bytes((int)M, D) : 0;
+    // split-K scratch for the stream's residual Linears when the caller opted into the latency forms (bd_*_weights.latency_mode) and the
+    // whole stream is a few tiles (one or two poses at a time)
+    const size_t skb = (latency && np == 2 && M <= BD_SPLITK_MAX_ROWS) ? bd_gemm_splitk_workspace_bytes((int)M, D) : 0;
     b.sk = skb ? c.take(skb) : nullptr;
     b.sk_flag_bytes = skb ? bd_gemm_splitk_flag_bytes((int)M, D) : 0;
     return b;
@@ -344,7 +345,7 @@ EncBufs carve_encoder(const bd_dino_weights* w, int n, int prec, void* ws) {
     const int np = planes_of(prec), P = w->grid * w->grid;
     EncBufs e;
     e.a_patch = c.take((size_t)n * P * w->kpad * 2 * np);
-    e.blk = carve_block(c, (int64_t)n * (P + w->n_prefix), w->dim, np);
+    e.blk = carve_block(c, (int64_t)n * (P + w->n_prefix), w->dim, np, w->latency_mode != 0);
     e.bytes = c.off + 256;
     return e;
 }
@@ -362,7 +363,7 @@ DecBufs carve_decoder(const bd_betr_weights* w, int B, int T, int prec, void* ws
     d.rgb = (float*)c.take((size_t)Mb * D * 4);
     d.qtok = c.take((size_t)Mq * D * 2 * np);
     d.proj = (float*)c.take((size_t)Mq * F * 4);
-    d.blk = carve_block(c, Mb, D, np);
+    d.blk = carve_block(c, Mb, D, np, w->latency_mode != 0);
     d.bytes = c.off + 256;
     return d;
 }

@@ -53,6 +53,7 @@ class DinoV2Encoder:
         depth = 1 + max(int(k.split(".")[1]) for k in self.sd if k.startswith("blocks."))
         # per-Linear promotion (F16C8 family -> split-f16, e4m3 -> bf16) (include/boxdreamer_hip.h: BD_PROMOTE_*), set by calibrate.py
         self.lanes = "auto"          # sub-batch lanes of one predict() call ("auto" | 1..4; bit-identical results, _lib.resolve_lanes)
+        self.latency = False         # opt-in latency forms (bd_dino_weights.latency_mode; see BETR.hip_latency)
         self.promote = [0] * depth
         self.promote_misc = 0
         self.feats_prec = 0          # 0: feats16 in the class of `prec`; the promoted class when the decoder's adapter fc1 is promoted
@@ -123,6 +124,10 @@ class DinoV2Encoder:
             raise ValueError(f"expected (N,3,S,S) with S % {self.patch} == 0, got {tuple(images.shape)}")
         pk = self._weights(size, prec)
         w = pk.struct
+        if w.latency_mode != int(self.latency):
+            if len(self._frozen_by):
+                raise RuntimeError("switching hip_latency would change the workspace layout a live GraphedPath still replays on; delete the graph first")
+            w.latency_mode = int(self.latency)
         P, D = w.grid * w.grid, w.dim
         lanes = _lib.resolve_lanes(self.lanes, n, n, prec)
         # sized for the laned AND the plain form: switching `lanes` under a live captured graph must never grow the workspace
@@ -189,6 +194,7 @@ class DinoV2Wrapper(PretrainedModelWrapper):
                 f"{self.model_type} state_dict file; torch.hub download is not available on this path")
         self.model = DinoV2Encoder(sd, heads=heads, prec=self.prec)
         self.model.lanes = self.cfg.get("hip_lanes", "auto")
+        self.model.latency = bool(self.cfg.get("hip_latency", False))
         if torch.cuda.is_available():
             self.model.to(device)
             self.device = torch.device(device) if not isinstance(device, torch.device) else device

@@ -90,6 +90,14 @@ class BoxDreamer(nn.Module):
         # outputs, tests/test_gpu_facade.py).  One graph is kept: a new batch shape drops it and captures again.
         self.hip_graph = bool(module_configs.get("hip_graph", False))
         self._graph, self._graph_key = None, None
+        # `hip_latency: true` in config["modules"]: opt into the latency forms for calls of one or two poses (the reference demo's per-frame
+        # call, src/demo/demo.py:1501-1514): the residual Linears run split-K (bd_*_weights.latency_mode, ABI 9) -- one pose 4.6 -> 3.9 ms.
+        # Deterministic and within the mode's tolerance, but a sample's bits then differ from the same sample inside a larger batch; off
+        # by default, so that every row stays bit-identical across batch sizes, lanes and launch forms.
+        if "hip_latency" in module_configs:
+            self.decoder.hip_latency = bool(module_configs["hip_latency"])
+            if hasattr(self.rgb_encoder, "model"):
+                self.rgb_encoder.model.latency = bool(module_configs["hip_latency"])
         self.decoder.validate_inputs = "deferred"      # the one-hot check of camera_mask travels with the corners' D2H (no sync of its own)
         self.host_syncs_per_forward = None             # filled by forward(): what still waits for the device, for the record
         self._pose_pin = None
@@ -247,7 +255,8 @@ class BoxDreamer(nn.Module):
         from .graph import GraphedPath
         B, T = images.shape[:2]
         key = (B, T, images.shape[-1], images.dtype, pose_feat.dtype, str(images.device), sig if sig is not None else self.decoder._signature(),
-               self.rgb_encoder.model.state_stamp(self.rgb_encoder.prec), str(self.decoder.hip_precision))
+               self.rgb_encoder.model.state_stamp(self.rgb_encoder.prec), str(self.decoder.hip_precision),
+               bool(self.decoder.hip_latency), bool(getattr(self.rgb_encoder.model, "latency", False)))
         if self._graph is None or self._graph_key != key:
             self._graph = None                      # lifts the modules' freeze before anything re-allocates
             if pose_feat.dtype != images.dtype:

@@ -367,6 +367,11 @@ typedef struct bd_dino_weights {
     int promote_misc;                /* BD_PROMOTE_PATCH_EMBED (F16C8 family only) */
     int feats_prec;                  /* operand class of feats16: 0 = the class of `prec`; BD_PREC_F16X3 (F16C8 family only) when the
                                         consumer's first Linear is promoted (BD_PROMOTE_ADAPTER_FC1) */
+    int latency_mode;                /* ABI 9.  != 0: OPT-IN latency forms for calls of one or two poses (token stream <= BD_SPLITK_MAX_ROWS rows):
+                                        the residual Linears of the F16C8 family may run split-K (bd_gemm_args.sk_ws; the workspace grows by
+                                        the scratch region).  Deterministic, within the mode's tolerance, but a sample's bits then depend on
+                                        whether its call took the latency forms -- 0 (default) keeps every row bit-identical across batch
+                                        sizes, lanes and launch forms.  src/demo/demo.py:1501-1514 (one query + its references per frame). */
 } bd_dino_weights;
 
 typedef struct bd_betr_weights {
@@ -377,6 +382,7 @@ typedef struct bd_betr_weights {
     const float* query_token;        /* fp32 [dim] */
     const bd_block_weights* blocks;  /* [host] */
     int promote_misc;                /* BD_PROMOTE_ADAPTER_FC1 | _ADAPTER_FC2 | _BBOX_EMB | _BBOX_PROJ (F16C8 family only) */
+    int latency_mode;                /* as bd_dino_weights.latency_mode */
 } bd_betr_weights;
 
 /* DinoV2Wrapper.predict (encoder/dinov2.py:45-60): images [n_images, 3, size, size] in [0,1]

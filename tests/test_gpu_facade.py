@@ -86,6 +86,38 @@ def test_forward_dict_contract(hip, dtype, prec):
     assert "regression_boxes" not in out2 and torch.equal(out2["pred_poses"], dev2["poses"])
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_facade_latency_opt_in(hip, graph):
+    """config["modules"]["hip_latency"] = True (the reference demo's per-frame call, src/demo/demo.py:1501-1514): the modules' latency forms
+    (ABI 9, split-K residual Linears) behind the same forward(dict) -> dict; within the bar against the CPU oracle, deterministic, eager ==
+    HIP graph; the default (flag absent) stays the throughput forms."""
+    cfg = _config_with(STRICT_DEFAULT)
+    assert BoxDreamer(copy.deepcopy(cfg)).decoder.hip_latency is False
+    cfg["modules"]["hip_latency"] = True
+    cfg["modules"]["hip_graph"] = graph
+    model = BoxDreamer(cfg)
+    assert model.decoder.hip_latency is True and model.rgb_encoder.model.latency is True
+    model.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
+    model = model.cuda().eval()
+    data = synth.make_batch(seed=8, B=1, T=6)
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    out1 = model(dict(dev))
+    l1, c1 = model.decoder.last_logits.clone(), out1["pred_corners_px"].clone()
+    out2 = model(dict(dev))
+    assert torch.equal(model.decoder.last_logits, l1) and torch.equal(out2["pred_corners_px"], c1)
+    o = orc.boxdreamer_forward(data, synth.betr_state_dict(1234, 2), synth.dino_state_dict(4321, 2))
+    assert (l1.cpu() - o["logits"]).abs().max().item() <= 1e-3
+    assert (c1.cpu() - o["corners_px"]).abs().max().item() <= 224 / 20 * 2
+    assert torch.isfinite(out2["pred_poses"]).all()
+    # the throughput forms on the same input differ in fp32 association only
+    ref = BoxDreamer(_config_with(STRICT_DEFAULT))
+    ref.load_state_dict({"decoder." + k: v for k, v in synth.betr_state_dict(1234, 2).items()}, strict=True)
+    ref = ref.cuda().eval()
+    ref(dict(dev))
+    d = (ref.decoder.last_logits - l1).abs().max().item()
+    assert 0.0 < d <= 5e-4, d
+
+
 def test_unsupported_configs_raise():
     cfg = _config("bf16")
     cfg["modules"]["use_tracking"] = True

@@ -184,6 +184,44 @@ def test_16bit_inputs_match_fp32_inputs(hip, in_dtype):
         assert (a[2] - b[2]).abs().max().item() < 0.05
 
 
+@pytest.mark.parametrize("case", ["full_T2", "full_T6"])
+def test_latency_forms_meet_the_bar_and_are_deterministic(hip, golden_dir, case):
+    """`hip_latency: true` (ABI 9, bd_*_weights.latency_mode): the residual Linears of a one-pose call run split-K.  The opt-in trades the
+    bit-identity with the throughput forms for latency -- the logits must still meet the 1e-3 bar against the CPU oracle and the REAL
+    reference's fixture with identical top-20 sets, be deterministic, and the flag must actually change the launch forms (else this test
+    measures nothing)."""
+    prec = "f16c8_qk16"
+    g = np.load(os.path.join(golden_dir, f"case_{case}.npz"))
+    meta = json.loads(str(g["meta"]))
+    B, T, dd, bd, seed = meta["B"], meta["T"], meta["dino_depth"], meta["betr_depth"], meta["input_seed"]
+    assert B == 1
+    data, feats_t, logits_t, *_ = _run(prec, B, T, dd, bd, seed)            # throughput forms
+    o = _oracle(data, dd, bd)
+    enc, dec = _build(prec, dd, bd)
+    enc.model.latency, dec.hip_latency = True, True
+    mask = torch.zeros(B, T, dtype=torch.bool); mask[torch.arange(B), data["query_idx"]] = True
+    img, bf = data["images"].cuda(), data["bbox_feat"].cuda()
+    outs = []
+    for _ in range(2):
+        heat = dec(bf, img, mask.cuda(), enc.predict(img), None)
+        kp, kn, idx = hip_ops.decode_topk(heat)
+        outs.append((dec.last_logits.cpu().clone(), kp.cpu().clone(), idx.cpu().long().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "the latency forms must be deterministic"
+    logits, kp, idx = outs[0]
+    e_logit = (logits - o["logits"]).abs().max().item()
+    e_gold = np.abs(logits.reshape(B, -1)[:, ::7].numpy() - g["logits_strided"]).max()
+    d_forms = (logits - logits_t).abs().max().item()
+    print(f"[latency forms {case}] logits vs oracle {e_logit:.3e}, vs the reference fixture {e_gold:.3e}, vs the throughput forms {d_forms:.3e}")
+    assert e_logit <= 1e-3 and e_gold <= 1e-3 + 1e-4
+    assert 0.0 < d_forms <= 5e-4, "split-K must be in effect (different fp32 association) and stay inside the mode's margin"
+    assert_identical_topk_sets(idx, o, e_logit, f"latency forms {case}")
+    assert (kp - o["corners_px"]).abs().max().item() <= 224 / 20 * 2
+    # switching back restores the throughput forms bit for bit
+    enc.model.latency, dec.hip_latency = False, False
+    dec(bf, img, mask.cuda(), enc.predict(img), None)
+    assert torch.equal(dec.last_logits.cpu(), logits_t)
+
+
 def test_batch_independence_and_determinism(hip):
     """Samples are independent units: a sample's result does not depend on its batch mates,
     and the path is run-to-run deterministic."""
