@@ -479,17 +479,20 @@ extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_fea
     }
     BD_TRY(bd_query_substitute(d.blk.x, d.rgb, w->pos_table, w->query_token, query_idx, B, T, P, D, stream));
     // K9: joint self-attention over all T*P tokens of a sample
+    // (latency forms, one or two poses per call: the q, k / v column split of BD_PREC_F16C8_QK16 is two launches of ~20 us each where one
+    // F16C8 QKV launch takes ~26 us -- at these sizes a launch costs its fixed part, not its passes; q, k then carry the full F16C8 product)
+    const int bprec = (w->latency_mode && Mb <= BD_SPLITK_MAX_ROWS && wprec == BD_PREC_F16C8_QK16) ? BD_PREC_F16C8 : wprec;
     bool folded = false, stale = false;      // LayerNorm 1 of block i is folded behind block i-1's fc2 (never block 0's); b.x is stale
     for (int i = 0; i + 1 < w->depth; ++i) {
         bool next_folded = false;
-        BD_TRY(run_block(w->blocks[i], d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, wprec, stream, 0, true, folded,
+        BD_TRY(run_block(w->blocks[i], d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, bprec, stream, 0, true, folded,
                          &w->blocks[i + 1], &next_folded, &stale, /*next_compact=*/i + 2 == w->depth));
         folded = next_folded;
     }
     if (stale) return BD_ERR_SHAPE;          // (the block in front of the last one writes fp32 rows: the last block gathers its query rows from them)
     // last block: query-view rows only past the K/V projection; d.t2 (dead since the adapter) holds the compact stream
     BD_TRY(run_last_block_query_only(w->blocks[w->depth - 1], d.blk, d.t2, query_idx, B, T, P, D, w->heads,
-                                     w->ln_eps, w->rms_eps, wprec, stream, folded));
+                                     w->ln_eps, w->rms_eps, bprec, stream, folded));
     // K10: head on the query view's tokens (no final norm, betr.py:298-306)
     BD_TRY(bd_gather_query_tokens(d.t2, nullptr, d.qtok, (int64_t)Mq * D, B, 1, P, D, c_bp, stream));
     {
