@@ -481,12 +481,13 @@ def algorithmic_gemm_bytes(prec: str, B: int, T: int) -> tuple[int, int]:
         gemm(Mtail, 768, 3072, a, w, 4, True)
 
     n = B * T
-    gemm(n * 256, 768, 640 if prec != "fp8" else 640, a, w, 4)                                  # patch embed (+ positional table)
+    c8 = prec in ("f16c8", "f16c8_qk16")          # (the F16C8 family pads the embeddings' K to 192s: pack.embed_k_multiple)
+    gemm(n * 256, 768, 768 if c8 else 640, a, w, 4)                                             # patch embed (+ positional table)
     for i in range(12):                                       # DINOv2: q, k not normalised -> split-bf16 attention in the strict modes
         block(n * 261, n * 261, a, w, 4 if strict else (2 if prec != "fp8" else 2), i, i == 11)
     M, Mq = n * 256, B * 256
     gemm(M, 768, 768, a, w, a); gemm(M, 768, 768, a, w, 4)                                     # adapter
-    gemm(M, 768, 1600 if prec != "fp8" else 1664, a, w, 4, True)                                # heatmap patch embedding + rgb + pos
+    gemm(M, 768, 1728 if c8 else (1600 if prec != "fp8" else 1664), a, w, 4, True)                                # heatmap patch embedding + rgb + pos
     for i in range(12):                                       # BETR: f16 attention in the strict modes (q, k RMS-normalised)
         Mt = M if i < 11 else Mq
         if prec == "f16c8_qk16":                              # QKV split by column: q, k one f16 pass on the f16 plane, v full F16C8

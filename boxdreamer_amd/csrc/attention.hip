@@ -760,13 +760,19 @@ template <class T, int NS, int HD, int NW, int OUTMODE = 0> int launch(const Att
     return BD_OK;
 }
 
+// (file-local) opt-in latency forms of the call being dispatched: set by bd_attention_q_forms around its dispatch, on the calling thread
+static thread_local bool g_latency_forms = false;
+
 template <class T, int NS, int OUTMODE = 0> int dispatch(const AttnArgs& a, int head_dim, hipStream_t s) {
     // 3 waves (96-query blocks) when that tiles the sequence with less waste (DINOv2: 261 -> 3 x 96)
     const int waste4 = ((a.q_len + 127) / 128) * 128 - a.q_len, waste3 = ((a.q_len + 95) / 96) * 96 - a.q_len;
     const bool use3 = waste3 < waste4;
     if constexpr (NS == 1) {
         // ping-pong kernel where its 256-query blocks tile the query range without waste (BETR: 1536 = 6 x 256; last block: 256)
-        if (head_dim == 96 && a.q_len % 256 == 0 && a.seq % KT == 0) return launch_pp<T, 96, OUTMODE>(a, s);      // (whole key tiles only: the kernel has no tail mask)
+        // (latency forms, round 6: one pose at a time the 256-query blocks are 48 workgroups on 256 CUs, 36 us; the 128-query kernel's 96
+        // take 31 us -- and lose from two poses on: profiles/r6_attn_b1_probe.txt)
+        const bool few = g_latency_forms && 4 * ((a.q_len + 255) / 256) * a.heads * a.batch <= 256;      // (a quarter of MI355X's 256 CUs)
+        if (head_dim == 96 && a.q_len % 256 == 0 && a.seq % KT == 0 && !few) return launch_pp<T, 96, OUTMODE>(a, s);      // (whole key tiles only: the kernel has no tail mask)
     }
     if (head_dim == 96) return use3 ? launch<T, NS, 96, 3, OUTMODE>(a, s) : launch<T, NS, 96, 4, OUTMODE>(a, s);
     if (head_dim == 64) return use3 ? launch<T, NS, 64, 3, OUTMODE>(a, s) : launch<T, NS, 64, 4, OUTMODE>(a, s);
@@ -779,6 +785,14 @@ inline bool sample_bytes_out_of_range(int seq, int heads, int head_dim) {
 }
 
 }  // namespace
+
+int bd_attention_q_forms(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch, int seq, int heads, int head_dim,
+                         float scale, const int32_t* q_view, int q_len, int prec, int latency_forms, void* stream) {
+    g_latency_forms = latency_forms != 0;
+    const int rc = bd_attention_q(qkv, qkv_plane, out, out_plane, batch, seq, heads, head_dim, scale, q_view, q_len, prec, stream);
+    g_latency_forms = false;
+    return rc;
+}
 
 extern "C" int bd_attention_q(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch, int seq,
                               int heads, int head_dim, float scale, const int32_t* q_view, int q_len, int prec,

@@ -438,6 +438,11 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
 // changes a result (every row is independent of the tile form).
 int& bd_concurrent_launches();
 
+// attention.hip: bd_attention_q with the opt-in latency forms (bd_*_weights.latency_mode): launches whose 256-query workgroups would
+// occupy at most a quarter of the CUs take the 128-query kernel instead (twice the workgroups; not bit-identical to the 256-query form)
+int bd_attention_q_forms(const void* qkv, int64_t qkv_plane, void* out, int64_t out_plane, int batch, int seq, int heads, int head_dim,
+                         float scale, const int32_t* q_view, int q_len, int prec, int latency_forms, void* stream);
+
 // trace.hip
 int bd_trace_open(hipStream_t s, int kind, int M, int N, int K);
 void bd_trace_close(hipStream_t s, int slot);

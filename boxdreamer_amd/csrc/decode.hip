@@ -122,6 +122,145 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
     }
 }
 
+// Round 6: the map held in REGISTERS.  decode_kernel above walks k = 20 dependent rounds of (workgroup arg-max over ds_bpermute shuffles and
+// two barriers, rescan of the winner's slice from L2): ~2.8 us per round, 56 us per launch whatever the number of maps -- 1.5 % of a one-pose
+// step.  Here 1024 threads load the whole map once, element i to thread i % 1024 (coalesced; the pixels of a heat-map peak -- neighbours in
+// a row, rows 224 apart -- land in different threads), keep their NE values in registers and their two best candidates in (value desc,
+// index asc) order.  A round is a wave arg-max on DPP row shifts / broadcasts (no LDS round trips), 16 LDS slots double-buffered by round
+// parity (one barrier), a 16-lane DPP combine; the winner promotes its second candidate and rescans its registers only after it has won
+// twice (behind a wave-uniform branch).  The picks collect in LDS; their (x, y) sums -- integers below 2^24: exact in any order -- and the
+// index list leave at the end, so no integer division sits in the loop.  All per-lane conditions are bitwise, not short-circuit (see
+// better_nb).  A one-wave-per-SIMD variant (256 threads x 196 registers) was slower: the scans and the rounds are dependent chains of
+// VALU -> SALU -> VALU hand-offs (~10-20 cycles per instruction for a lone wave; a build cut after each phase: loads 5 us, first scan 27 us, rounds 31 us),
+// which four waves per SIMD interleave.  Same total order, same tie rule, same arithmetic as decode_kernel: bit-identical corners and
+// index lists (tests/test_gpu_ops.py, tests/test_gpu_fuzz.py).
+// `better` without short-circuit evaluation: hipcc compiles && / || on per-lane conditions into EXEC-mask branches (a dozen scalar
+// instructions and a branch per element of the unrolled register scans below); bitwise forms stay two compares and an s_and / s_or
+__device__ __forceinline__ bool better_nb(float v, int i, float bv, int bi) { return (v > bv) | ((v == bv) & (i < bi)); }
+
+// (value, index) arg-max steps on the VALU's data-parallel primitives: lane l takes the better of its pair and the pair of the lane the DPP
+// control names (row_shr:n = 0x110 + n inside a row of 16 lanes, row_bcast15 / row_bcast31 across rows; lanes without a source keep their own)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_best(float& v, int& i) {
+    const int vb = __builtin_bit_cast(int, v);
+    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vb, vb, CTRL, ROW_MASK, 0xF, false));
+    const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xF, false);
+    const bool b = better_nb(ov, oi, v, i);
+    v = b ? ov : v;
+    i = b ? oi : i;
+}
+// best pair of a row of 16 lanes, in its lane 15
+__device__ __forceinline__ void row_best(float& v, int& i) {
+    dpp_best<0x111, 0xF>(v, i);
+    dpp_best<0x112, 0xF>(v, i);
+    dpp_best<0x114, 0xF>(v, i);
+    dpp_best<0x118, 0xF>(v, i);
+}
+// best pair of the wave, broadcast to every lane (ds_bpermute shuffles cost an LDS round trip per step: six dependent ones per round)
+__device__ __forceinline__ void wave_best(float& v, int& i) {
+    row_best(v, i);
+    dpp_best<0x142, 0xA>(v, i);         // row_bcast15 into rows 1, 3
+    dpp_best<0x143, 0xC>(v, i);         // row_bcast31 into rows 2, 3
+    v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    i = __builtin_amdgcn_readlane(i, 63);
+}
+
+// the two best of a thread's register-resident elements strictly after (pv, pi); element j of thread t is map index t + 1024 j
+template <int NE>
+__device__ __forceinline__ void regs_rescan(const float (&v)[NE], int tid, float pv, int pi, float& c1v, int& c1i, float& c2v, int& c2i) {
+    c1v = c2v = -INFINITY;
+    c1i = c2i = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int i = tid + 1024 * j;
+        const float x = v[j];                                   // (elements past the map are NaN: every comparison below is false)
+        const bool ok = (x < pv) | ((x == pv) & (i > pi));
+        const bool b1 = ok & better_nb(x, i, c1v, c1i), b2 = ok & !b1 & better_nb(x, i, c2v, c2i);
+        c2v = b1 ? c1v : (b2 ? x : c2v);
+        c2i = b1 ? c1i : (b2 ? i : c2i);
+        c1v = b1 ? x : c1v;
+        c1i = b1 ? i : c1i;
+    }
+}
+
+template <int NE>
+__global__ __launch_bounds__(1024) void decode_kernel_regs(const float* __restrict__ heat, int hw, int width, int height, int k,
+                                                          float* __restrict__ kp_px, float* __restrict__ kp_norm, int32_t* __restrict__ topk_idx) {
+    __shared__ float sv[2][16];
+    __shared__ int si[2][16];
+    __shared__ int s_idx[64];                  // the picks, in order (k <= 64: host-checked)
+    __shared__ float s_xy[2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* h = heat + (int64_t)blockIdx.x * hw;
+    float v[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int i = tid + 1024 * j;
+        const float x = (h[i < hw ? i : tid] + 1.0f) / 2.0f;     // box_utils.py:79
+        v[j] = i < hw ? x : __builtin_nanf("");
+    }
+    float c1v, c2v;
+    int c1i, c2i;
+    // first scan, unfiltered: indices ascend with j, so STRICT comparisons keep the lower index among equal values (NaN past the map: false)
+    c1v = c2v = -INFINITY;
+    c1i = c2i = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int i = tid + 1024 * j;
+        const float x = v[j];
+        const bool b1 = x > c1v, b2 = !b1 & (x > c2v);
+        c2v = b1 ? c1v : (b2 ? x : c2v);
+        c2i = b1 ? c1i : (b2 ? i : c2i);
+        c1v = b1 ? x : c1v;
+        c1i = b1 ? i : c1i;
+    }
+    for (int round = 0; round < k; ++round) {
+        float bv = c1v;
+        int bi = c1i;
+        wave_best(bv, bi);
+        const int par = round & 1;
+        if (lane == 0) { sv[par][wid] = bv; si[par][wid] = bi; }
+        __syncthreads();
+        // the 16 wave results: every row of 16 lanes reads them (one slot per lane) and reduces them with four DPP steps
+        float fv = sv[par][lane & 15];
+        int fi = si[par][lane & 15];
+        row_best(fv, fi);
+        fv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fv), 15));
+        fi = __builtin_amdgcn_readlane(fi, 15);
+        if (tid == 0) s_idx[round] = fi;
+        // this thread's candidate won: its second best moves up; none left -> look through the registers again.  The rescan sits behind a
+        // WAVE-UNIFORM branch: as a per-lane branch around side-effect-free code hipcc turned it into straight-line code + selects, i.e.
+        // every wave rescanned its NE registers in every round (measured: 108 us per launch instead of 15)
+        const bool won = c1i == fi, dry = won && c2i == 0x7fffffff;
+        if (won && !dry) { c1v = c2v; c1i = c2i; c2v = -INFINITY; c2i = 0x7fffffff; }
+        if (__builtin_amdgcn_ballot_w64(dry) != 0) {
+            float n1v, n2v;
+            int n1i, n2i;
+            regs_rescan<NE>(v, tid, fv, fi, n1v, n1i, n2v, n2i);
+            if (dry) { c1v = n1v; c1i = n1i; c2v = n2v; c2i = n2i; }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int fi = tid < k ? s_idx[tid] : 0;
+        if (topk_idx && tid < k) topk_idx[(int64_t)blockIdx.x * k + tid] = fi;
+        s_xy[0][tid] = tid < k ? (float)(fi % width) : 0.f;
+        s_xy[1][tid] = tid < k ? (float)(fi / width) : 0.f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float sx = 0.f, sy = 0.f;              // (xs.float().mean(dim=2): sums of integers below 2^24 -- exact, order-free)
+        for (int r = 0; r < k; ++r) { sx += s_xy[0][r]; sy += s_xy[1][r]; }
+        const float mx = sx / (float)k, my = sy / (float)k;
+        kp_px[blockIdx.x * 2 + 0] = mx;
+        kp_px[blockIdx.x * 2 + 1] = my;
+        if (kp_norm) {
+            kp_norm[blockIdx.x * 2 + 0] = (mx / (float)width) * 2.0f - 1.0f;   // box_utils.py:105-108
+            kp_norm[blockIdx.x * 2 + 1] = (my / (float)height) * 2.0f - 1.0f;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int bd_decode_topk(const float* heat, int n_maps, int height, int width, int k, float* kp_px,
@@ -129,6 +268,17 @@ extern "C" int bd_decode_topk(const float* heat, int n_maps, int height, int wid
     if (!heat || !kp_px) return BD_ERR_NULL;
     if (n_maps <= 0 || height <= 0 || width <= 0 || k <= 0 || (int64_t)k > (int64_t)height * width) return BD_ERR_SHAPE;
     const int hw = height * width;
+#ifndef BD_DECODE_SLICES      // (measurement builds only: tools/r6_decode_probe.py times the round-1 slice kernel against the register-resident one)
+    // the register-resident form: at most 49 elements per thread (224 x 224), k small against a thread's share
+    if (hw <= 49 * 1024 && k <= 64) {
+        if (hw <= 16 * 1024)
+            hipLaunchKernelGGL(decode_kernel_regs<16>, dim3(n_maps), dim3(1024), 0, (hipStream_t)stream, heat, hw, width, height, k, kp_px, kp_norm, topk_idx);
+        else
+            hipLaunchKernelGGL(decode_kernel_regs<49>, dim3(n_maps), dim3(1024), 0, (hipStream_t)stream, heat, hw, width, height, k, kp_px, kp_norm, topk_idx);
+        BD_CHECK_LAUNCH();
+        return BD_OK;
+    }
+#endif
     if (hw % 1024 == 0 && ((uintptr_t)heat & 15) == 0)      // 256 slices of a multiple of 4 floats: float4 scans
         hipLaunchKernelGGL(decode_kernel<true>, dim3(n_maps), dim3(256), 0, (hipStream_t)stream, heat, hw, width, height,
                            k, kp_px, kp_norm, topk_idx);

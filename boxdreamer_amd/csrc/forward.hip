@@ -287,7 +287,8 @@ inline bool next_ln1_folds(const bd_block_weights& w, const BlockPlan& p, const 
 // other rows (the last decoder block), so its proj cannot read this block's copy.
 int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, int seq, int D, int heads, float ln_eps, float rms_eps,
               int wprec, void* stream, int n_prefix = 0, bool prefix_queries = true, bool ln1_folded = false,
-              const bd_block_weights* next = nullptr, bool* next_folded = nullptr, bool* x_stale = nullptr, bool next_compact = false) {
+              const bd_block_weights* next = nullptr, bool* next_folded = nullptr, bool* x_stale = nullptr, bool next_compact = false,
+              bool latency = false) {
     const BlockPlan p = plan_block(w, wprec);
     const int hd = D / heads;
     BD_TRY(qkv_stage(w, p, b, M, D, heads, ln_eps, rms_eps, stream, ln1_folded));
@@ -295,7 +296,8 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
     if (n_prefix > 0 && seq > n_prefix && !prefix_queries)
         BD_TRY(bd_attention_prefix(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)M * D, batch, seq, heads, hd, scale, n_prefix, 0, p.aprec, stream));
     else
-        BD_TRY(bd_attention(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)M * D, batch, seq, heads, hd, scale, p.aprec, stream));
+        BD_TRY(bd_attention_q_forms(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)M * D, batch, seq, heads, hd, scale, nullptr, seq, p.aprec,
+                                    latency ? 1 : 0, stream));
     const bool emit = next_ln1_folds(w, p, next, wprec, b, M, D, heads, ln_eps, rms_eps);
     if (next_folded) *next_folded = emit;
     bool next_c8 = false;
@@ -313,12 +315,13 @@ int run_block(const bd_block_weights& w, const BlockBufs& b, int M, int batch, i
 // compact [B*P, D] result; proj, LN2 and the MLP then run on B*P rows (1/T of the work).  Row-wise arithmetic is
 // unchanged, so the result is bit-identical to the full-width block.  xc: fp32 [B*P, D] compact residual stream.
 int run_last_block_query_only(const bd_block_weights& w, const BlockBufs& b, float* xc, const int32_t* query_idx, int B, int T, int P,
-                              int D, int heads, float ln_eps, float rms_eps, int wprec, void* stream, bool ln1_folded = false) {
+                              int D, int heads, float ln_eps, float rms_eps, int wprec, void* stream, bool ln1_folded = false,
+                              bool latency = false) {
     const BlockPlan p = plan_block(w, wprec);
     const int hd = D / heads, M = B * T * P, Mq = B * P;
     BD_TRY(qkv_stage(w, p, b, M, D, heads, ln_eps, rms_eps, stream, ln1_folded));
-    BD_TRY(bd_attention_q(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)Mq * D, B, T * P, heads, hd, 1.0f / sqrtf((float)hd), query_idx, P,
-                          p.aprec, stream));
+    BD_TRY(bd_attention_q_forms(b.qkv, (int64_t)M * 3 * D, b.ao, (int64_t)Mq * D, B, T * P, heads, hd, 1.0f / sqrtf((float)hd), query_idx, P,
+                                p.aprec, latency ? 1 : 0, stream));
     BD_TRY(bd_gather_query_rows_f32(b.x, query_idx, xc, B, T, P, D, stream));
     return proj_mlp_stage(w, p, b, xc, Mq, D, ln_eps, stream);
 }
@@ -481,18 +484,19 @@ extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_fea
     // K9: joint self-attention over all T*P tokens of a sample
     // (latency forms, one or two poses per call: the q, k / v column split of BD_PREC_F16C8_QK16 is two launches of ~20 us each where one
     // F16C8 QKV launch takes ~26 us -- at these sizes a launch costs its fixed part, not its passes; q, k then carry the full F16C8 product)
-    const int bprec = (w->latency_mode && Mb <= BD_SPLITK_MAX_ROWS && wprec == BD_PREC_F16C8_QK16) ? BD_PREC_F16C8 : wprec;
+    const bool lat = w->latency_mode && Mb <= BD_SPLITK_MAX_ROWS;
+    const int bprec = (lat && wprec == BD_PREC_F16C8_QK16) ? BD_PREC_F16C8 : wprec;
     bool folded = false, stale = false;      // LayerNorm 1 of block i is folded behind block i-1's fc2 (never block 0's); b.x is stale
     for (int i = 0; i + 1 < w->depth; ++i) {
         bool next_folded = false;
         BD_TRY(run_block(w->blocks[i], d.blk, Mb, B, T * P, D, w->heads, w->ln_eps, w->rms_eps, bprec, stream, 0, true, folded,
-                         &w->blocks[i + 1], &next_folded, &stale, /*next_compact=*/i + 2 == w->depth));
+                         &w->blocks[i + 1], &next_folded, &stale, /*next_compact=*/i + 2 == w->depth, lat));
         folded = next_folded;
     }
     if (stale) return BD_ERR_SHAPE;          // (the block in front of the last one writes fp32 rows: the last block gathers its query rows from them)
     // last block: query-view rows only past the K/V projection; d.t2 (dead since the adapter) holds the compact stream
     BD_TRY(run_last_block_query_only(w->blocks[w->depth - 1], d.blk, d.t2, query_idx, B, T, P, D, w->heads,
-                                     w->ln_eps, w->rms_eps, bprec, stream, folded));
+                                     w->ln_eps, w->rms_eps, bprec, stream, folded, lat));
     // K10: head on the query view's tokens (no final norm, betr.py:298-306)
     BD_TRY(bd_gather_query_tokens(d.t2, nullptr, d.qtok, (int64_t)Mq * D, B, 1, P, D, c_bp, stream));
     {

@@ -349,7 +349,10 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64, (WM * WN + NPW) <= 4 ? 2 : 1)
             }
             for (int sk = 0; sk < S - 1; ++sk) {
                 const int idx = (t * 3 + sk) * NCW + wid;
-                while (__hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+                // (bounded: ~1 s of polling.  A secondary of this launch is resident or done by construction -- it was dispatched first --
+                // so the bound is never reached in a healthy launch; it turns a lost flag into a wrong tile instead of a hung device.)
+                for (int spin = 0; spin < (1 << 24) && __hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
+                    __builtin_amdgcn_s_sleep(1);
                 asm volatile("" ::: "memory");
                 if (lane == 0) __hip_atomic_store(flags + idx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const f32x4* src = parts + (size_t)idx * (MI * NI * 4 * 64) + lane;
@@ -495,6 +498,8 @@ int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     // Every row's result is unchanged.
     const int tiles_small = ((a.M + 127) / 128) * ((a.N + 191) / 192);
     const bool small = s3 && ep != 0 && 2 * tiles * bd_concurrent_launches() <= cus;      // (sub-batch lanes: their launches share the CUs)
+    const bool small0 = ep == 0 && 2 * tiles * bd_concurrent_launches() <= cus;             // the generic epilogue's small form (either ring depth)
+    const dim3 g0(tiles_small < cus ? tiles_small : cus);
     const int grid = small ? (tiles_small < cus ? tiles_small : cus) : (tiles < cus ? tiles : cus);
     const dim3 g(grid), b(small ? 512 : 768);
 #define BD_C8_LAUNCH(EP_, OUTK_, GELU_)                                                                     \
@@ -550,7 +555,11 @@ int bd_launch_gemm_f16c8(const bd_gemm_args& a, hipStream_t s) {
     else if (ep == 1 && outk == OUT_OPERAND) BD_C8_LAUNCH(1, OUT_OPERAND, false)
     else if (ep == 1 && outk == OUT_F16) BD_C8_LAUNCH(1, OUT_F16, false)
     else if (ep == 1) BD_C8_LAUNCH(1, OUT_BF16X2, false)
-    else if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 0, OUT_OPERAND, false>), g, b, 0, s, a);      // generic epilogue: the big form only
+    // generic epilogue (table add, row remap, hand-offs between operand classes: the patch / heat-map embeddings, the adapter): round 6 gives
+    // it the small form too -- one pose at a time these launches were 24 workgroups of the large form, 64 us each (rows bit-identical)
+    else if (small0 && s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 0, OUT_OPERAND, false, 2, 2, 4>), g0, dim3(512), 0, s, a);
+    else if (small0) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, 0, OUT_OPERAND, false, 2, 2, 4>), g0, dim3(512), 0, s, a);
+    else if (s3) hipLaunchKernelGGL((gemm_kernel_pc_f16c8<3, 0, OUT_OPERAND, false>), g, b, 0, s, a);
     else hipLaunchKernelGGL((gemm_kernel_pc_f16c8<2, 0, OUT_OPERAND, false>), g, b, 0, s, a);
 #undef BD_C8_LAUNCH
 #undef BD_C8_LAUNCH_LN

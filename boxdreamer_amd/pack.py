@@ -42,6 +42,14 @@ def split_planes(w: torch.Tensor, prec) -> torch.Tensor:
     return torch.stack([hi, lo]).contiguous()
 
 
+def embed_k_multiple(prec) -> int:
+    """K padding of the two embedding GEMMs (patch embed: K = 588, heat-map embed: K = 1568 -- the only K of the path that the model does not
+    fix).  F16C8 family: a multiple of 192 (= 6 slabs of 32), so that these launches take the THREE-stage operand ring of gemm_kernel_pc_f16c8
+    like every other Linear (K / 32 % 3 == 0) instead of the two-stage form (~1.3 us per slab against ~0.7 one pose at a time, ~2800 against
+    ~2000 cycles at B = 32): 768 / 1728 instead of 640 / 1600 -- the padded columns are zeros on both operands, the sums do not change."""
+    return 192 if _lib.operand_prec(prec) == _lib.PREC_F16C8 else _lib.k_multiple(prec)
+
+
 def pack_linear_weight(weight: torch.Tensor, prec, kpad: int | None = None,
                        row_scale: torch.Tensor | None = None, return_scale: bool = False):
     """[N, K] fp32 -> [planes?, N, Kpad] operand dtype (row_scale folds LayerScale).
@@ -261,7 +269,7 @@ def pack_dino(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int
     grid = img_size // patch
     reg = sd.get("register_tokens")
     prefix, pos_patch = dino_pos_tables(sd["pos_embed"], sd["cls_token"], reg, grid)
-    kpad = round_up(3 * patch * patch, _lib.k_multiple(prec))
+    kpad = round_up(3 * patch * patch, embed_k_multiple(prec))
     blocks = (_lib.BlockWeights * depth)()
     for i in range(depth):
         blocks[i] = _pack_block(pk, sd, f"blocks.{i}.", prec, device, ls=f"blocks.{i}.ls1.gamma" in sd, qk_norm=False)
@@ -286,7 +294,7 @@ def pack_betr(sd: dict, prec, device, heads: int, patch: int = 14, img_size: int
     dim = sd["bbox_learnable_query"].shape[-1]
     depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("attn."))
     grid = img_size // patch
-    kpad = round_up(patch * patch * box_dim, _lib.k_multiple(prec))
+    kpad = round_up(patch * patch * box_dim, embed_k_multiple(prec))
     blocks = (_lib.BlockWeights * depth)()
     for i in range(depth):
         blocks[i] = _pack_block(pk, sd, f"attn.{i}.", prec, device, ls=False, qk_norm=True)
