@@ -91,7 +91,7 @@ class BoxDreamer(nn.Module):
         self.hip_graph = bool(module_configs.get("hip_graph", False))
         self._graph, self._graph_key = None, None
         # `hip_latency: true` in config["modules"]: opt into the latency forms for calls of one or two poses (the reference demo's per-frame
-        # call, src/demo/demo.py:1501-1514): the residual Linears run split-K (bd_*_weights.latency_mode, ABI 9) -- one pose 4.6 -> 3.9 ms.
+        # call, src/demo/demo.py:1501-1514): the residual Linears run split-K (bd_*_weights.latency_mode, ABI 9) -- one pose 4.6 -> 3.6 ms.
         # Deterministic and within the mode's tolerance, but a sample's bits then differ from the same sample inside a larger batch; off
         # by default, so that every row stays bit-identical across batch sizes, lanes and launch forms.
         if "hip_latency" in module_configs:
