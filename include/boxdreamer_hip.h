@@ -369,7 +369,8 @@ typedef struct bd_dino_weights {
                                         consumer's first Linear is promoted (BD_PROMOTE_ADAPTER_FC1) */
     int latency_mode;                /* ABI 9.  != 0: OPT-IN latency forms for calls of one or two poses (token stream <= BD_SPLITK_MAX_ROWS rows):
                                         the residual Linears of the F16C8 family may run split-K (bd_gemm_args.sk_ws; the workspace grows by
-                                        the scratch region).  Deterministic, within the mode's tolerance, but a sample's bits then depend on
+                                        the scratch region), BETR's QKV Linear runs as one F16C8 launch instead of the q,k / v column split,
+                                        and attention launches of a few 256-query blocks take the 128-query kernel.  Deterministic, within the mode's tolerance, but a sample's bits then depend on
                                         whether its call took the latency forms -- 0 (default) keeps every row bit-identical across batch
                                         sizes, lanes and launch forms.  src/demo/demo.py:1501-1514 (one query + its references per frame). */
 } bd_dino_weights;
