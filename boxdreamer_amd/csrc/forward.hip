@@ -516,7 +516,6 @@ extern "C" int bd_decoder_forward(const bd_betr_weights* w, const void* bbox_fea
 // the caller's capture).  What it buys: the kernels of one lane run on the CUs the other lane's ragged last round leaves idle and
 // the HBM-bound launches (LayerNorm) of one lane overlap the MFMA-bound launches of the other -- what two BATCHES in flight bought
 // in rounds 2-4, now inside one batch of configs[1] (profiles/r4_subbatch_lanes.md).
-#include <mutex>
 namespace {
 
 constexpr int kMaxLanes = 4, kMaxDevices = 64;
@@ -525,10 +524,12 @@ struct LaneSet {
     hipEvent_t fork, join[kMaxLanes - 1];
     bool ready = false;
 };
-std::mutex g_lane_mu;          // held for the whole host-side enqueue of a laned call: the events / side streams are per device
-LaneSet g_lanes[kMaxDevices];
+// Per HOST THREAD and device (round 6; process-global until then): a thread that captures `stream` into a HIP graph pulls ITS OWN side
+// streams into the capture and nobody else's -- two threads may enqueue laned calls on one device at the same time, capturing or not.
+// Created on first use (or by bd_lanes_prepare), never destroyed: a thread that exits leaves its three streams / four events behind.
+thread_local LaneSet g_lanes[kMaxDevices];
 
-int lanes_of_current_device(LaneSet** out) {      // caller holds g_lane_mu
+int lanes_of_current_device(LaneSet** out) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
@@ -562,7 +563,6 @@ inline int dtype_bytes(int dt) { return dt == BD_DTYPE_F32 ? 4 : 2; }
 // fork / join around the per-lane calls.  Every lane is enqueued even after an earlier one failed, and the joins are always
 // recorded, so that a capture in progress is left well-formed; the first error is returned.
 template <class F> int run_lanes(int lanes, hipStream_t main, F&& lane_call) {
-    std::lock_guard<std::mutex> guard(g_lane_mu);
     LaneSet* L = nullptr;
     BD_TRY(lanes_of_current_device(&L));
     hipError_t e = hipEventRecord(L->fork, main);
@@ -586,7 +586,6 @@ template <class F> int run_lanes(int lanes, hipStream_t main, F&& lane_call) {
 }  // namespace
 
 extern "C" int bd_lanes_prepare(void) {
-    std::lock_guard<std::mutex> guard(g_lane_mu);
     LaneSet* L = nullptr;
     return lanes_of_current_device(&L);
 }

@@ -14,7 +14,7 @@ from . import hip_ops
 
 class GraphedPath:
     def __init__(self, encoder, decoder, B: int, T: int, size: int = 224, in_dtype: torch.dtype = torch.bfloat16,
-                 device=None, want_idx: bool = False):
+                 device=None, want_idx: bool = False, capture_error_mode: str = "global"):
         self.encoder, self.decoder = encoder, decoder
         dev = torch.device("cuda") if device is None else torch.device(device)
         self.images = torch.zeros((B, T, 3, size, size), dtype=in_dtype, device=dev)
@@ -35,7 +35,10 @@ class GraphedPath:
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # capture_error_mode: torch's default ("global") makes unsafe CUDA calls of OTHER host threads -- an allocation, say -- invalidate
+        # this capture; a process whose other threads keep working on the device passes "thread_local" (the library's own side streams
+        # are per host thread: include/boxdreamer_hip.h, Sub-batch lanes)
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
             self.out = self._run()
         # The captured launches hold RAW device pointers into memory the modules own (workspaces allocated during the
         # warm-up above, packed weights).  (1) Keep those tensors alive on this object, so nothing the modules do later can

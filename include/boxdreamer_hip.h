@@ -11,7 +11,7 @@
  *   - the caller (PyTorch) owns every input / output / workspace buffer; the library never allocates or frees device memory,
  *     never synchronises the device, and reads no environment variables: everything that affects numerics or scheduling is an
  *     argument;
- *   - library-owned state, all of it: (1) per device, the side streams and fork / join events of the sub-batch lanes
+ *   - library-owned state, all of it: (1) per host thread and device, the side streams and fork / join events of the sub-batch lanes
  *     (bd_*_forward_lanes, created on first use or by bd_lanes_prepare, never destroyed; see "Sub-batch lanes" for what that
  *     means for concurrent callers), (2) the optional launch trace at the end of this file (off by default), (3) an immutable
  *     per-device cache of the compute-unit count, (4) a THREAD-LOCAL hint "this thread's bd_gemm launches run side by side with
@@ -411,12 +411,11 @@ int bd_decoder_forward(const bd_betr_weights* w /*[host]*/, const void* bbox_fea
  * kernels of one lane fill the CUs the other lane's ragged last round leaves idle.  `lanes` <= 1 (or more lanes than samples)
  * IS the plain form.  The workspace is the sum of the lanes' workspaces (*_workspace_bytes_lanes).  bd_lanes_prepare creates
  * the current device's side streams / events ahead of a stream capture (they are otherwise created on first use).
- * CONCURRENCY.  The side streams and the fork / join events are PROCESS-GLOBAL per device, and the host-side enqueue of a laned
- * call holds one mutex for its whole duration.  Consequences: (1) laned calls from several host threads on one device serialise
- * on the host and share the side streams -- correct, every call forks from and joins into ITS caller's stream; (2) a thread that
- * is CAPTURING `stream` into a HIP graph while another thread enqueues a laned call eagerly on the same device would pull that
- * thread's side-stream work into its capture (the side streams join the capture at the event wait): capture from one thread at a
- * time, or have the other threads call with lanes <= 1 (the plain, re-entrant form) while a capture is open. */
+ * CONCURRENCY.  The side streams and the fork / join events belong to the calling HOST THREAD (per device; round 6 -- they were
+ * process-global before): laned calls from several host threads on one device are independent, and a thread that is CAPTURING `stream`
+ * into a HIP graph pulls only its own side streams into the capture, whatever other threads enqueue meanwhile.  Call bd_lanes_prepare
+ * on the thread that will capture, before the capture opens (stream creation is not capturable).  The objects are never destroyed: a
+ * host thread that exits leaves its three side streams and four events behind. */
 int bd_lanes_prepare(void);
 size_t bd_encoder_workspace_bytes_lanes(const bd_dino_weights* w /*[host]*/, int n_images, int prec, int lanes);
 int bd_encoder_forward_lanes(const bd_dino_weights* w /*[host]*/, const void* images, int img_dtype,

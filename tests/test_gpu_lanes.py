@@ -176,3 +176,58 @@ def test_facade_runs_a_large_batch_as_two_lanes_and_says_so(hip):
         outs.append({k: out[k].clone() for k in ("pred_bbox", "pred_corners_px", "pred_poses", "regression_boxes")})
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_one_thread_captures_while_another_enqueues_laned_calls(hip):
+    """The lanes' side streams / events belong to the calling HOST THREAD (round 6; process-global before: a thread capturing next to a
+    thread enqueueing eagerly pulled the other thread's side-stream work into its capture).  Thread B runs eager two-lane
+    forwards in a loop while the main thread warms up, CAPTURES and replays the two-lane step of another module pair; both must give the
+    bits of their single-threaded runs."""
+    import threading
+    from boxdreamer_amd.graph import GraphedPath
+    prec, B, T = "f16c8_qk16", 4, 6
+    encA, decA = _build(prec)
+    encB, decB = _build(prec)
+    for e, d in ((encA, decA), (encB, decB)):
+        e.model.lanes, d.hip_lanes = 2, 2
+    dA, dB = synth.make_batch(seed=31, B=B, T=T), synth.make_batch(seed=32, B=B, T=T)
+    mask = torch.zeros(B, T, dtype=torch.bool); mask[:, T - 1] = True
+    mask = mask.cuda()
+    imgA, bfA = dA["images"].to(torch.bfloat16).cuda(), dA["bbox_feat"].to(torch.bfloat16).cuda()
+    imgB, bfB = dB["images"].to(torch.bfloat16).cuda(), dB["bbox_feat"].to(torch.bfloat16).cuda()
+
+    def eager(enc, dec, img, bf):
+        heat = dec(bf, img, mask, enc.predict(img), None)
+        return dec.last_logits.clone(), heat.clone()
+    refA, refB = eager(encA, decA, imgA, bfA), eager(encB, decB, imgB, bfB)
+    torch.cuda.synchronize()
+    stop, errs, runs = threading.Event(), [], [0]
+
+    def worker():
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                while not stop.is_set():
+                    got = eager(encB, decB, imgB, bfB)
+                    s.synchronize()
+                    if not (torch.equal(got[0], refB[0]) and torch.equal(got[1], refB[1])):
+                        errs.append("thread B's eager laned forward changed while thread A captured")
+                        return
+                    runs[0] += 1
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+    th = threading.Thread(target=worker)
+    th.start()
+    try:
+        while runs[0] < 2 and not errs:          # B is running before A starts to capture
+            torch.cuda.current_stream().synchronize()
+        g = GraphedPath(encA, decA, B, T, 224, torch.bfloat16, "cuda", capture_error_mode="thread_local")
+        for _ in range(5):
+            heat, kp, kn, _ = g(imgA, bfA)
+            torch.cuda.current_stream().synchronize()
+            assert torch.equal(heat, refA[1]), "the captured two-lane step differs from the single-threaded run"
+    finally:
+        stop.set()
+        th.join(60)
+    assert not errs, errs
+    assert runs[0] >= 3
