@@ -614,3 +614,34 @@ def test_dense_pose_rejects_a_bad_round_like_solvepnpransac():
     # fewer than six distinct 3-D points: the ITERATIVE solve of everything (the reference's fallback)
     ok, R, t, m = pnp.solve_pnp_ransac(b3[:5], uv[:5], K)
     assert m.all()
+
+
+def test_latency_opt_in_and_embedding_k_padding_host_side():
+    """Round 6 host logic (CPU): `modules.hip_latency` reaches both plugins and is off by default (the latency forms are an opt-in: their rows are
+    not bit-identical to the same sample inside a larger batch, include/boxdreamer_hip.h bd_*_weights.latency_mode); the F16C8 family pads the
+    two embedding GEMMs' K to multiples of 192 (three-stage operand ring), every other class keeps its own granularity; the weight structs
+    carry the ABI-9 field at the offset the C header gives it (last member)."""
+    import copy
+    from boxdreamer_amd.model import BoxDreamer
+    mods = copy.deepcopy(json.load(open(os.path.join(ROOT, "tests", "golden", "model_modules_config.json")))["modules"])
+    mods["encoder"]["dino"]["cfg"].update(synthetic_seed=1, depth=1)
+    mods["decoder"]["num_decoder_layers"] = 1
+    m = BoxDreamer({"modules": copy.deepcopy(mods)})
+    assert m.decoder.hip_latency is False and m.rgb_encoder.model.latency is False
+    mods["hip_latency"] = True
+    m = BoxDreamer({"modules": mods})
+    assert m.decoder.hip_latency is True and m.rgb_encoder.model.latency is True
+    for prec, want in (("f16c8_qk16", (768, 1728)), ("f16c8", (768, 1728)), ("bf16", (640, 1600)), ("bf16x3", (640, 1600)), ("fp8", (640, 1664))):
+        assert pack.embed_k_multiple(prec) in (64, 128, 192)
+        kd = pack.pack_dino(synth.dino_state_dict(4321, 1), prec, "cpu", 12).struct.kpad
+        kb = pack.pack_betr(synth.betr_state_dict(1234, 1), prec, "cpu", 8).struct.kpad
+        assert (kd, kb) == want, (prec, kd, kb)
+        assert kd % 64 == 0 and kb % 64 == 0 and kd >= 588 and kb >= 1568
+    assert _lib.DinoWeights._fields_[-1][0] == "latency_mode" and _lib.BetrWeights._fields_[-1][0] == "latency_mode"
+    assert _lib.GemmArgs._fields_[-2][0] == "sk_ws" and _lib.GemmArgs._fields_[-1][0] == "sk_split"
+    hdr = open(os.path.join(ROOT, "include", "boxdreamer_hip.h")).read()
+    for sym in ("bd_gemm_splitk_workspace_bytes", "bd_gemm_splitk_flag_bytes", "BD_SPLITK_MAX_ROWS", "BD_SPLITK_FLAG_BYTES", "latency_mode", "sk_ws"):
+        assert sym in hdr, sym
+    lib = _lib.load()
+    assert lib.bd_gemm_splitk_workspace_bytes(1536, 768) == 16384 + 96 * 3 * 2 * 64 * 96 * 4
+    assert lib.bd_gemm_splitk_workspace_bytes(8192, 768) == 0 and lib.bd_gemm_splitk_workspace_bytes(1536, 1000) == 0
