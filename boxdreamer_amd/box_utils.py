@@ -31,7 +31,26 @@ def recover_bb8_corners_chw(heat: torch.Tensor, want_idx: bool = False):
     return kn, kp, idx
 
 
-def solve_poses_host(kp_px: np.ndarray, bbox_3d: np.ndarray, K: np.ndarray, workers: int = 8) -> np.ndarray:
+def _host_workers() -> int:
+    """Threads of the native host solver: the CPUs this process may use (affinity and cgroup quota), at most 16."""
+    global _WORKERS
+    if _WORKERS is None:
+        import os
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+        except Exception:  # noqa: BLE001
+            pass
+        _WORKERS = max(1, min(16, n))
+    return _WORKERS
+
+
+_WORKERS = None
+
+
+def solve_poses_host(kp_px: np.ndarray, bbox_3d: np.ndarray, K: np.ndarray, workers: int | None = None) -> np.ndarray:
     """kp_px [N,8,2], bbox_3d [N,8,3], K [N,3,3] (host) -> poses [N,4,4] ([R|t], zeros on failure).
     One batched solve for all N poses ("next" row f3: no per-sample Python loop; pnp.solve_pnp_batched)."""
     n = kp_px.shape[0]
@@ -46,7 +65,8 @@ def solve_poses_host(kp_px: np.ndarray, bbox_3d: np.ndarray, K: np.ndarray, work
         try:
             lib = _lib.load()
             kp32, p32, K32 = (np.ascontiguousarray(a, np.float32) for a in (kp_px, bbox_3d, K))
-            rc = lib.bd_solve_pnp_host(kp32.ctypes.data, p32.ctypes.data, K32.ctypes.data, n, kp32.shape[1], 30, out.ctypes.data, workers)
+            rc = lib.bd_solve_pnp_host(kp32.ctypes.data, p32.ctypes.data, K32.ctypes.data, n, kp32.shape[1], 30, out.ctypes.data,
+                                       _host_workers() if workers is None else workers)
             if rc == 0:
                 return out
             out[:] = 0.0

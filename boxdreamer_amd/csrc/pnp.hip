@@ -9,6 +9,10 @@
 #include "bd_common.h"
 #include <cmath>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <unistd.h>
 #include <vector>
 
 namespace {
@@ -276,6 +280,62 @@ __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ kp, c
 
 }  // namespace
 
+// Host worker threads of bd_solve_pnp_host, kept between calls (round 6: starting seven std::threads per call was ~0.25 ms of the 0.36 ms
+// a batch of 32 poses took -- device idle time in a facade forward, profiles/r6_facade_gaps.txt).  Library-owned HOST state (no device state):
+// up to 15 detached threads per process, parked on a condition variable; one call at a time uses them (a mutex serialises callers); a forked
+// child finds the parent's pid in the pool and starts its own.  Never torn down.
+namespace {
+struct HostPool {
+    std::mutex m;
+    std::condition_variable wake, done;
+    const std::function<void(int)>* job = nullptr;
+    int threads = 0, nt = 0, gen = 0, pending = 0;
+    pid_t pid = 0;
+};
+std::mutex g_pool_mu;
+HostPool* g_pool = nullptr;
+
+void host_pool_worker(HostPool* P, int t) {
+    int seen = 0;
+    for (;;) {
+        std::unique_lock<std::mutex> lk(P->m);
+        P->wake.wait(lk, [&] { return P->gen != seen; });
+        seen = P->gen;
+        const std::function<void(int)>* job = P->job;
+        const bool mine = t < P->nt;
+        lk.unlock();
+        if (!mine) continue;
+        (*job)(t);
+        lk.lock();
+        if (--P->pending == 0) P->done.notify_one();
+    }
+}
+
+void host_pool_run(int nt, const std::function<void(int)>& job) {      // job(0) on the caller, job(1 .. nt-1) on the pool
+    std::lock_guard<std::mutex> callers(g_pool_mu);
+    if (!g_pool || g_pool->pid != getpid() || g_pool->threads < nt - 1) {
+        HostPool* P = new HostPool();                                    // (an older / inherited pool is left behind, its threads parked or gone)
+        P->pid = getpid();
+        P->threads = nt - 1 > 15 ? nt - 1 : 15;
+        for (int t = 1; t <= P->threads; ++t) std::thread(host_pool_worker, P, t).detach();
+        g_pool = P;
+    }
+    HostPool* P = g_pool;
+    {
+        std::lock_guard<std::mutex> lk(P->m);
+        P->job = &job;
+        P->nt = nt;
+        P->pending = nt - 1;
+        ++P->gen;
+    }
+    P->wake.notify_all();
+    job(0);
+    std::unique_lock<std::mutex> lk(P->m);
+    P->done.wait(lk, [&] { return P->pending == 0; });
+    P->job = nullptr;
+}
+}  // namespace
+
 // The host form ("PnP post-solve stays on the host CPU", north_star): the same per-pose solver on a pool of host threads, poses
 // dealt out in contiguous chunks.  All pointers are HOST pointers.  Replaces the per-sample Python loop around cv2.solvePnP of
 // src/models/utils/box_utils.py:139-199 when OpenCV is not importable (and the single-threaded numpy restatement of round 2:
@@ -293,11 +353,7 @@ extern "C" int bd_solve_pnp_host(const float* kp_px, const float* pts3, const fl
                            poses + (size_t)i * 16);
     };
     if (nt <= 1) { work(0); return BD_OK; }
-    std::vector<std::thread> pool;
-    pool.reserve(nt - 1);
-    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto& th : pool) th.join();
+    host_pool_run(nt, work);
     return BD_OK;
 }
 

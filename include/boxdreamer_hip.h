@@ -13,7 +13,9 @@
  *     argument;
  *   - library-owned state, all of it: (1) per host thread and device, the side streams and fork / join events of the sub-batch lanes
  *     (bd_*_forward_lanes, created on first use or by bd_lanes_prepare, never destroyed; see "Sub-batch lanes" for what that
- *     means for concurrent callers), (2) the optional launch trace at the end of this file (off by default), (3) an immutable
+ *     means for concurrent callers), (2) the optional launch trace at the end of this file (off by default), (2b) HOST state only: up to 15
+ *     detached worker threads of bd_solve_pnp_host, parked on a condition variable between calls (one call at a time uses them; a forked
+ *     child starts its own), (3) an immutable
  *     per-device cache of the compute-unit count, (4) a THREAD-LOCAL hint "this thread's bd_gemm launches run side by side with
  *     n - 1 others of the same shape" (1 outside the laned entry points, which set it for the duration of their enqueue and reset it
  *     before they return): it only biases the choice between kernel FORMS of a launch (large / small tiles) towards the CUs' share
