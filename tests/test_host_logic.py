@@ -645,3 +645,58 @@ def test_latency_opt_in_and_embedding_k_padding_host_side():
     lib = _lib.load()
     assert lib.bd_gemm_splitk_workspace_bytes(1536, 768) == 16384 + 96 * 3 * 2 * 64 * 96 * 4
     assert lib.bd_gemm_splitk_workspace_bytes(8192, 768) == 0 and lib.bd_gemm_splitk_workspace_bytes(1536, 1000) == 0
+
+
+def test_native_pnp_worker_pool_is_reused_thread_safe_and_survives_a_fork():
+    """Round 6: bd_solve_pnp_host keeps its worker threads between calls (csrc/pnp.hip: host_pool_run).  The same poses must come out (a) of
+    repeated calls with changing thread counts, (b) of several Python threads calling at once (one call at a time uses the pool; ctypes drops
+    the GIL around the call), (c) of a forked child, which must start its own pool instead of waiting for the parent's threads."""
+    import threading
+    from boxdreamer_amd.box_utils import solve_poses_host
+    rng = np.random.default_rng(3)
+    N = 32
+    box = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], float) * [0.1, 0.07, 0.05]
+    p3 = np.tile(box, (N, 1, 1)).astype(np.float32)
+    K = np.tile(np.array([[600.0, 0, 112], [0, 600, 112], [0, 0, 1]]), (N, 1, 1)).astype(np.float32)
+    p2 = np.zeros((N, 8, 2), np.float32)
+    for i in range(N):
+        R = pnp.rodrigues(rng.normal(size=3) * 0.9)
+        pc = box @ R.T + np.array([0.0, 0.0, 0.7 + 0.01 * i])
+        p2[i] = pc[:, :2] / pc[:, 2:3] * 600 + 112
+    ref = solve_poses_host(p2, p3, K, workers=1)
+    assert (ref[:, 3, 3] == 1.0).all()
+    for workers in (16, 2, 8, 16, 5, None):
+        assert np.array_equal(solve_poses_host(p2, p3, K, workers=workers), ref), workers
+    bad = []
+
+    def hammer():
+        for _ in range(20):
+            if not np.array_equal(solve_poses_host(p2, p3, K, workers=8), ref):
+                bad.append(1)
+    ths = [threading.Thread(target=hammer) for _ in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(120)
+    assert not bad and not any(t.is_alive() for t in ths)
+    pid = os.fork()
+    if pid == 0:                                   # the child: the parent's worker threads do not exist here
+        try:
+            ok = np.array_equal(solve_poses_host(p2, p3, K, workers=8), ref)
+            os._exit(0 if ok else 3)
+        except BaseException:                      # noqa: BLE001
+            os._exit(4)
+    deadline, status = 60.0, None
+    import time
+    t0 = time.time()
+    while time.time() - t0 < deadline:
+        done, st = os.waitpid(pid, os.WNOHANG)
+        if done:
+            status = st
+            break
+        time.sleep(0.05)
+    if status is None:
+        os.kill(pid, 9)
+        os.waitpid(pid, 0)
+        raise AssertionError("the forked child hung in bd_solve_pnp_host (it waited for the parent's worker threads)")
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
