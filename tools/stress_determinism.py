@@ -1,4 +1,4 @@
-"""Race screen (python tools/stress_determinism.py <prec> <runs> [batch] [lanes]): the full-depth step (T=6; default B=32) repeated N times must give bit-identical logits
+"""Race screen (python tools/stress_determinism.py <prec> <runs> [batch] [lanes] [latency]): the full-depth step (T=6; default B=32) repeated N times must give bit-identical logits
 every time (LDS-DMA / barrier schedules: a RAW race shows up as rare differing tiles).  The reference run is the ONE-LANE step; the repeated runs use `lanes`
 ("auto" by default: two sub-batch lanes at B >= 11), so a cross-lane overlap of workspace slices or a missing join shows up here too."""
 import sys, os
@@ -22,6 +22,8 @@ bf = small["bbox_feat"].repeat(rep, 1, 1, 1, 1).to(torch.bfloat16).cuda()
 mask = torch.zeros(img.shape[0], 6, dtype=torch.bool, device="cuda"); mask[:, 5] = True
 lanes = sys.argv[4] if len(sys.argv) > 4 else "auto"
 lanes = lanes if lanes == "auto" else int(lanes)
+if len(sys.argv) > 5 and sys.argv[5] == "latency":      # the opt-in latency forms (split-K hand-over through flags: a lost / early flag would show up as differing tiles)
+    enc.model.latency, dec.hip_latency = True, True
 enc.model.lanes, dec.hip_lanes = 1, 1
 dec(bf, img, mask, enc.predict(img), None)
 ref = dec.last_logits.clone()
@@ -33,4 +35,4 @@ for i in range(n):
     if not torch.equal(ref, l):
         bad += 1
         print("run", i, "differs: max", (ref - l).abs().max().item(), "count", int((ref != l).sum()))
-print(f"{prec} B={img.shape[0]} lanes={lanes}: {n} runs against the one-lane step, {bad} differing")
+print(f"{prec} B={img.shape[0]} lanes={lanes}{' latency forms' if dec.hip_latency else ''}: {n} runs against the one-lane step, {bad} differing")
